@@ -1,0 +1,91 @@
+"""Deterministic synthetic weights / inputs shared by the golden generator (tools/make_goldens.py),
+the oracle checks and the GPU parity tests.
+
+Everything here is derived from numpy ``RandomState`` streams keyed by *name*, so the values do not
+depend on torch's RNG, on construction order, or on which process (reference import vs. this repo's
+own modules) asks for them.  Data only -- no reference code involved.
+"""
+import zlib
+
+import numpy as np
+
+
+def _rng(name, seed):
+    return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+
+
+def synth_param(name, shape, seed=0):
+    """Value for one state-dict entry.  Rules are keyed on the *suffix* of the reference key names
+    (checkpoint row) so the same function serves backbone, FPN and decoders."""
+    shape = tuple(int(s) for s in shape)
+    rng = _rng(name, seed)
+    if len(shape) == 0:
+        return np.float32(1.0)                       # e.g. embedding_head.time_scale
+    n = rng.standard_normal(shape).astype(np.float32)
+    if len(shape) >= 2:                              # conv weight [Cout, Cin, k...]: He-normal
+        fan_in = int(np.prod(shape[1:]))
+        return (n * np.float32(np.sqrt(2.0 / fan_in))).astype(np.float32)
+    if name.endswith("running_var"):
+        return (0.5 + 0.5 * np.abs(n)).astype(np.float32)
+    if name.endswith("running_mean"):
+        return (0.1 * n).astype(np.float32)
+    if name.endswith("bn3.weight"):                  # keep the residual branch small -> no blow-up
+        return (0.3 + 0.05 * n).astype(np.float32)
+    if name.endswith(".weight"):                     # GroupNorm / FrozenBN scale
+        return (1.0 + 0.2 * n).astype(np.float32)
+    return (0.1 * n).astype(np.float32)              # every bias
+
+
+def synth_state_dict(named_shapes, seed=0, prefix=""):
+    """named_shapes: iterable of (key, shape).  Returns {key: np.float32 array}."""
+    return {k: synth_param(prefix + k, s, seed) for k, s in named_shapes}
+
+
+def synth_features(T, H32, W32, C=256, seed=0, dtype=np.float32):
+    """Four FPN-like feature stacks [C, T, h, w] ordered 32x, 16x, 8x, 4x."""
+    out = []
+    for i, s in enumerate((1, 2, 4, 8)):
+        rng = _rng("feat%d" % i, seed)
+        out.append(rng.standard_normal((C, T, H32 * s, W32 * s)).astype(dtype))
+    return out
+
+
+def synth_frames(T, H, W, seed=0):
+    """uint8 BGR frames [T, H, W, 3]."""
+    return np.random.RandomState(seed).randint(0, 256, size=(T, H, W, 3)).astype(np.uint8)
+
+
+def synth_cluster_case(T, H, W, K, E=4, Ev=2, seed=0, bg_fraction=0.15, noise=0.05,
+                       free_dims=2, seed_peak=1.0):
+    """Structured head outputs: K instances as moving boxes (SURVEY.md section 8(d) 'clustering driver').
+
+    Returns emb [E,T,H,W], bw [Ev,T,H,W], seed [1,T,H,W] (float32) and fg [T,H,W] uint8.
+    Instance centres are spread on a lattice so that clusters are well separated (margin cases);
+    background pixels get far-away embeddings and low seediness.
+    """
+    rng = np.random.RandomState(1000 + seed)
+    emb = (10.0 + 3.0 * rng.standard_normal((E, T, H, W))).astype(np.float32)
+    bw = (25.0 + rng.uniform(0, 1, size=(Ev, T, H, W))).astype(np.float32)
+    sd = rng.uniform(0, 0.2, size=(1, T, H, W)).astype(np.float32)
+    fg = np.zeros((T, H, W), np.uint8)
+    if K > 0:
+        cols = int(np.ceil(np.sqrt(K)))
+        bh, bw_ = max(2, H // (cols + 1)), max(2, W // (cols + 1))
+        for k in range(K):
+            cy, cx = (k // cols), (k % cols)
+            y0 = int(cy * (H - bh) / max(cols - 1, 1))
+            x0 = int(cx * (W - bw_) / max(cols - 1, 1))
+            centre = np.array([-1.5 + 3.0 * (cy + 0.5) / cols, -1.5 + 3.0 * (cx + 0.5) / cols] +
+                              [0.6 * ((k * 7) % 5 - 2) for _ in range(E - 2)], np.float32)[:E]
+            for t in range(T):
+                dx = min(t, max(W - (x0 + bw_), 0))      # box drifts right, clipped
+                ys, xs = slice(y0, y0 + bh), slice(x0 + dx, x0 + dx + bw_)
+                nz = (noise * rng.standard_normal((E, bh, bw_))).astype(np.float32)
+                emb[:, t, ys, xs] = centre[:, None, None] + nz
+                nrm = np.sqrt((nz ** 2).sum(0))
+                sd[0, t, ys, xs] = np.clip(seed_peak - nrm, 0, 1)
+                fg[t, ys, xs] = 1
+    # sprinkle some background into the fg mask so outliers (-1) exist
+    extra = rng.uniform(size=(T, H, W)) < bg_fraction * 0.1
+    fg = np.where(extra, 1, fg).astype(np.uint8)
+    return emb, bw, sd, fg

@@ -1,0 +1,137 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by the reference itself
+(tools/make_goldens.py -> tests/golden/*.npz).  Float outputs <= 1e-5, integer outputs exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder as odec
+from oracle import encoder as oenc
+from oracle import pipeline as opipe
+from oracle.clusterer import sequential_clustering
+from tests import synth
+
+TOL = 1e-5
+
+
+def _dec_sd(prefix, seed, **kw):
+    return synth.synth_state_dict(odec.decoder_param_shapes(prefix, **kw), seed)
+
+
+@pytest.mark.parametrize("T", [8, 16, 4])
+def test_embedding_decoder(golden, T):
+    g = golden("decoder_T%d" % T)
+    names = [k for k in g.files if k.startswith("emb_") and "__" not in k]
+    assert names
+    for name in names:
+        E, h32, w32, ws, tanh, so = g[name + "__meta"].tolist()
+        mode = str(g[name + "__mode"])
+        sd = _dec_sd("embedding_head.", ws, mode=mode, embedding_size=E, seediness_output=bool(so))
+        feats = synth.synth_features(T, h32, w32, seed=ws)
+        out = odec.embedding_decoder(feats, sd, mode, bool(tanh)).numpy()
+        assert out.shape == g[name].shape
+        assert np.abs(out - g[name]).max() <= TOL, name
+
+
+@pytest.mark.parametrize("T", [8, 16, 4])
+def test_seediness_decoder(golden, T):
+    g = golden("decoder_T%d" % T)
+    _, h32, w32, ws, _, _ = g["seediness__meta"].tolist()
+    sd = _dec_sd("seediness_head.", ws, kind="seediness")
+    out = odec.seediness_decoder(synth.synth_features(T, h32, w32, seed=ws), sd).numpy()
+    assert np.abs(out - g["seediness"]).max() <= TOL
+
+
+@pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
+def test_encoder(golden, btype):
+    g = golden("encoder")
+    tag = btype.replace("-", "")
+    H, W, seed, stride = g[tag + "__meta"].tolist()
+    sd = synth.synth_state_dict(oenc.backbone_param_shapes(btype), seed)
+    x = synth.synth_frames(2, H, W, seed=seed).astype(np.float32)
+    x = torch.from_numpy(x).permute(0, 3, 1, 2) - torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    feats = oenc.resnet_fpn(x, sd, btype)
+    for s in (4, 8, 16, 32):
+        ref = g["%s_s%d" % (tag, s)]
+        assert list(feats[s].shape) == g["%s_s%d__shape" % (tag, s)].tolist()
+        got = feats[s].numpy().reshape(-1)[::stride]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= TOL * scale, (btype, s)
+
+
+def _run_cluster_case(c, n):
+    p = c[n + "__params"]
+    nfree = int(p[3])
+    return sequential_clustering(c[n + "__emb"], c[n + "__bw"], c[n + "__seed"], label_start=int(p[2]),
+                                 min_seediness=p[0], max_instances=int(p[1]), free_dim_stds=p[4:4 + nfree],
+                                 return_masks=True)
+
+
+def test_clusterer_bit_exact(golden):
+    c = golden("cluster")
+    for n in c["__names"]:
+        n = str(n)
+        labels, meta = _run_cluster_case(c, n)
+        E = c[n + "__emb"].shape[1]
+        assert labels.dtype == np.int64
+        assert np.array_equal(labels, c[n + "__labels"]), n
+        assert meta["instance_labels"] == c[n + "__instance_labels"].tolist(), n
+        assert np.array_equal(np.array(meta["instance_centers"], np.float32).reshape(-1, E), c[n + "__centers"]), n
+        assert np.array_equal(np.array(meta["instance_stds"], np.float32).reshape(-1, E), c[n + "__stds"]), n
+        masks = np.stack(meta["instance_masks"]) if meta["instance_masks"] else np.zeros((0, labels.shape[0]), bool)
+        assert np.array_equal(masks, c[n + "__masks"]), n
+
+
+def test_clusterer_quirks_documented(golden):
+    """farthest-centre secondary assignment and the stale mask are reproduced on purpose."""
+    c = golden("cluster")
+    assert c["quirk_max_distance__labels"].tolist() == [1, 1, 1, -1, 2]
+    assert c["quirk_stale_mask__labels"].tolist() == [5, 5, 5, 5, 6, -1]
+
+
+def test_model_davis_embed_path(golden):
+    """encoder -> two decoders -> channel split -> exp*10, per clip incl. the short-video dedup case, and the
+    seediness-averaged fg mask (inference_model.py:130-162, inference/main.py:93-103)."""
+    g = golden("model_davis")
+    names = (oenc.backbone_param_shapes("R-50-FPN") +
+             odec.decoder_param_shapes("embedding_head.", mode="xyff", embedding_size=4) +
+             odec.decoder_param_shapes("seediness_head.", kind="seediness"))
+    sd = synth.synth_state_dict(names, 21)
+    mean = torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    for tag, nframes in (("seq12", 12), ("seq5", 5)):
+        frames = torch.from_numpy(synth.synth_frames(nframes, 96, 128, seed=21).astype(np.float32)).permute(0, 3, 1, 2) - mean
+        clips = []
+        for i, sub in enumerate(g[tag + "__subseqs"].tolist()):
+            emb, bw, seed = opipe.embed_clip(frames[sub], sd, "R-50-FPN", "xyff", 4, True)
+            uniq = sorted(set(sub))
+            sel = [sub.index(t) if sub.count(t) == 1 else max(j for j, v in enumerate(sub) if v == t) for t in uniq]
+            emb, bw, seed = emb[:, sel], bw[:, sel], seed[:, sel]
+            assert g["%s_c%d_frames" % (tag, i)].tolist() == uniq
+            for got, key in ((emb, "emb"), (bw, "bw"), (seed, "seed")):
+                ref = g["%s_c%d_%s" % (tag, i, key)]
+                assert np.abs(got.numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (tag, i, key)
+            clips.append((uniq, torch.from_numpy(g["%s_c%d_seed" % (tag, i)])))
+        fg = opipe.fg_mask_from_seediness(clips, float(g[tag + "__fg_thr"]))
+        assert np.array_equal(fg.numpy(), g[tag + "__fg"])
+
+
+def test_grid_vectors(golden):
+    g = golden("misc")
+    for key in [k for k in g.files if k.startswith("grid_") and k.endswith("_x")]:
+        _, H, W, T, _ = key.split("_")
+        t, y, x = odec.grid_vectors(int(H), int(W), int(T))
+        base = key[:-2]
+        assert np.array_equal(t.numpy(), g[base + "_t"]) and np.array_equal(y.numpy(), g[base + "_y"]) \
+            and np.array_equal(x.numpy(), g[base + "_x"])
+    for m, nd, nf in zip(g["modes"], g["modes__nb_dims"], g["modes__nb_free"]):
+        m = str(m)
+        assert odec.nb_embedding_dims(m) == nd and odec.nb_free_dims(m) == nf
+        z = torch.zeros(int(nd), 3, 4, 6)
+        assert np.array_equal(odec.add_offset(z, m).numpy(), g["offset_" + m])
+
+
+def test_gather_order():
+    emb, bw, sd, fg = synth.synth_cluster_case(3, 6, 7, 2, seed=1)
+    e, b, s, counts = opipe.gather_fg(emb, bw, sd, fg)
+    ts, ys, xs = np.nonzero(fg)
+    assert np.array_equal(e, emb[:, ts, ys, xs].T) and np.array_equal(s[:, 0], sd[0, ts, ys, xs])
+    assert counts.tolist() == [int(fg[t].sum()) for t in range(3)]

@@ -1,0 +1,379 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container: it imports the reference from
+/root/reference through tools/ref_shim.py, feeds it the deterministic synthetic inputs/weights of
+tests/synth.py and stores the *outputs* (plus tiny hand-made inputs) as .npz fixtures under
+tests/golden/.  The reference publishes no tests or golden vectors of its own,
+so these files are what pins the oracle and the host logic.
+
+    python tools/make_goldens.py            # regenerate everything (spawns one process per cfg preset,
+                                            # because the reference's `cfg` is a process-global singleton)
+    python tools/make_goldens.py --group dec_T8
+
+Fixtures are data only: inputs and expected outputs.  No reference source text is stored.
+"""
+import argparse
+import os
+import subprocess
+import sys
+from functools import partial
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from tests import synth  # noqa: E402
+
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "encoder", "model_davis", "cluster", "chainer", "misc"]
+
+
+def _save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-40s %8.1f kB" % (os.path.relpath(path, ROOT), os.path.getsize(path) / 1e3))
+
+
+def _load_synth_weights(module, seed, prefix=""):
+    import torch
+    sd = module.state_dict()
+    new = {k: torch.from_numpy(np.asarray(synth.synth_param(prefix + k, v.shape, seed))).reshape(v.shape)
+           for k, v in sd.items()}
+    module.load_state_dict(new)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_decoders(T):
+    import ref_shim
+    ref_shim.install(num_frames=T)
+    import torch
+    import torch.nn as nn
+    from stemseg.modeling.embedding_decoder import EMBEDDING_HEAD_REGISTRY
+    from stemseg.modeling.seediness_decoder import SEEDINESS_HEAD_REGISTRY
+    Emb = EMBEDDING_HEAD_REGISTRY["squeeze_expand_decoder"]
+    Seed = SEEDINESS_HEAD_REGISTRY["squeeze_expand_decoder"]
+    norm = partial(nn.GroupNorm, 32)
+    inter = [256, 256, 128, 128]
+
+    cases = [
+        # name,            E, mode,   tanh,  seed_out, H32, W32, wseed
+        ("emb_xyff_noseed", 4, "xyff", True,  False,    3,   4,   1),
+        ("emb_xyff_seed",   4, "xyff", True,  True,     3,   5,   2),
+        ("emb_xyt_seed",    3, "xyt",  True,  True,     4,   3,   3),
+        ("emb_xytf_notanh", 4, "xytf", False, True,     3,   3,   4),
+        ("emb_xy",          2, "xy",   True,  False,    3,   3,   5),
+    ]
+    if T != 8:
+        cases = cases[:2]
+    out = {}
+    with torch.no_grad():
+        for name, E, mode, tanh, so, h32, w32, ws in cases:
+            head = Emb(256, inter, E, tanh_activation=tanh, seediness_output=so, experimental_dims=mode,
+                       PoolType=nn.AvgPool3d, NormType=norm).eval()
+            _load_synth_weights(head, ws, prefix="embedding_head.")
+            feats = [torch.from_numpy(f)[None] for f in synth.synth_features(T, h32, w32, seed=ws)]
+            y = head(feats)[0].numpy()
+            out[name] = y
+            out[name + "__meta"] = np.array([E, h32, w32, ws, int(tanh), int(so)], np.int64)
+            out[name + "__mode"] = np.array(mode)
+        head = Seed(256, inter, PoolType=nn.AvgPool3d, NormType=norm).eval()
+        _load_synth_weights(head, 6, prefix="seediness_head.")
+        feats = [torch.from_numpy(f)[None] for f in synth.synth_features(T, 3, 4, seed=6)]
+        out["seediness"] = head(feats)[0].numpy()
+        out["seediness__meta"] = np.array([0, 3, 4, 6, 0, 0], np.int64)
+    _save("decoder_T%d" % T, **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_encoder():
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    from stemseg.modeling.backbone import BACKBONE_REGISTRY
+    out = {}
+    with torch.no_grad():
+        for btype, hw, seed, stride in (("R-50-FPN", (64, 96), 11, 3), ("R-101-FPN", (64, 64), 12, 5)):
+            cfg.MODEL.BACKBONE.update_param("TYPE", btype)
+            bb = BACKBONE_REGISTRY[btype](cfg).eval()
+            _load_synth_weights(bb, seed, prefix="backbone.")
+            x = synth.synth_frames(2, hw[0], hw[1], seed=seed).astype(np.float32)
+            x = torch.from_numpy(x).permute(0, 3, 1, 2) - torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+            feats = bb(x)
+            tag = btype.replace("-", "")
+            for s, f in zip((4, 8, 16, 32), feats):
+                out["%s_s%d" % (tag, s)] = f.numpy().reshape(-1)[::stride].copy()
+                out["%s_s%d__shape" % (tag, s)] = np.array(f.shape, np.int64)
+            out[tag + "__meta"] = np.array([hw[0], hw[1], seed, stride], np.int64)
+    _save("encoder", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_model_davis():
+    """InferenceModel.forward end-to-end on the DAVIS preset with an R-50 backbone (BASELINE config 0
+    scaled down), windowing via get_subsequence_frames, fg mask via get_fg_masks_from_seediness."""
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    cfg.merge_from_file(os.path.join(ref_shim.REFERENCE_ROOT, "stemseg", "config", "davis_1.yaml"))
+    cfg.INPUT.update_param("MIN_DIM", 96)
+    cfg.INPUT.update_param("MAX_DIM", 128)
+    cfg.MODEL.BACKBONE.update_param("TYPE", "R-50-FPN")
+    from stemseg.modeling.inference_model import InferenceModel
+    from stemseg.inference.main import get_subsequence_frames, TrackGenerator
+
+    model = InferenceModel(None, cpu_workers=0, preload_images=False, semseg_output_type=None, resize_scale=1.0)
+    _load_synth_weights(model._model, 21)
+    out = {}
+    for tag, nframes, overlap in (("seq12", 12, 4), ("seq5", 5, 4)):
+        frames = synth.synth_frames(nframes, 96, 128, seed=21)
+        subseqs, _ = get_subsequence_frames(nframes, 8, "davis", overlap)
+        res = model([f for f in frames], subseqs)
+        out[tag + "__subseqs"] = np.array(subseqs, np.int64)
+        for i, e in enumerate(res["embeddings"]):
+            out["%s_c%d_frames" % (tag, i)] = np.array(e.subseq_frames, np.int64)
+            out["%s_c%d_emb" % (tag, i)] = e.embeddings.numpy()
+            out["%s_c%d_bw" % (tag, i)] = e.bandwidths.numpy()
+            out["%s_c%d_seed" % (tag, i)] = e.seediness.numpy()
+        allseed = np.concatenate([e.seediness.numpy().ravel() for e in res["embeddings"]])
+        thr = float(np.median(allseed))
+
+        class _Fake:
+            seediness_fg_threshold = thr
+        out[tag + "__fg_thr"] = np.float64(thr)
+        out[tag + "__fg"] = TrackGenerator.get_fg_masks_from_seediness(_Fake, res).numpy()
+    _save("model_davis", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def _cluster_cases():
+    """(name, emb[N,E], bw[N,Ev], seed[N,1], kwargs)"""
+    cases = []
+    # structured margin cases from the shared synthetic driver
+    for K, seed in ((0, 0), (1, 1), (5, 2), (10, 3), (20, 4), (25, 5)):
+        emb, bw, sd, fg = synth.synth_cluster_case(4, 20, 28, K, seed=seed)
+        m = fg.astype(bool)
+        e = np.stack([emb[c][m] for c in range(emb.shape[0])], 1)
+        b = np.stack([bw[c][m] for c in range(bw.shape[0])], 1)
+        s = sd[0][m][:, None]
+        cases.append(("blobs_K%d" % K, e, b, s, dict(n_free_dims=2, free_dim_stds=[0.3, 0.3], label_start=1 + K)))
+    # kitti-like: no free dims, E == Ev == 3, min seediness 0.95
+    emb, bw, sd, fg = synth.synth_cluster_case(4, 16, 24, 6, E=3, Ev=3, seed=9)
+    m = fg.astype(bool)
+    cases.append(("kitti_like", np.stack([emb[c][m] for c in range(3)], 1), np.stack([bw[c][m] for c in range(3)], 1),
+                  sd[0][m][:, None], dict(n_free_dims=0, free_dim_stds=[], label_start=7, min_seediness_prob=0.95)))
+    # SURVEY.md A.2 probes (E=2, bw=1)
+    x = np.array([0.0, 2.0, 1.7, 5.5, 3.4], np.float32)
+    e = np.stack([x, np.zeros_like(x)], 1)
+    s = np.array([0.99, 0.1, 0.1, 0.1, 0.98], np.float32)[:, None]
+    cases.append(("quirk_max_distance", e, np.ones_like(e), s, dict(n_free_dims=0, free_dim_stds=[], label_start=1)))
+    x = np.array([0, 1, 1.5, 2, 2.5, 9], np.float32)
+    e = np.stack([x, np.zeros_like(x)], 1)
+    s = np.array([0.99, 0.2, 0.98, 0.2, 0.2, 0.97], np.float32)[:, None]
+    cases.append(("quirk_stale_mask", e, np.ones_like(e), s,
+                  dict(n_free_dims=0, free_dim_stds=[], label_start=5, max_instances=2)))
+    # all seeds below threshold, ties in seediness (first index must win), single point
+    rng = np.random.RandomState(77)
+    e = rng.standard_normal((50, 4)).astype(np.float32)
+    cases.append(("all_low_seed", e, np.full((50, 2), 20, np.float32), np.full((50, 1), 0.5, np.float32),
+                  dict(n_free_dims=2, free_dim_stds=[0.3, 0.3], label_start=1)))
+    e = np.concatenate([rng.standard_normal((30, 2)) * 0.05, 4 + rng.standard_normal((30, 2)) * 0.05]).astype(np.float32)
+    s = np.full((60, 1), 0.9, np.float32)      # every seediness equal -> argmax tie-break = lowest index
+    cases.append(("seed_ties", e, np.full((60, 2), 30, np.float32), s,
+                  dict(n_free_dims=0, free_dim_stds=[], label_start=3)))
+    cases.append(("single_point", np.zeros((1, 4), np.float32), np.ones((1, 2), np.float32),
+                  np.full((1, 1), 0.99, np.float32), dict(n_free_dims=2, free_dim_stds=[0.3, 0.3], label_start=1)))
+    cases.append(("empty", np.zeros((0, 4), np.float32), np.zeros((0, 2), np.float32),
+                  np.zeros((0, 1), np.float32), dict(n_free_dims=2, free_dim_stds=[0.3, 0.3], label_start=1)))
+    # secondary assignment actually firing with K == 1 (ring of points between the two thresholds)
+    ang = np.linspace(0, 2 * np.pi, 40, endpoint=False)
+    ring = np.stack([1.9 * np.cos(ang), 1.9 * np.sin(ang)], 1)
+    core = rng.standard_normal((40, 2)) * 0.1
+    e = np.concatenate([core, ring]).astype(np.float32)
+    s = np.concatenate([np.full(40, 0.95), np.full(40, 0.1)]).astype(np.float32)[:, None]
+    s[0] = 0.99
+    cases.append(("secondary_K1", e, np.ones_like(e), s, dict(n_free_dims=0, free_dim_stds=[], label_start=1)))
+    # dense random cloud near the thresholds ("adversarial": compared with a tolerance band)
+    e = (rng.standard_normal((4000, 4)) * 0.6).astype(np.float32)
+    b = (2.0 + rng.uniform(0, 2, (4000, 2))).astype(np.float32)
+    s = rng.uniform(0.5, 1.0, (4000, 1)).astype(np.float32)
+    cases.append(("adversarial_cloud", e, b, s, dict(n_free_dims=2, free_dim_stds=[0.5, 0.5], label_start=1)))
+    return cases
+
+
+def gen_cluster():
+    import ref_shim
+    ref_shim.install()
+    import torch
+    from stemseg.inference.clusterers import SequentialClustering
+    out = {}
+    names = []
+    for name, e, b, s, kw in _cluster_cases():
+        kw = dict(kw)
+        cl = SequentialClustering(0.5, 0.3, kw.pop("min_seediness_prob", 0.8), kw["n_free_dims"], kw["free_dim_stds"],
+                                  "cpu", max_instances=kw.pop("max_instances", 20))
+        labels, meta = cl(torch.from_numpy(e), bandwidths=torch.from_numpy(b), seediness=torch.from_numpy(s),
+                          cluster_label_start=kw["label_start"], return_label_masks=True)
+        names.append(name)
+        out[name + "__emb"], out[name + "__bw"], out[name + "__seed"] = e, b, s
+        out[name + "__labels"] = labels.numpy()
+        out[name + "__instance_labels"] = np.array(meta["instance_labels"], np.int64)
+        E = e.shape[1]
+        out[name + "__centers"] = np.array(meta["instance_centers"], np.float32).reshape(-1, E)
+        out[name + "__stds"] = np.array(meta["instance_stds"], np.float32).reshape(-1, E)
+        out[name + "__masks"] = (np.stack([m.numpy() for m in meta["instance_masks"]]) if meta["instance_masks"]
+                                 else np.zeros((0, e.shape[0]), bool))
+        out[name + "__params"] = np.array([cl.min_seediness_prob, cl.max_instances, kw["label_start"],
+                                           kw["n_free_dims"]] + list(kw["free_dim_stds"]), np.float64)
+    out["__names"] = np.array(names)
+    _save("cluster", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def _chainer_sequence(n_frames, H, W, seed):
+    """Sequence-level structured head outputs with instance births/deaths.  Returns per-frame maps
+    emb[4,F,H,W], bw[2,F,H,W], seed[1,F,H,W], fg[F,H,W]."""
+    rng = np.random.RandomState(seed)
+    emb = (10 + 3 * rng.standard_normal((4, n_frames, H, W))).astype(np.float32)
+    bw = (25 + rng.uniform(0, 1, (2, n_frames, H, W))).astype(np.float32)
+    sd = rng.uniform(0, 0.2, (1, n_frames, H, W)).astype(np.float32)
+    fg = np.zeros((n_frames, H, W), np.uint8)
+    inst = [  # y0, x0, h, w, first, last, free-dim code
+        (1, 1, 5, 6, 0, n_frames - 1, (-0.6, 0.6)),
+        (9, 2, 5, 5, 0, 9, (0.6, 0.6)),
+        (2, 14, 6, 6, 3, n_frames - 1, (0.6, -0.6)),
+        (10, 15, 4, 7, 10, n_frames - 1, (-0.6, -0.6)),
+        (7, 9, 3, 3, 6, 13, (0.0, 1.2)),
+    ]
+    for (y0, x0, h, w, a, b, free) in inst:
+        for t in range(a, min(b, n_frames - 1) + 1):
+            cy, cx = -1 + 2 * (y0 + h / 2) / H, -1.3 + 2.6 * (x0 + w / 2) / W
+            c = np.array([cy, cx, free[0], free[1]], np.float32)
+            nz = (0.04 * rng.standard_normal((4, h, w))).astype(np.float32)
+            emb[:, t, y0:y0 + h, x0:x0 + w] = c[:, None, None] + nz
+            sd[0, t, y0:y0 + h, x0:x0 + w] = np.clip(1 - np.sqrt((nz ** 2).sum(0)), 0, 1)
+            fg[t, y0:y0 + h, x0:x0 + w] = 1
+    fg = np.where(rng.uniform(size=fg.shape) < 0.02, 1, fg).astype(np.uint8)
+    return emb, bw, sd, fg
+
+
+def gen_chainer():
+    import ref_shim
+    ref_shim.install()
+    import torch
+    from stemseg.inference.clusterers import SequentialClustering
+    from stemseg.inference.online_chainer import OnlineChainer
+    from stemseg.inference.main import get_subsequence_frames
+    out = {}
+    for tag, n_frames, overlap, seed in (("seq20_ov4", 20, 4, 31), ("seq14_ov6", 14, 6, 32), ("seq8_single", 8, 4, 33)):
+        H, W = 16, 24
+        emb, bw, sd, fg = _chainer_sequence(n_frames, H, W, seed)
+        subseqs, _ = get_subsequence_frames(n_frames, 8, "davis", overlap)
+        dicts = [dict(frames=list(fr), embeddings=torch.from_numpy(emb[:, fr].copy()),
+                      bandwidths=torch.from_numpy(bw[:, fr].copy()), seediness=torch.from_numpy(sd[:, fr].copy()))
+                 for fr in subseqs]
+        ch = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0)
+        (track_labels, pt_counts, lifetimes), mask_idxes, subseq_labels, _, meta = ch.process(torch.from_numpy(fg), dicts)
+        out[tag + "__seed"] = np.int64(seed)
+        out[tag + "__subseqs"] = np.array(subseqs, np.int64)
+        out[tag + "__emb"], out[tag + "__bw"], out[tag + "__sd"], out[tag + "__fg"] = emb, bw, sd, fg
+        for t, l in enumerate(track_labels):
+            out["%s_track_%02d" % (tag, t)] = l.numpy()
+        out[tag + "__pt_counts"] = np.array(sorted(pt_counts.items()), np.int64).reshape(-1, 2)
+        out[tag + "__lifetimes"] = np.array(sorted(lifetimes.items()), np.int64).reshape(-1, 2)
+        for i, ls in enumerate(subseq_labels):
+            out["%s_clip%d_labels" % (tag, i)] = np.concatenate([l.numpy() for l in ls]) if ls else np.zeros(0, np.int64)
+            out["%s_clip%d_instance_labels" % (tag, i)] = np.array(meta[i]["instance_labels"], np.int64)
+    # resize path (online_chainer.py:127-140): x4 trilinear of emb / seed / (activated) bw
+    rng = np.random.RandomState(5)
+    e = rng.standard_normal((4, 2, 5, 7)).astype(np.float32)
+    sub = {"embeddings": torch.from_numpy(e), "seediness": torch.from_numpy(e[:1].copy()), "bandwidths": torch.from_numpy(e[:2].copy())}
+    OnlineChainer(None, 4.0).resize_tensors(sub)
+    out["resize__in"] = e
+    out["resize__emb"] = sub["embeddings"].numpy()
+    _save("chainer", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_misc():
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    from stemseg.inference.main import get_subsequence_frames
+    from stemseg.modeling.embedding_utils import (creat_spatiotemporal_grid, add_spatiotemporal_offset,
+                                                  get_nb_embedding_dims, get_nb_free_dims)
+    from stemseg.data.common import compute_resize_params_2
+    from stemseg.data.inference_image_loader import InferenceImageLoader, collate_fn
+    out = {}
+    # windowing table (inference/main.py:23-49)
+    rows = []
+    for ds in ("davis", "ytvis", "kittimots"):
+        for seq_len in (3, 5, 8, 9, 12, 20, 36, 64):
+            for T in (8, 16):
+                for ov in (-1, 1, 4, 6):
+                    subseqs, padded = get_subsequence_frames(seq_len, T, ds, ov)
+                    key = "win_%s_%d_%d_%d" % (ds, seq_len, T, ov)
+                    out[key] = np.array(subseqs, np.int64)
+                    out[key + "__padded"] = np.array(padded if padded is not None else [], np.int64)
+                    rows.append(key)
+    out["win__keys"] = np.array(rows)
+    # coordinate grids (embedding_utils.py:28-41)
+    for (H, W, T) in ((16, 24, 8), (120, 216, 8), (152, 488, 8), (7, 5, 4), (24, 16, 16), (1, 9, 2)):
+        t, y, x = creat_spatiotemporal_grid(H, W, T, 1.0)
+        out["grid_%d_%d_%d_t" % (H, W, T)] = t[:, 0, 0].numpy()
+        out["grid_%d_%d_%d_y" % (H, W, T)] = y[0, :, 0].numpy()
+        out["grid_%d_%d_%d_x" % (H, W, T)] = x[0, 0, :].numpy()
+    modes = ["xy", "ff", "xyt", "xyf", "xytf", "xyff", "xytff", "xyfff"]
+    out["modes"] = np.array(modes)
+    out["modes__nb_dims"] = np.array([get_nb_embedding_dims(m) for m in modes], np.int64)
+    out["modes__nb_free"] = np.array([get_nb_free_dims(m) for m in modes], np.int64)
+    for m in modes:
+        z = torch.zeros(1, get_nb_embedding_dims(m), 3, 4, 6)
+        out["offset_" + m] = add_spatiotemporal_offset(z, torch.tensor(1.0), m)[0].numpy()
+    # resize parameters (data/common.py:142-159) and pad-to-32 rule (structures/image_list.py:93-95)
+    dims = [(854, 480), (640, 360), (1242, 375), (96, 64), (70, 50), (1280, 720), (500, 333)]
+    cfgs = [(480, 854), (736, 1248), (640, 1196), (800, 1948), (64, 96), (800, 1333)]
+    tab = []
+    for (w, h) in dims:
+        for (mn, mx) in cfgs:
+            nw, nh, _ = compute_resize_params_2((w, h), mn, mx)
+            tab.append([w, h, mn, mx, nw, nh])
+    out["resize_params"] = np.array(tab, np.int64)
+    # preprocessing of one odd-sized frame (inference_image_loader.py:23-43) incl. padding by collate_fn
+    cfg.INPUT.update_param("MIN_DIM", 64)
+    cfg.INPUT.update_param("MAX_DIM", 96)
+    img = synth.synth_frames(1, 50, 70, seed=3)[0]
+    loader = InferenceImageLoader([img])
+    il, _ = collate_fn([loader[0]])
+    out["preproc__in"] = img
+    out["preproc__out"] = il.tensors[0, 0].numpy()
+    _save("misc", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--group", default=None, choices=GROUPS)
+    args = ap.parse_args()
+    if args.group is None:
+        for g in GROUPS:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--group", g])
+        return
+    g = args.group
+    if g.startswith("dec_T"):
+        gen_decoders(int(g[5:]))
+    elif g == "encoder":
+        gen_encoder()
+    elif g == "model_davis":
+        gen_model_davis()
+    elif g == "cluster":
+        gen_cluster()
+    elif g == "chainer":
+        gen_chainer()
+    elif g == "misc":
+        gen_misc()
+
+
+if __name__ == "__main__":
+    main()
