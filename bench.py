@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/sec of the embed+cluster hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one synthetic clip (T=8 frames, padded 480x864, ResNet-101-FPN, DAVIS heads: embedding decoder +
+separate seediness decoder) through encoder -> 3-D decoders -> fused heads -> fg mask -> fg gather -> sequential
+clustering -> read-back of the clustering record (K, instance list), with the input frames already resident in
+HBM.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
+are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
+
+import torch  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+T, H, W = 8, 480, 864             # BASELINE config 1: DAVIS-shape 480p (480x854 padded to a multiple of 32)
+BACKBONE = "R-101-FPN"
+
+
+def synth_weights_(module, seed, seediness_gain=30.0):
+    """Random-init weights of the named architecture (no checkpoint is available offline).  He-normal convs,
+    near-identity norms; the seediness head's last conv is scaled so that seediness spans (0, 1) -- with the default
+    init every pixel sits near 0.5 < MIN_SEEDINESS_PROB and the clusterer would legitimately stop after one round
+    (SURVEY.md section 8(d)); the gain makes it run its full <= 20 rounds, i.e. the expensive case."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if v.dim() == 0:
+            new[k] = v.clone()
+            continue
+        n = torch.randn(v.shape, generator=g, dtype=torch.float32)
+        if v.dim() >= 2:
+            fan_in = v[0].numel()
+            n = n * (2.0 / fan_in) ** 0.5
+            if k.endswith("seediness_head.conv_out.weight") or k.endswith("conv_seediness.weight"):
+                n = n * seediness_gain
+        elif k.endswith("running_var"):
+            n = 0.5 + 0.5 * n.abs()
+        elif k.endswith("running_mean"):
+            n = 0.1 * n
+        elif k.endswith("bn3.weight"):
+            n = 0.3 + 0.05 * n
+        elif k.endswith(".weight"):
+            n = 1.0 + 0.2 * n
+        else:
+            n = 0.1 * n
+        new[k] = n
+    module.load_state_dict(new)
+    return new
+
+
+def build_pipeline(device):
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset("davis")
+    config.cfg.MODEL.BACKBONE.TYPE = BACKBONE
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 480, 854
+    model = InferenceModel()
+    sd = synth_weights_(model._model, seed=1234)
+    return ClipPipeline(model, device=device), sd
+
+
+def make_clip(seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    frames = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.int32).float()
+    frames[:, :, :, 854:] = 102.9801          # right padding columns are zero after mean subtraction
+    mean = torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    x = frames - mean
+    x[:, :, :, 854:] = 0.0
+    return x.to(device)
+
+
+def cpu_baseline(sd, frames_cpu):
+    """The CPU oracle (a restatement of the reference's PyTorch path, pinned against reference-generated goldens)
+    on the host cores: ONE clip of the same workload, 1 timed run (no warm-up; ~10-30 s)."""
+    from oracle import pipeline as opipe
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    t0 = time.time()
+    out = opipe.embed_and_cluster_clip(frames_cpu, sd, BACKBONE, "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 clip (T=8, 480x864, %s, DAVIS heads), 1 timed run incl. first-call overhead; %d fg points, %d instances"
+                      % (BACKBONE, out["labels"].shape[0], len(out["meta"]["instance_labels"]))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the (still torch-op) encoder convs
+
+    from stemseg_amd import hip
+    hip.require_gpu()
+    pipe, sd = build_pipeline(device)
+    clips = [make_clip(1000 + rank * 97 + i, device) for i in range(2)]
+
+    def step(i):
+        out = pipe.step(clips[i % len(clips)])
+        return hip.read_cluster_meta(out["meta"])     # the consumer's read-back (K, centres): one small D2H per clip
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    meta = None
+    for i in range(args.warmup):
+        meta = step(i)
+    sync()
+    hip.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        meta = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = hip.profile_read()
+    hip.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        clips_total = args.steps * world
+        # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes), measured inside the timed region
+        k3 = [prof[t] for t in (8, 4, 2) if t in prof]
+        ms = sum(p[0] for p in k3)
+        fl = sum(p[1] for p in k3)
+        launches = sum(p[2] for p in k3)
+        ach = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        res = {
+            "metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(clips_total / dt, 4), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + "
+                                   "seediness decoders, fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE,
+                       "clips_per_step": 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
+                       "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, fp32 MFMA 32x32x2)", "achieved": round(ach, 2),
+                         "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+                         "traffic": None, "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
+                         "share_of_step_time": round(ms * 1e-3 / dt, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items()}, clips[0].cpu())
+            except Exception as e:  # noqa: BLE001  (never lose the GPU number because the baseline leg failed)
+                res["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+/*
+ * stemseg_hip.h -- C-ABI of libstemseg_hip.so: the MI355X (gfx950) implementation of STEm-Seg's
+ * embed+cluster hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (sabarim/STEm-Seg) has no FFI of its own: its extension surface is Python
+ * (registries + nn.Module / callable contracts).  Each entry point below
+ * names the reference interface it stands in for (file:line relative to the reference tree); the
+ * Python host-side mirror in stem-seg_amd/stemseg_amd/ binds these with ctypes and re-exposes the
+ * reference's class / function names.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative STEMSEG_E_* code; nothing throws;
+ *     stemseg_hip_last_error() gives a thread-local message valid until the next call on the thread.
+ *   - no allocation and no ownership transfer: all device memory (inputs, outputs, workspaces) is
+ *     provided by the caller; pointers are device pointers unless the name ends in _host.
+ *   - work is enqueued on the hipStream_t passed as `void* stream` (NULL = default stream); the
+ *     only functions that synchronise with the host are the *_read_* ones, and they say so.
+ *   - all floating point is IEEE fp32 (the reference asserts fp32, inference/clusterers.py:12),
+ *     labels are int64, masks are uint8.
+ */
+#ifndef STEMSEG_HIP_H
+#define STEMSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEMSEG_HIP_ABI_VERSION 1
+
+#define STEMSEG_OK              0
+#define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
+#define STEMSEG_E_HIP          -2   /* a HIP runtime call failed (see last_error)     */
+#define STEMSEG_E_WORKSPACE    -3   /* workspace too small                            */
+#define STEMSEG_E_UNSUPPORTED  -4
+
+#define STEMSEG_MAX_INSTANCES  64   /* upper bound for ClusterParams.max_instances    */
+#define STEMSEG_MAX_EMB_DIMS    8
+
+int         stemseg_hip_version(void);
+const char* stemseg_hip_last_error(void);
+/* number of HIP devices visible, or a negative error (used to fail loudly when there is no GPU) */
+int         stemseg_hip_device_count(void);
+
+/* Optional in-library profiler (measurement only): when enabled, every convolution launch is bracketed by a
+ * hipEvent pair on its own stream.  profile_read SYNCHRONISES the device, then writes per tag t
+ * out_host[3t] = summed kernel ms, out_host[3t+1] = summed algorithmic FLOPs, out_host[3t+2] = launches, and clears the
+ * log.  Tags: 8 / 4 / 2 = 3x3x3 conv with an 8 / 4 / 2-row tile, 18 / 14 = 1x1x1 conv (256 / 128-voxel tile). */
+int stemseg_hip_profile_enable(int32_t on);
+int stemseg_hip_profile_read(double* out_host, int32_t n_tags);
+
+/* ------------------------------------------------------------------------------------------------
+ * Volumes.  A volume is a [C][T][H][W] fp32 tensor addressed as
+ *     ptr + c*c_stride + t*t_stride + y*y_stride + x            (strides in floats, x contiguous)
+ * which covers the reference's dense NCDHW tensors (N = 1), channel slices of concat buffers and the
+ * zero-haloed ("padded") layout the 3x3x3 convolution consumes.  limit = number of floats that may
+ * be read starting at ptr (tile over-reads beyond a row are clamped against it).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct StemsegVolume {
+    float*  ptr;
+    int64_t c_stride, t_stride, y_stride;
+    int32_t C, T, H, W;
+    int64_t limit;
+} StemsegVolume;
+
+/* Geometry of the zero-haloed layout for a logical [C][T][H][W] volume: one zero voxel on every side
+ * of T, H, W, row pitch rounded up to 4 floats.  out[0..4] = {row_pitch, t_stride, c_stride,
+ * total_floats (incl. tail slack), interior_offset}: element (c,t,y,x) lives at
+ * base + interior_offset + c*c_stride + t*t_stride + y*row_pitch + x. */
+int stemseg_hip_padded_geometry(int32_t C, int32_t T, int32_t H, int32_t W, int64_t out[5]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder building blocks (each is also used on its own by the parity tests).
+ * Reference: nn.Conv3d / nn.GroupNorm / nn.ReLU / nn.AvgPool3d / F.interpolate as instantiated in
+ * stemseg/modeling/embedding_decoder.py:20-96 and common.py:69-78.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Repack a reference-layout conv weight [Cout][Cin][taps] (taps = kt*kh*kw, row-major over kt,kh,kw)
+ * into the MFMA implicit-GEMM layout [Cin/4][taps][4][Cout].  Cin % 4 == 0, Cout % 32 == 0. */
+int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
+
+/* out[co,t,y,x] = bias[co] + sum_{ci,dt,dy,dx} W[co,ci,dt,dy,dx] * in[ci, t+dt, y+dy, x+dx]
+ * "valid" cross-correlation: `in` is the haloed volume (in->T = out->T + kt-1, likewise H, W), so
+ * Conv3d(k=3, padding=1) of embedding_decoder.py:21 is `in` = zero-haloed layout.  (kt,kh,kw) is
+ * (3,3,3) or (1,1,1).  bias may be NULL.  tile_cfg: 0 = auto, 1..3 = force a tile shape (tuning). */
+int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
+                       int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, void* stream);
+
+/* GroupNorm statistics over a dense [C][S] tensor (S = T*H*W), `groups` contiguous channel groups:
+ * stats[2g] = mean, stats[2g+1] = 1/sqrt(biased_var + eps).  scratch: >= groups*128 doubles. */
+int stemseg_hip_groupnorm_stats(const float* x, int32_t C, int64_t S, int32_t groups, float eps,
+                                float* stats, double* scratch, void* stream);
+
+/* y = ReLU(GroupNorm(x)) optionally followed by AvgPool3d(3, stride (2,1,1), padding 1,
+ * count_include_pad) -- embedding_decoder.py:22-24.  `x` dense [C][T][H][W]; `out` any volume with
+ * out->T == (pool ? (T+1)/2 : T). */
+int stemseg_hip_gn_relu_pool(const float* x, int32_t C, int32_t T, int32_t H, int32_t W, int32_t groups,
+                             const float* stats, const float* gamma, const float* beta, int32_t pool,
+                             const StemsegVolume* out, void* stream);
+
+/* F.interpolate(mode='trilinear', align_corners=False) with integer scale (st, sy, sx) -- common.py:77-78 and
+ * online_chainer.py:127-140 (sx = sy = 4, st = 1).  `in` dense [C][T][H][W]; out->T/H/W = scaled dims. */
+int stemseg_hip_upsample_trilinear(const float* in, int32_t C, int32_t T, int32_t H, int32_t W,
+                                   int32_t st, int32_t sy, int32_t sx, const StemsegVolume* out, void* stream);
+
+/* Copy a dense feature stack into a volume (typically the zero-haloed layout).
+ * layout 0: in = [C][T][H][W] (the head input of embedding_decoder.py:101-109);
+ * layout 1: in = [T][C][H][W] (what the 2-D encoder emits, model_builder.py:154-169). */
+int stemseg_hip_copy_to_volume(const float* in, int32_t layout, const StemsegVolume* out, void* stream);
+
+/* Fused 1x1x1 heads (embedding_decoder.py:131-143, seediness_decoder.py:112, inference_model.py:148):
+ * out[o, v] = act_o( bias[o] + sum_c w[o][c] * x[c, v] ),  x dense [Cin][V], out dense [n_out][V].
+ * act codes: 0 identity, 1 tanh(0.25*z) + grid, 2 sigmoid, 3 exp(z)*10, 4 identity + grid.
+ * grid_axis[o]: 0 none, 1 t, 2 y, 3 x -- the coordinate added for act 1/4 (embedding_utils.py:44-120);
+ * grid_t/y/x are the linspace vectors of embedding_utils.py:28-41 (length T, H, W). */
+int stemseg_hip_heads(const float* x, int32_t Cin, int32_t T, int32_t H, int32_t W,
+                      const float* w, const float* bias, int32_t n_out, const int32_t* act_host,
+                      const int32_t* grid_axis_host, const float* grid_t, const float* grid_y, const float* grid_x,
+                      float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole decoder: SqueezingExpandDecoder.forward (embedding_decoder.py:101-145) and the seediness twin
+ * (seediness_decoder.py:92-112), optionally with the bandwidth activation of inference_model.py:148.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct StemsegDecoderDesc {
+    int32_t struct_bytes;        /* = sizeof(StemsegDecoderDesc), checked                                   */
+    int32_t in_channels;         /* FPN channels (256)                                                      */
+    int32_t inter[4];            /* INTER_CHANNELS for the 32x,16x,8x,4x branches (256,256,128,128)          */
+    int32_t T, H4, W4;           /* clip length and 1/4-resolution output size; H4 % 8 == 0, W4 % 8 == 0    */
+    int32_t gn_groups;           /* 32                                                                      */
+    float   gn_eps;              /* 1e-5                                                                    */
+    int32_t pool[3];             /* common.py:8-24 : is temporal pooling layer i active (T=8: 1,1,0)        */
+    int32_t t_scale[3];          /* common.py:27-35: temporal up-sampling factors (T=8: 1,2,2)              */
+    int32_t n_out;               /* head output channels (emb + var + seed, or 1 for the seediness decoder)  */
+    int32_t act[STEMSEG_MAX_EMB_DIMS * 2];        /* per output channel, see stemseg_hip_heads          */
+    int32_t grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
+    int32_t input_layout;        /* 0: [C][T][h][w] dense, 1: [T][C][h][w] dense, 2: already zero-haloed     */
+} StemsegDecoderDesc;
+
+typedef struct StemsegDecoderWeights {
+    /* 3x3x3 convs in order block_32x.{0,4,8}, block_16x.{0,4}, block_8x.0, block_4x.0 (packed layout) */
+    const float* conv_w[7];
+    const float* conv_b[7];
+    const float* gn_w[7];
+    const float* gn_b[7];
+    const float* fuse_w[3];      /* conv_16, conv_8, conv_4 (1x1x1, no bias), packed layout */
+    const float* head_w;         /* [n_out][inter[3]] row-major */
+    const float* head_b;         /* [n_out] (zero where the reference conv has no bias) */
+    const float* grid_t;         /* [T], [H4], [W4] linspace vectors (may be NULL if no act uses the grid) */
+    const float* grid_y;
+    const float* grid_x;
+} StemsegDecoderWeights;
+
+size_t stemseg_hip_decoder_workspace_bytes(const StemsegDecoderDesc* desc);
+/* zero the halos; call once per (workspace, desc) before the first forward */
+int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
+/* feats[0..3] = 32x,16x,8x,4x feature stacks in desc->input_layout; out = [n_out][T][H4][W4] dense */
+int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* weights,
+                                const float* const feats[4], float* out,
+                                void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Clustering side.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* inference/main.py:93-103: per-frame running sum of seediness over the clips that contain the frame,
+ * then (sum / count) > thr.  accumulate: acc = (first ? 0 : acc) + plane, n floats. */
+int stemseg_hip_seediness_accumulate(float* acc, const float* plane, int64_t n, int32_t first, void* stream);
+int stemseg_hip_fg_mask(const float* acc, float count, float thr, uint8_t* mask, int64_t n, void* stream);
+
+/* online_chainer.py:11-22 + :258-281 : compact the foreground voxels of a clip.
+ * emb [E][V], bw [Ev][V], seed [V] dense with V = T*HW, fg uint8 [V].  Point order = flat voxel order
+ * (frame-major, row-major).  Outputs: emb_out [N][E], bw_out [N][Ev], seed_out [N], voxel_index [N] (int32),
+ * frame_offsets [T+1] int64 (exclusive prefix of per-frame counts; frame_offsets[T] = N).  Outputs must be
+ * sized for N = V.  scratch: >= 8 * (V/1024 + 2) bytes.  No host synchronisation. */
+int stemseg_hip_fg_gather(const float* emb, const float* bw, const float* seed, const uint8_t* fg,
+                          int32_t E, int32_t Ev, int32_t T, int64_t HW,
+                          float* emb_out, float* bw_out, float* seed_out, int32_t* voxel_index,
+                          int64_t* frame_offsets, void* scratch, void* stream);
+
+typedef struct StemsegClusterParams {
+    float   primary_prob_thresh;    /* 0.5  (clusterers.py:40)  */
+    float   secondary_prob_thresh;  /* 0.3                      */
+    float   min_seediness_prob;     /* 0.8 / 0.95 (KITTI)       */
+    int32_t max_instances;          /* 20                       */
+    int32_t n_free_dims;
+    float   free_dim_bandwidths[STEMSEG_MAX_EMB_DIMS];   /* 1/std^2, computed by the caller in fp32 */
+} StemsegClusterParams;
+
+/* read-back record, written by the last kernel into caller-provided DEVICE memory (copy it to the host
+ * when convenient; it is what online_chainer.py needs to continue: K and the instance list). */
+typedef struct StemsegClusterMeta {
+    int32_t K;                      /* instances found; instance_labels = label_start + 0..K-1 */
+    int32_t exhausted;              /* loop ran max_instances rounds (stale-mask quirk active) */
+    int64_t n_points;
+    int64_t n_unassigned_last;      /* num_unassigned_pts at the last evaluated loop header     */
+    float   centers[STEMSEG_MAX_INSTANCES][STEMSEG_MAX_EMB_DIMS];
+    float   bandwidths[STEMSEG_MAX_INSTANCES][STEMSEG_MAX_EMB_DIMS];   /* cat(bw_seed, free) ; std = sqrt(clamp(1/bw)) */
+    float   seed_prob[STEMSEG_MAX_INSTANCES];
+} StemsegClusterMeta;
+
+size_t stemseg_hip_cluster_workspace_bytes(int64_t n_max);
+/* SequentialClustering._process (inference/clusterers.py:60-166) including its quirks.
+ * emb [N][E], bw [N][Ev], seed [N]; E = Ev + n_free_dims <= 8.  n_points_dev: optional device pointer to the
+ * actual N (e.g. frame_offsets + T from stemseg_hip_fg_gather) -- if NULL, N = n_max.
+ * labels [n_max] int64 (-1 = unassigned).  opt_masks: NULL or uint8 [max_instances][n_max] primary match masks;
+ * opt_probs: NULL or float [max_instances][n_max] per-round probabilities (0 where unavailable).
+ * Enqueues max_instances + 2 kernels; no host synchronisation. */
+int stemseg_hip_cluster(const float* emb, const float* bw, const float* seed, int64_t n_max,
+                        const int64_t* n_points_dev, int32_t E, int32_t Ev,
+                        const StemsegClusterParams* params, int64_t label_start,
+                        int64_t* labels, StemsegClusterMeta* meta_dev,
+                        uint8_t* opt_masks, float* opt_probs,
+                        void* workspace, size_t ws_bytes, void* stream);
+
+/* online_chainer.py:291-343: label-pair statistics on the overlap frames.  lut_a / lut_b map (label + 1)
+ * to a row / column index or -1 (ignore; the outlier label -1 maps through slot 0).  Outputs (int64,
+ * zeroed by the call): inter [Ka][Kb], cnt_a [Ka], cnt_b [Kb]. */
+int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t* labels_b, int64_t n,
+                               const int32_t* lut_a, int32_t lut_a_len, const int32_t* lut_b, int32_t lut_b_len,
+                               int32_t Ka, int32_t Kb, int64_t* inter, int64_t* cnt_a, int64_t* cnt_b, void* stream);
+
+/* in-place relabel: labels[i] = map[labels[i] + 1] for labels[i] + 1 in [0, map_len) (online_chainer.py:219-229) */
+int stemseg_hip_relabel(int64_t* labels, int64_t n, const int64_t* map, int32_t map_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEMSEG_HIP_H */

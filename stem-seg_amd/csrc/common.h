@@ -1,0 +1,94 @@
+// Shared host/device helpers for libstemseg_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/stemseg_hip.h"
+
+namespace stemseg {
+
+void set_error(const char* fmt, ...);
+
+#define SS_CHECK_ARG(cond, ...)                                     \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            ::stemseg::set_error(__VA_ARGS__);                      \
+            return STEMSEG_E_INVALID;                               \
+        }                                                           \
+    } while (0)
+
+#define SS_HIP(call)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            ::stemseg::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),         \
+                                 __FILE__, __LINE__);                                           \
+            return STEMSEG_E_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+#define SS_LAUNCH_CHECK() SS_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// zero-haloed layout of a logical [C][T][H][W] volume (see stemseg_hip_padded_geometry)
+struct PaddedGeom {
+    int64_t pitch, ts, cs, total, interior;
+    PaddedGeom() = default;
+    PaddedGeom(int C, int T, int H, int W) {
+        pitch = round_up((int64_t)W + 2, 4);
+        ts = (int64_t)(H + 2) * pitch;
+        cs = (int64_t)(T + 2) * ts;
+        total = (int64_t)C * cs + 64;  // tail slack: tile over-reads past the last row stay inside
+        interior = ts + pitch + 1;
+    }
+};
+
+static inline StemsegVolume make_volume(float* ptr, int64_t cs, int64_t ts, int64_t ys, int C, int T, int H, int W,
+                                        int64_t limit) {
+    StemsegVolume v;
+    v.ptr = ptr; v.c_stride = cs; v.t_stride = ts; v.y_stride = ys; v.C = C; v.T = T; v.H = H; v.W = W; v.limit = limit;
+    return v;
+}
+// dense [C][T][H][W]
+static inline StemsegVolume dense_volume(float* ptr, int C, int T, int H, int W) {
+    return make_volume(ptr, (int64_t)T * H * W, (int64_t)H * W, W, C, T, H, W, (int64_t)C * T * H * W);
+}
+// the haloed view (what conv3d reads): extents T+2, H+2, W+2, origin at the buffer base
+static inline StemsegVolume padded_halo_view(float* base, int C, int T, int H, int W) {
+    PaddedGeom g(C, T, H, W);
+    return make_volume(base, g.cs, g.ts, g.pitch, C, T + 2, H + 2, W + 2, g.total);
+}
+// the interior view (what producers write)
+static inline StemsegVolume padded_interior_view(float* base, int C, int T, int H, int W) {
+    PaddedGeom g(C, T, H, W);
+    return make_volume(base + g.interior, g.cs, g.ts, g.pitch, C, T, H, W, g.total - g.interior);
+}
+
+// ---- optional in-library profiler: hipEvent pairs around tagged launches (off by default) -------
+void* profile_begin(int tag, double work, hipStream_t s);   // returns NULL when profiling is off
+void profile_end(void* handle, hipStream_t s);
+
+// ---- internal kernel launchers shared between api.hip and decoder.hip -------------------------
+int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
+                  int kt, int kh, int kw, int tile_cfg, hipStream_t s);
+int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s);
+int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
+                        const float* beta, int pool, const StemsegVolume& out, hipStream_t s);
+int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy, int sx, const StemsegVolume& out,
+                    hipStream_t s);
+int launch_copy_to_volume(const float* in, int layout, const StemsegVolume& out, hipStream_t s);
+struct HeadSpec {
+    int n_out;
+    int act[STEMSEG_MAX_EMB_DIMS * 2];
+    int grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
+};
+int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s);
+
+}  // namespace stemseg

@@ -1,0 +1,300 @@
+// Implicit-GEMM 3-D convolution on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces nn.Conv3d(k=3, s=1, p=1) of /root/reference/stemseg/modeling/embedding_decoder.py:21-58 and
+// the 1x1x1 fuse convs of :68-80 (cuDNN / MKL-DNN calls in the reference).
+//
+// GEMM view:  D[co][voxel] = sum_{ci,tap} W[co][ci,tap] * X[ci][voxel + off(tap)]
+//   M = Cout, N = T*H*W voxels, K = Cin * taps.
+// One workgroup (4 waves) owns MT output channels x (ROWS rows x COLS*32 columns) voxels of one t-plane.
+// Per chunk of CK input channels it stages into LDS
+//   * the input halo tile  [CK][KT][ROWS+KH-1][XP]   -- rows are W-contiguous in HBM, loaded as 16-B
+//     pieces (the zero-haloed source layout makes every row start 16-B aligned and removes all
+//     boundary predicates from the inner loop), and
+//   * the weight slab      [CK/4][taps][4][MT]       -- a plain linear copy of the packed layout,
+// then every tap is a *shifted read* of the same LDS tile: the B fragment of lane l for tap (dt,dy,dx)
+// is in_lds[c0 + (l>>5)][dt][row+dy][col0 + (l&31) + dx] -- 32 consecutive floats per half-wave, i.e.
+// conflict-free ds_read_b32 with a compile-time immediate offset, zero VALU in the loop.
+// The A fragment is w_lds[k][co0 + (l&31)], likewise conflict-free.
+// fp32 MFMA issues one instruction per 64 cycles per SIMD, so 6 LDS reads per 8 MFMAs (MI=4, NI=2) leave
+// the LDS pipe < 15 % busy; two workgroups per CU (<= 80 KB LDS, <= 256 VGPRs each) overlap one group's
+// staging with the other's MFMA stream.
+#include "common.h"
+#include <algorithm>
+
+namespace stemseg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKParams {
+    const float* in;
+    int64_t in_cs, in_ts, in_ys, in_limit;
+    int in_H;
+    const float* wpk;
+    const float* bias;
+    float* out;
+    int64_t out_cs, out_ts, out_ys;
+    int Cin, Cout, T, H, W;
+    int tiles_x, tiles_y;
+    int vec4;
+};
+
+template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_>
+struct ConvCfg {
+    static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
+    static constexpr int TAPS = KT * KH * KW;
+    static constexpr int NTHREADS = 64 * WM * WN;
+    static constexpr int MT = WM * MI * 32;
+    static constexpr int NSEG = WN * NI;
+    static constexpr int ROWS = NSEG / COLS;
+    static constexpr int RH = ROWS + KH - 1;
+    static constexpr int XP = ((COLS * 32 + KW - 1) + 3) / 4 * 4;
+    static constexpr int IN_CH_STRIDE = KT * RH * XP;
+    static constexpr int IN_FLOATS = CK * IN_CH_STRIDE;
+    static constexpr int W_FLOATS = CK * TAPS * MT;
+    static constexpr int LDS_FLOATS = IN_FLOATS + W_FLOATS;
+    static_assert(NSEG % COLS == 0, "segments must fill whole rows");
+    static_assert(CK % 4 == 0, "channel chunk is a multiple of the packed sub-chunk (4)");
+    static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    float* const in_lds = smem;
+    float* const w_lds = smem + C::IN_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int t = bx / p.tiles_y;
+    const int x0 = tx * (C::COLS * 32), y0 = ty * C::ROWS;
+    const int co0 = blockIdx.y * C::MT;
+
+    f32x16 acc[C::MI][C::NI];
+#pragma unroll
+    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const float* a_ptr = w_lds + half * C::MT + wm * (C::MI * 32) + l31;
+    const float* b_ptr[C::NI];
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) {
+        const int s = wn * C::NI + ni;
+        b_ptr[ni] = in_lds + half * C::IN_CH_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+    }
+
+    const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
+    const int64_t tile_base = (int64_t)t * p.in_ts + x0;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += C::CK) {
+        __syncthreads();   // everyone is done reading the previous chunk
+        // ---- stage the input halo tile --------------------------------------------------------
+        if (p.vec4) {
+            constexpr int XQ = C::XP / 4;
+            constexpr int NQ = C::CK * C::KT * C::RH * XQ;
+            for (int q = tid; q < NQ; q += C::NTHREADS) {
+                const int xq = q % XQ;
+                int rr = q / XQ;
+                const int r = rr % C::RH;
+                rr /= C::RH;
+                const int dt = rr % C::KT;
+                const int c = rr / C::KT;
+                const int yy = min(y0 + r, p.in_H - 1);
+                const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + c < p.Cin && tile_base + rel + 4 <= p.in_limit) v = *reinterpret_cast<const float4*>(in_tile + rel);
+                *reinterpret_cast<float4*>(in_lds + ((c * C::KT + dt) * C::RH + r) * C::XP + xq * 4) = v;
+            }
+        } else {
+            constexpr int NE = C::CK * C::KT * C::RH * C::XP;
+            for (int q = tid; q < NE; q += C::NTHREADS) {
+                const int xx = q % C::XP;
+                int rr = q / C::XP;
+                const int r = rr % C::RH;
+                rr /= C::RH;
+                const int dt = rr % C::KT;
+                const int c = rr / C::KT;
+                const int yy = min(y0 + r, p.in_H - 1);
+                const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xx;
+                float v = 0.f;
+                if (c0 + c < p.Cin && tile_base + rel < p.in_limit) v = in_tile[rel];
+                in_lds[((c * C::KT + dt) * C::RH + r) * C::XP + xx] = v;
+            }
+        }
+        // ---- stage the weight slab: rows (sub, tap, c4) x MT output channels -------------------
+        {
+            constexpr int MQ = C::MT / 4;
+            constexpr int NWQ = C::CK * C::TAPS * MQ;
+            const float* wsrc = p.wpk + (int64_t)(c0 / 4) * (C::TAPS * 4) * p.Cout + co0;
+            for (int q = tid; q < NWQ; q += C::NTHREADS) {
+                const int mq = q % MQ;
+                const int row = q / MQ;                       // = (sub*TAPS + tap)*4 + c4
+                const int ch = c0 + (row / (C::TAPS * 4)) * 4 + (row & 3);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch < p.Cin && co0 + mq * 4 < p.Cout) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * p.Cout + mq * 4);
+                *reinterpret_cast<float4*>(w_lds + row * C::MT + mq * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA stream: every tap is a shifted LDS read ---------------------------------------
+#pragma unroll
+        for (int sub = 0; sub < C::CK / 4; ++sub) {
+#pragma unroll
+            for (int dt = 0; dt < C::KT; ++dt) {
+#pragma unroll
+                for (int dy = 0; dy < C::KH; ++dy) {
+#pragma unroll
+                    for (int dx = 0; dx < C::KW; ++dx) {
+#pragma unroll
+                        for (int cp = 0; cp < 2; ++cp) {
+                            const int tap = (dt * C::KH + dy) * C::KW + dx;
+                            const int wrow = (sub * C::TAPS + tap) * 4 + cp * 2;
+                            const int boff = (sub * 4 + cp * 2) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
+                            float a[C::MI], b[C::NI];
+#pragma unroll
+                            for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[wrow * C::MT + mi * 32];
+#pragma unroll
+                            for (int ni = 0; ni < C::NI; ++ni) b[ni] = b_ptr[ni][boff];
+#pragma unroll
+                            for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < C::NI; ++ni)
+                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel) ----
+    const int co_base = co0 + wm * (C::MI * 32);
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) {
+        const int s = wn * C::NI + ni;
+        const int y = y0 + s / C::COLS;
+        const int x = x0 + (s % C::COLS) * 32 + l31;
+        if (y < p.H && x < p.W) {
+            float* o = p.out + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+#pragma unroll
+            for (int mi = 0; mi < C::MI; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.Cout) {
+                        const float bv = p.bias ? p.bias[co] : 0.f;
+                        o[(int64_t)co * p.out_cs] = acc[mi][ni][r] + bv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// [Cout][Cin][taps] -> [Cin/4][taps][4][Cout]
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int Cout, int Cin, int taps) {
+    const int64_t n = (int64_t)Cout * Cin * taps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t r = i / Cout;
+        const int c4 = (int)(r & 3);
+        r >>= 2;
+        const int tap = (int)(r % taps);
+        const int chunk = (int)(r / taps);
+        const int ci = chunk * 4 + c4;
+        packed[i] = w[((int64_t)co * Cin + ci) * taps + tap];
+    }
+}
+
+// tile shapes --------------------------------------------------------------------------------------
+//                       KT KH KW  CK  MI NI WM WN COLS
+using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
+using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1>;   // 128 co x (4 rows x 32 cols)
+using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1>; // 128 co x (2 rows x 32 cols)
+using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8>;  // 128 co x 256 voxels
+using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4>; // 128 co x 128 voxels
+
+template <class C>
+static int launch_cfg(ConvKParams p, hipStream_t s) {
+    p.tiles_x = (int)ceil_div(p.W, C::COLS * 32);
+    p.tiles_y = (int)ceil_div(p.H, C::ROWS);
+    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT));
+    const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
+    const int tag = C::TAPS == 1 ? 10 + C::NSEG : C::ROWS;   // 8/4/2: 3x3x3 tile rows, 18/14: 1x1x1
+    void* ev = profile_begin(tag, flops, s);
+    hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
+    profile_end(ev, s);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+template <class C>
+static int64_t num_workgroups(int Cout, int T, int H, int W) {
+    return ceil_div(W, C::COLS * 32) * ceil_div(H, C::ROWS) * T * ceil_div(Cout, C::MT);
+}
+
+int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
+                  int kt, int kh, int kw, int tile_cfg, hipStream_t s) {
+    SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
+    const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1);
+    SS_CHECK_ARG(k3 || k1, "conv3d: kernel %dx%dx%d unsupported (3x3x3 or 1x1x1)", kt, kh, kw);
+    SS_CHECK_ARG(in.T == out.T + kt - 1 && in.H == out.H + kh - 1 && in.W == out.W + kw - 1,
+                 "conv3d: input extents (%d,%d,%d) must be output (%d,%d,%d) + kernel - 1", in.T, in.H, in.W, out.T, out.H, out.W);
+    SS_CHECK_ARG(in.C % 4 == 0 && out.C % 32 == 0, "conv3d: Cin %% 4 == 0 and Cout %% 32 == 0 required (got %d, %d)", in.C, out.C);
+    ConvKParams p;
+    p.in = in.ptr; p.in_cs = in.c_stride; p.in_ts = in.t_stride; p.in_ys = in.y_stride; p.in_limit = in.limit; p.in_H = in.H;
+    p.wpk = packed_w; p.bias = bias;
+    p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
+    p.Cin = in.C; p.Cout = out.C; p.T = out.T; p.H = out.H; p.W = out.W;
+    p.tiles_x = p.tiles_y = 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in.ptr) % 16 == 0) && (in.c_stride % 4 == 0) &&
+                         (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
+    p.vec4 = aligned ? 1 : 0;
+    SS_CHECK_ARG(reinterpret_cast<uintptr_t>(packed_w) % 16 == 0, "conv3d: packed weights must be 16-byte aligned");
+    if (k3) {
+        int cfg = tile_cfg;
+        if (cfg <= 0 || cfg > 3) {
+            // largest tile that still gives every CU two workgroups
+            if (num_workgroups<K3Big>(p.Cout, p.T, p.H, p.W) >= 512) cfg = 1;
+            else if (num_workgroups<K3Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
+            else cfg = 3;
+        }
+        if (cfg == 1) return launch_cfg<K3Big>(p, s);
+        if (cfg == 2) return launch_cfg<K3Med>(p, s);
+        return launch_cfg<K3Small>(p, s);
+    }
+    int cfg = tile_cfg;
+    if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) ? 1 : 2;
+    if (cfg == 1) return launch_cfg<K1Big>(p, s);
+    return launch_cfg<K1Small>(p, s);
+}
+
+}  // namespace stemseg
+
+extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(w && packed, "pack_conv_weight: null pointer");
+    SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0 && taps > 0, "pack_conv_weight: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
+    const int64_t n = (int64_t)Cout * Cin * taps;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, packed, Cout, Cin, taps);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
+                                  int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(in && out, "conv3d: null volume");
+    return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream));
+}

@@ -1,0 +1,281 @@
+// Host-side orchestration of the 3-D squeeze-expand decoder (embedding and seediness variants) and the
+// library's bookkeeping entry points (version, error string, geometry).
+//
+// Reference: SqueezingExpandDecoder.forward, /root/reference/stemseg/modeling/embedding_decoder.py:101-145 and
+// seediness_decoder.py:92-112; topology table common.py:8-35.  The reference materialises every intermediate
+// (conv out, GN out, ReLU in place, pool out, interpolate out, cat copy); here each stage writes straight into
+// the layout its consumer reads:
+//     conv (MFMA)  -> dense scratch D
+//     GN stats     <- D
+//     GN+ReLU+pool <- D -> zero-haloed input of the next conv | channel slice of the concat buffer
+//     trilinear up -> the other channel slice of the concat buffer          (no torch.cat copy)
+//     1x1x1 fuse   <- concat buffer viewed as [C][V]
+//     heads        <- X4, one read, all activations + grid + bandwidth fused
+// All buffers live in one caller-provided workspace whose halos are zeroed once.
+#include "common.h"
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+namespace stemseg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- profiler ----------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int tag; double work; };
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+constexpr size_t PROF_MAX = 1 << 16;
+
+void* profile_begin(int tag, double work, hipStream_t s) {
+    if (!g_prof_on) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() >= PROF_MAX) return nullptr;
+    ProfRec r;
+    r.tag = tag; r.work = work;
+    if (hipEventCreate(&r.a) != hipSuccess) return nullptr;
+    if (hipEventCreate(&r.b) != hipSuccess) { hipEventDestroy(r.a); return nullptr; }
+    hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    return reinterpret_cast<void*>(g_prof.size());   // index + 1
+}
+void profile_end(void* handle, hipStream_t s) {
+    if (!handle) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const size_t i = reinterpret_cast<size_t>(handle) - 1;
+    if (i < g_prof.size()) hipEventRecord(g_prof[i].b, s);
+}
+
+struct DecoderPlan {
+    int cin, c32, c16, c8, c4, T, G;
+    int h[4], w[4];                 // 32x, 16x, 8x, 4x
+    int Ta1, Ta2, Ta3, Tb1, Tb2, Tc1, T16, T8;
+    // workspace offsets in floats
+    int64_t pin[4], D, P32b, P32c, X32, cat16, P16b, X16, cat8, X8, cat4, X4, stats, gn_scratch, total;
+};
+
+static inline int pooled(int T, int on) { return on ? (T + 1) / 2 : T; }
+
+static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
+    SS_CHECK_ARG(d, "decoder: null descriptor");
+    SS_CHECK_ARG(d->struct_bytes == (int32_t)sizeof(StemsegDecoderDesc), "decoder: descriptor size mismatch (%d vs %d): ABI skew",
+                 d->struct_bytes, (int)sizeof(StemsegDecoderDesc));
+    SS_CHECK_ARG(d->T >= 1 && d->H4 >= 8 && d->W4 >= 8 && d->H4 % 8 == 0 && d->W4 % 8 == 0,
+                 "decoder: T=%d H4=%d W4=%d (H4, W4 must be positive multiples of 8)", d->T, d->H4, d->W4);
+    SS_CHECK_ARG(d->in_channels % 4 == 0 && d->in_channels > 0, "decoder: in_channels %% 4");
+    for (int i = 0; i < 4; ++i) SS_CHECK_ARG(d->inter[i] > 0 && d->inter[i] % 32 == 0 && d->inter[i] % d->gn_groups == 0,
+                                             "decoder: inter[%d]=%d must be a multiple of 32 and of gn_groups", i, d->inter[i]);
+    SS_CHECK_ARG(d->n_out >= 1 && d->n_out <= 8, "decoder: n_out=%d", d->n_out);
+    SS_CHECK_ARG(d->input_layout >= 0 && d->input_layout <= 2, "decoder: input_layout");
+    p.cin = d->in_channels; p.c32 = d->inter[0]; p.c16 = d->inter[1]; p.c8 = d->inter[2]; p.c4 = d->inter[3];
+    p.T = d->T; p.G = d->gn_groups;
+    for (int i = 0; i < 4; ++i) { p.h[i] = d->H4 >> (3 - i); p.w[i] = d->W4 >> (3 - i); }
+    p.Ta1 = pooled(p.T, d->pool[0]); p.Ta2 = pooled(p.Ta1, d->pool[1]); p.Ta3 = pooled(p.Ta2, d->pool[2]);
+    p.Tb1 = pooled(p.T, d->pool[0]); p.Tb2 = pooled(p.Tb1, d->pool[1]);
+    p.Tc1 = pooled(p.T, d->pool[0]);
+    p.T16 = p.Ta3 * d->t_scale[0];
+    p.T8 = p.T16 * d->t_scale[1];
+    SS_CHECK_ARG(p.T16 == p.Tb2 && p.T8 == p.Tc1 && p.T8 * d->t_scale[2] == p.T,
+                 "decoder: pool / t_scale tables inconsistent for T=%d (32x->%d*%d vs 16x %d; ->%d vs 8x %d; ->%d vs %d)", p.T, p.Ta3,
+                 d->t_scale[0], p.Tb2, p.T8, p.Tc1, p.T8 * d->t_scale[2], p.T);
+    int64_t off = 0;
+    auto take = [&](int64_t floats) { int64_t o = off; off += round_up(floats, 64); return o; };
+    for (int i = 0; i < 4; ++i) p.pin[i] = (d->input_layout == 2) ? -1 : take(PaddedGeom(p.cin, p.T, p.h[i], p.w[i]).total);
+    int64_t dmax = 0;
+    dmax = std::max<int64_t>(dmax, (int64_t)p.c32 * p.T * p.h[0] * p.w[0]);
+    dmax = std::max<int64_t>(dmax, (int64_t)p.c16 * p.T * p.h[1] * p.w[1]);
+    dmax = std::max<int64_t>(dmax, (int64_t)p.c8 * p.T * p.h[2] * p.w[2]);
+    dmax = std::max<int64_t>(dmax, (int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
+    p.D = take(dmax);
+    p.P32b = take(PaddedGeom(p.c32, p.Ta1, p.h[0], p.w[0]).total);
+    p.P32c = take(PaddedGeom(p.c32, p.Ta2, p.h[0], p.w[0]).total);
+    p.X32 = take((int64_t)p.c32 * p.Ta3 * p.h[0] * p.w[0]);
+    p.cat16 = take((int64_t)(p.c32 + p.c16) * p.T16 * p.h[1] * p.w[1]);
+    p.P16b = take(PaddedGeom(p.c16, p.Tb1, p.h[1], p.w[1]).total);
+    p.X16 = take((int64_t)p.c16 * p.T16 * p.h[1] * p.w[1]);
+    p.cat8 = take((int64_t)(p.c16 + p.c8) * p.T8 * p.h[2] * p.w[2]);
+    p.X8 = take((int64_t)p.c8 * p.T8 * p.h[2] * p.w[2]);
+    p.cat4 = take((int64_t)(p.c8 + p.c4) * p.T * p.h[3] * p.w[3]);
+    p.X4 = take((int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
+    p.stats = take(2 * 64);
+    p.gn_scratch = take(2 * 64 * 128);   // doubles: groups(<=64) * GN_SPLIT(64) * 2
+    p.total = off;
+    SS_CHECK_ARG(p.G <= 64, "decoder: gn_groups > 64");
+    return STEMSEG_OK;
+}
+
+// channel slice [c0, c0+C) of a dense [Ctot][T][H][W] buffer
+static inline StemsegVolume slice_volume(float* base, int c0, int C, int T, int H, int W) {
+    const int64_t cs = (int64_t)T * H * W;
+    return make_volume(base + (int64_t)c0 * cs, cs, (int64_t)H * W, W, C, T, H, W, (int64_t)C * cs);
+}
+// dense [C][V] viewed as a 1-row volume for the 1x1x1 convolution
+static inline StemsegVolume flat_volume(float* base, int C, int64_t V) {
+    return make_volume(base, V, 0, 0, C, 1, 1, (int)V, (int64_t)C * V);
+}
+
+static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b, const float* gw, const float* gb, int Cout, int T, int H,
+                   int W, int pool, const StemsegVolume& dst, float* D, float* stats, double* scratch, int G, float eps, hipStream_t s) {
+    StemsegVolume d = dense_volume(D, Cout, T, H, W);
+    int rc = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s);
+    if (rc) return rc;
+    rc = launch_gn_stats(D, Cout, (int64_t)T * H * W, G, eps, stats, scratch, s);
+    if (rc) return rc;
+    return launch_gn_relu_pool(D, Cout, T, H, W, G, stats, gw, gb, pool, dst, s);
+}
+
+}  // namespace stemseg
+
+using namespace stemseg;
+
+extern "C" int stemseg_hip_version(void) { return STEMSEG_HIP_ABI_VERSION; }
+extern "C" const char* stemseg_hip_last_error(void) { return g_err; }
+extern "C" int stemseg_hip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return STEMSEG_E_HIP;
+    }
+    return n;
+}
+
+extern "C" int stemseg_hip_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return STEMSEG_OK;
+}
+
+// Synchronises the device, then sums (elapsed ms, work, launches) per tag into out[tag*3 + {0,1,2}] and clears the log.
+extern "C" int stemseg_hip_profile_read(double* out_host, int32_t n_tags) {
+    SS_CHECK_ARG(out_host && n_tags > 0, "profile_read: bad arguments");
+    SS_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < n_tags * 3; ++i) out_host[i] = 0.0;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.tag >= 0 && r.tag < n_tags) {
+            out_host[r.tag * 3 + 0] += ms;
+            out_host[r.tag * 3 + 1] += r.work;
+            out_host[r.tag * 3 + 2] += 1.0;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_padded_geometry(int32_t C, int32_t T, int32_t H, int32_t W, int64_t out[5]) {
+    SS_CHECK_ARG(out && C > 0 && T > 0 && H > 0 && W > 0, "padded_geometry: bad arguments");
+    PaddedGeom g(C, T, H, W);
+    out[0] = g.pitch; out[1] = g.ts; out[2] = g.cs; out[3] = g.total; out[4] = g.interior;
+    return STEMSEG_OK;
+}
+
+extern "C" size_t stemseg_hip_decoder_workspace_bytes(const StemsegDecoderDesc* desc) {
+    DecoderPlan p;
+    if (make_plan(desc, p) != STEMSEG_OK) return 0;
+    return (size_t)p.total * sizeof(float);
+}
+
+extern "C" int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc, void* workspace, size_t ws_bytes, void* stream) {
+    DecoderPlan p;
+    int rc = make_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(workspace) % 256 == 0), "decoder: workspace must be 256-byte aligned");
+    if (ws_bytes < (size_t)p.total * sizeof(float)) {
+        set_error("decoder: workspace too small (%zu < %zu bytes)", ws_bytes, (size_t)p.total * sizeof(float));
+        return STEMSEG_E_WORKSPACE;
+    }
+    SS_HIP(hipMemsetAsync(workspace, 0, (size_t)p.total * sizeof(float), as_stream(stream)));
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* wts, const float* const feats[4],
+                                           float* out, void* workspace, size_t ws_bytes, void* stream) {
+    DecoderPlan p;
+    int rc = make_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(wts && feats && out && workspace, "decoder_forward: null pointer");
+    if (ws_bytes < (size_t)p.total * sizeof(float)) {
+        set_error("decoder: workspace too small (%zu < %zu bytes)", ws_bytes, (size_t)p.total * sizeof(float));
+        return STEMSEG_E_WORKSPACE;
+    }
+    for (int i = 0; i < 7; ++i) SS_CHECK_ARG(wts->conv_w[i] && wts->conv_b[i] && wts->gn_w[i] && wts->gn_b[i], "decoder_forward: null block weight %d", i);
+    for (int i = 0; i < 3; ++i) SS_CHECK_ARG(wts->fuse_w[i], "decoder_forward: null fuse weight %d", i);
+    SS_CHECK_ARG(wts->head_w, "decoder_forward: null head weight");
+    for (int i = 0; i < 4; ++i) SS_CHECK_ARG(feats[i], "decoder_forward: null feature map %d", i);
+
+    hipStream_t s = as_stream(stream);
+    float* ws = reinterpret_cast<float*>(workspace);
+    float* D = ws + p.D;
+    float* stats = ws + p.stats;
+    double* scratch = reinterpret_cast<double*>(ws + p.gn_scratch);
+    const float eps = desc->gn_eps;
+    const int G = p.G, T = p.T;
+
+    // 0. inputs into the zero-haloed layout (skipped when the caller already provides it)
+    float* pin[4];
+    for (int i = 0; i < 4; ++i) {
+        if (desc->input_layout == 2) pin[i] = const_cast<float*>(feats[i]);
+        else {
+            pin[i] = ws + p.pin[i];
+            rc = launch_copy_to_volume(feats[i], desc->input_layout, padded_interior_view(pin[i], p.cin, T, p.h[i], p.w[i]), s);
+            if (rc) return rc;
+        }
+    }
+    // 1. block_32x: three conv/GN/ReLU(/pool) stages  (embedding_decoder.py:20-35)
+    rc = conv_gn(padded_halo_view(pin[0], p.cin, T, p.h[0], p.w[0]), wts->conv_w[0], wts->conv_b[0], wts->gn_w[0], wts->gn_b[0], p.c32, T,
+                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    rc = conv_gn(padded_halo_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), wts->conv_w[1], wts->conv_b[1], wts->gn_w[1], wts->gn_b[1], p.c32,
+                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    rc = conv_gn(padded_halo_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), wts->conv_w[2], wts->conv_b[2], wts->gn_w[2], wts->gn_b[2], p.c32,
+                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    // 2. 32x -> 16x: upsample into cat16[0:c32], block_16x into cat16[c32:], 1x1x1 fuse  (:112-117)
+    rc = launch_upsample(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2,
+                         slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s);
+    if (rc) return rc;
+    rc = conv_gn(padded_halo_view(pin[1], p.cin, T, p.h[1], p.w[1]), wts->conv_w[3], wts->conv_b[3], wts->gn_w[3], wts->gn_b[3], p.c16, T,
+                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    rc = conv_gn(padded_halo_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), wts->conv_w[4], wts->conv_b[4], wts->gn_w[4], wts->gn_b[4], p.c16,
+                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    const int64_t V16 = (int64_t)p.T16 * p.h[1] * p.w[1], V8 = (int64_t)p.T8 * p.h[2] * p.w[2], V4 = (int64_t)T * p.h[3] * p.w[3];
+    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s);
+    if (rc) return rc;
+    // 3. 16x -> 8x  (:119-123)
+    rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
+                         slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s);
+    if (rc) return rc;
+    rc = conv_gn(padded_halo_view(pin[2], p.cin, T, p.h[2], p.w[2]), wts->conv_w[5], wts->conv_b[5], wts->gn_w[5], wts->gn_b[5], p.c8, T, p.h[2],
+                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s);
+    if (rc) return rc;
+    // 4. 8x -> 4x  (:125-129)
+    rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s);
+    if (rc) return rc;
+    rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D, stats, scratch, G, eps, s);
+    if (rc) return rc;
+    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, s);
+    if (rc) return rc;
+    // 5. heads (:131-143)
+    HeadSpec hs;
+    hs.n_out = desc->n_out;
+    for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
+    return launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, s);
+}

@@ -1,0 +1,138 @@
+// Fused output heads: three 1x1x1 convs + activations + coordinate grid + bandwidth activation in one pass.
+//
+// Reference: /root/reference/stemseg/modeling/embedding_decoder.py:131-143
+//   emb = tanh(0.25 * conv_embedding(x)) + grid ; var = conv_variance(x) (+bias) ; seed = sigmoid(conv_seediness(x))
+// seediness_decoder.py:112 (sigmoid(conv_out(x))) and modeling/inference_model.py:148 (bandwidth = exp(var) * 10).
+// The reference reads the 128-channel feature tensor three times (three convs) and runs five more elementwise
+// kernels; here it is read exactly once (HBM-bound: 4*Cin bytes in, 4*n_out bytes out per voxel).
+#include "common.h"
+#include <algorithm>
+
+namespace stemseg {
+
+constexpr int HEADS_MAX_OUT = STEMSEG_MAX_EMB_DIMS * 2;
+
+struct HeadsParams {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* gt;
+    const float* gy;
+    const float* gx;
+    float* out;
+    int Cin, T, H, W;
+    int64_t V;
+    int act[HEADS_MAX_OUT];
+    int axis[HEADS_MAX_OUT];
+};
+
+__device__ __forceinline__ float head_act(float z, int act, float grid) {
+    switch (act) {
+        case 1: return tanhf(0.25f * z) + grid;
+        case 2: return 1.0f / (1.0f + expf(-z));
+        case 3: return expf(z) * 10.0f;
+        case 4: return z + grid;
+        default: return z;
+    }
+}
+
+// one thread = 4 consecutive voxels (float4 loads along W), NOUT accumulators each
+template <int NOUT>
+__global__ __launch_bounds__(256) void heads_kernel(const HeadsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [NOUT][Cin]
+    for (int i = threadIdx.x; i < NOUT * p.Cin; i += blockDim.x) w_lds[i] = p.w[i];
+    __syncthreads();
+    const int64_t nq = p.V / 4;
+    const int64_t HW = (int64_t)p.H * p.W;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        float4 acc[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* xp = reinterpret_cast<const float4*>(p.x) + q;
+        for (int c = 0; c < p.Cin; c += 4) {
+            float4 xv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[k] = xp[(int64_t)(c + k) * nq];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float4 wv = *reinterpret_cast<const float4*>(w_lds + o * p.Cin + c);   // LDS broadcast
+                acc[o].x += wv.x * xv[0].x; acc[o].y += wv.x * xv[0].y; acc[o].z += wv.x * xv[0].z; acc[o].w += wv.x * xv[0].w;
+                acc[o].x += wv.y * xv[1].x; acc[o].y += wv.y * xv[1].y; acc[o].z += wv.y * xv[1].z; acc[o].w += wv.y * xv[1].w;
+                acc[o].x += wv.z * xv[2].x; acc[o].y += wv.z * xv[2].y; acc[o].z += wv.z * xv[2].z; acc[o].w += wv.z * xv[2].w;
+                acc[o].x += wv.w * xv[3].x; acc[o].y += wv.w * xv[3].y; acc[o].z += wv.w * xv[3].z; acc[o].w += wv.w * xv[3].w;
+            }
+        }
+        // voxel coordinates of the 4 lanes (W % 4 == 0 so they share t and y)
+        const int64_t v0 = q * 4;
+        const int t = (int)(v0 / HW);
+        const int64_t r = v0 - (int64_t)t * HW;
+        const int y = (int)(r / p.W), x0 = (int)(r - (int64_t)y * p.W);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float b = p.bias ? p.bias[o] : 0.f;
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            const int ax = p.axis[o];
+            if (ax == 1) { g[0] = g[1] = g[2] = g[3] = p.gt[t]; }
+            else if (ax == 2) { g[0] = g[1] = g[2] = g[3] = p.gy[y]; }
+            else if (ax == 3) { g[0] = p.gx[x0]; g[1] = p.gx[x0 + 1]; g[2] = p.gx[x0 + 2]; g[3] = p.gx[x0 + 3]; }
+            float4 o4;
+            o4.x = head_act(acc[o].x + b, p.act[o], g[0]);
+            o4.y = head_act(acc[o].y + b, p.act[o], g[1]);
+            o4.z = head_act(acc[o].z + b, p.act[o], g[2]);
+            o4.w = head_act(acc[o].w + b, p.act[o], g[3]);
+            reinterpret_cast<float4*>(p.out + (int64_t)o * p.V)[q] = o4;
+        }
+    }
+}
+
+template <int NOUT>
+static int launch_heads_n(const HeadsParams& p, hipStream_t s) {
+    const int64_t nq = p.V / 4;
+    const int blocks = (int)std::min<int64_t>(ceil_div(nq, 256), 256 * 8);
+    hipLaunchKernelGGL(heads_kernel<NOUT>, dim3(blocks), dim3(256), (size_t)NOUT * p.Cin * sizeof(float), s, p);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s) {
+    SS_CHECK_ARG(x && w && out, "heads: null pointer");
+    SS_CHECK_ARG(hs.n_out >= 1 && hs.n_out <= 8, "heads: n_out=%d unsupported (1..8)", hs.n_out);
+    SS_CHECK_ARG(Cin % 4 == 0 && W % 4 == 0, "heads: Cin %% 4 == 0 and W %% 4 == 0 required (Cin=%d, W=%d)", Cin, W);
+    SS_CHECK_ARG((reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0), "heads: 16-byte alignment");
+    HeadsParams p;
+    p.x = x; p.w = w; p.bias = bias; p.gt = gt; p.gy = gy; p.gx = gx; p.out = out;
+    p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.V = (int64_t)T * H * W;
+    for (int o = 0; o < HEADS_MAX_OUT; ++o) { p.act[o] = 0; p.axis[o] = 0; }
+    for (int o = 0; o < hs.n_out; ++o) {
+        p.act[o] = hs.act[o];
+        p.axis[o] = hs.grid_axis[o];
+        SS_CHECK_ARG(p.act[o] >= 0 && p.act[o] <= 4 && p.axis[o] >= 0 && p.axis[o] <= 3, "heads: bad act/axis code for channel %d", o);
+        const bool needs_grid = (p.act[o] == 1 || p.act[o] == 4) && p.axis[o] != 0;
+        if (!needs_grid) p.axis[o] = 0;
+        SS_CHECK_ARG(!needs_grid || (gt && gy && gx), "heads: grid vectors required for channel %d", o);
+    }
+    switch (hs.n_out) {
+        case 1: return launch_heads_n<1>(p, s);
+        case 2: return launch_heads_n<2>(p, s);
+        case 3: return launch_heads_n<3>(p, s);
+        case 4: return launch_heads_n<4>(p, s);
+        case 5: return launch_heads_n<5>(p, s);
+        case 6: return launch_heads_n<6>(p, s);
+        case 7: return launch_heads_n<7>(p, s);
+        default: return launch_heads_n<8>(p, s);
+    }
+}
+
+}  // namespace stemseg
+
+extern "C" int stemseg_hip_heads(const float* x, int32_t Cin, int32_t T, int32_t H, int32_t W, const float* w, const float* bias,
+                                 int32_t n_out, const int32_t* act_host, const int32_t* grid_axis_host, const float* grid_t,
+                                 const float* grid_y, const float* grid_x, float* out, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(act_host && grid_axis_host && n_out >= 1 && n_out <= 8, "heads: bad head spec");
+    HeadSpec hs;
+    hs.n_out = n_out;
+    for (int o = 0; o < n_out; ++o) { hs.act[o] = act_host[o]; hs.grid_axis[o] = grid_axis_host[o]; }
+    return launch_heads(x, Cin, T, H, W, w, bias, hs, grid_t, grid_y, grid_x, out, as_stream(stream));
+}

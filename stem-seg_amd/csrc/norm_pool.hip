@@ -1,0 +1,180 @@
+// GroupNorm statistics and the fused GroupNorm-apply + ReLU + temporal-stride-2 average pool.
+//
+// Reference ops: nn.GroupNorm(32, C) (model_builder.py:32-34, eps 1e-5, biased variance), nn.ReLU and
+// nn.AvgPool3d(3, stride=(2,1,1), padding=1) with count_include_pad (divide by 27 always) as instantiated
+// in /root/reference/stemseg/modeling/embedding_decoder.py:20-60.  All HBM-bound: the statistics pass reads
+// the conv output once; the apply pass reads it once more and writes the (T/2) result straight into the next
+// consumer's layout (zero-haloed conv input or a channel slice of a concat buffer), so ReLU and the pool
+// never touch HBM on their own.
+#include "common.h"
+#include <algorithm>
+
+namespace stemseg {
+
+constexpr int GN_SPLIT = 64;   // partial sums per group (deterministic two-level reduction, no atomics)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// grid = (GN_SPLIT, groups).  A group is a contiguous block of cpg*S floats.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, int64_t group_elems,
+                                                         double* __restrict__ partial) {
+    const int g = blockIdx.y, sp = blockIdx.x;
+    const int64_t per = (group_elems + GN_SPLIT - 1) / GN_SPLIT;
+    const int64_t per4 = (per + 3) & ~int64_t(3);
+    const int64_t beg = (int64_t)sp * per4;
+    const int64_t end = (beg + per4 < group_elems) ? beg + per4 : group_elems;
+    const float* base = x + (int64_t)g * group_elems;
+    float s = 0.f, ss = 0.f;
+    const bool vec = ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+    if (vec) {
+        const int64_t n4 = (end > beg) ? (end - beg) / 4 : 0;
+        const float4* b4 = reinterpret_cast<const float4*>(base + beg);
+        for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+            const float4 v = b4[i];
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        for (int64_t i = beg + n4 * 4 + threadIdx.x; i < end; i += blockDim.x) {
+            const float v = base[i];
+            s += v;
+            ss += v * v;
+        }
+    } else {
+        for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+            const float v = base[i];
+            s += v;
+            ss += v * v;
+        }
+    }
+    __shared__ double red[2][4];
+    double ds = wave_sum((double)s), dss = wave_sum((double)ss);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = ds; red[1][w] = dss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((int64_t)g * GN_SPLIT + sp) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[((int64_t)g * GN_SPLIT + sp) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// one wave per group: fixed-order combine of the GN_SPLIT partials -> mean, rstd
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restrict__ partial, double group_elems, float eps,
+                                                         float* __restrict__ stats) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    if (lane < GN_SPLIT) {
+        s = partial[((int64_t)g * GN_SPLIT + lane) * 2 + 0];
+        ss = partial[((int64_t)g * GN_SPLIT + lane) * 2 + 1];
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const double mean = s / group_elems;
+        double var = ss / group_elems - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        stats[2 * g + 0] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+struct GnApplyParams {
+    const float* x;
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    float* out;
+    int64_t out_cs, out_ts, out_ys;
+    int C, T, H, W, To, cpg;
+};
+
+// one thread per output element, x fastest (coalesced stores; the 27 pool reads hit L1/L2)
+template <bool POOL>
+__global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t per_c = (int64_t)p.To * HW;
+    const int64_t total = per_c * p.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / per_c);
+        int64_t r = i - (int64_t)c * per_c;
+        const int to = (int)(r / HW);
+        r -= (int64_t)to * HW;
+        const int y = (int)(r / p.W), x = (int)(r - (int64_t)y * p.W);
+        const int g = c / p.cpg;
+        const float a = p.stats[2 * g + 1] * p.gamma[c];
+        const float b = p.beta[c] - p.stats[2 * g] * a;
+        const float* xc = p.x + (int64_t)c * p.T * HW;
+        float v;
+        if (POOL) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dt = -1; dt <= 1; ++dt) {
+                const int t = 2 * to + dt;
+                if (t < 0 || t >= p.T) continue;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int yy = y + dy;
+                    if (yy < 0 || yy >= p.H) continue;
+                    const float* row = xc + (int64_t)t * HW + (int64_t)yy * p.W;
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int xx = x + dx;
+                        if (xx < 0 || xx >= p.W) continue;
+                        acc += fmaxf(fmaf(row[xx], a, b), 0.f);
+                    }
+                }
+            }
+            v = acc / 27.0f;
+        } else {
+            v = fmaxf(fmaf(xc[(int64_t)to * HW + (int64_t)y * p.W + x], a, b), 0.f);
+        }
+        p.out[(int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)y * p.out_ys + x] = v;
+    }
+}
+
+int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s) {
+    SS_CHECK_ARG(x && stats && scratch, "groupnorm_stats: null pointer");
+    SS_CHECK_ARG(groups > 0 && C % groups == 0 && S > 0, "groupnorm_stats: C=%d not divisible by groups=%d", C, groups);
+    const int64_t ge = (int64_t)(C / groups) * S;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SPLIT, groups), dim3(256), 0, s, x, ge, scratch);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups), dim3(64), 0, s, (const double*)scratch, (double)ge, eps, stats);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
+                        const float* beta, int pool, const StemsegVolume& out, hipStream_t s) {
+    SS_CHECK_ARG(x && stats && gamma && beta && out.ptr, "gn_relu_pool: null pointer");
+    const int To = pool ? (T + 1) / 2 : T;   // floor((T + 2 - 3)/2) + 1
+    SS_CHECK_ARG(out.C == C && out.T == To && out.H == H && out.W == W,
+                 "gn_relu_pool: output volume (%d,%d,%d,%d) != expected (%d,%d,%d,%d)", out.C, out.T, out.H, out.W, C, To, H, W);
+    GnApplyParams p;
+    p.x = x; p.stats = stats; p.gamma = gamma; p.beta = beta;
+    p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
+    p.C = C; p.T = T; p.H = H; p.W = W; p.To = To; p.cpg = C / groups;
+    const int64_t total = (int64_t)C * To * H * W;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+    if (pool) hipLaunchKernelGGL(gn_relu_pool_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gn_relu_pool_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+}  // namespace stemseg
+
+extern "C" int stemseg_hip_groupnorm_stats(const float* x, int32_t C, int64_t S, int32_t groups, float eps, float* stats,
+                                           double* scratch, void* stream) {
+    return stemseg::launch_gn_stats(x, C, S, groups, eps, stats, scratch, stemseg::as_stream(stream));
+}
+
+extern "C" int stemseg_hip_gn_relu_pool(const float* x, int32_t C, int32_t T, int32_t H, int32_t W, int32_t groups,
+                                        const float* stats, const float* gamma, const float* beta, int32_t pool,
+                                        const StemsegVolume* out, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(out, "gn_relu_pool: null volume");
+    return launch_gn_relu_pool(x, C, T, H, W, groups, stats, gamma, beta, pool, *out, as_stream(stream));
+}

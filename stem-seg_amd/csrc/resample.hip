@@ -1,0 +1,127 @@
+// Trilinear up-sampling and the layout copy into (zero-haloed) volumes.  HBM-bound streaming kernels.
+//
+// Reference: UpsampleTrilinear3D.forward = F.interpolate(mode='trilinear', align_corners=False)
+// (/root/reference/stemseg/modeling/common.py:77-78, used at embedding_decoder.py:64-79) and the x4 resize of
+// OnlineChainer.resize_tensors (inference/online_chainer.py:127-140).  Per axis, for integer scale s:
+//   src = max((dst + 0.5) / s - 0.5, 0) ; i0 = floor(src) ; i1 = min(i0 + 1, n - 1) ; w1 = src - i0.
+#include "common.h"
+#include <algorithm>
+
+namespace stemseg {
+
+struct UpParams {
+    const float* in;
+    float* out;
+    int64_t out_cs, out_ts, out_ys;
+    int C, T, H, W, To, Ho, Wo;
+    float rt, ry, rx;   // 1/scale
+};
+
+__device__ __forceinline__ void src_index(int dst, float rscale, int n, int& i0, int& i1, float& w1) {
+    // ATen area_pixel_compute_source_index(align_corners=false): scale*(dst+0.5)-0.5, clamped at 0
+    float src = rscale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + ((i0 < n - 1) ? 1 : 0);
+    w1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void upsample_trilinear_kernel(const UpParams p) {
+    const int64_t HWo = (int64_t)p.Ho * p.Wo;
+    const int64_t per_c = (int64_t)p.To * HWo;
+    const int64_t total = per_c * p.C;
+    const int64_t HW = (int64_t)p.H * p.W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / per_c);
+        int64_t r = i - (int64_t)c * per_c;
+        const int to = (int)(r / HWo);
+        r -= (int64_t)to * HWo;
+        const int yo = (int)(r / p.Wo), xo = (int)(r - (int64_t)yo * p.Wo);
+        int t0, t1, y0, y1, x0, x1;
+        float wt, wy, wx;
+        src_index(to, p.rt, p.T, t0, t1, wt);
+        src_index(yo, p.ry, p.H, y0, y1, wy);
+        src_index(xo, p.rx, p.W, x0, x1, wx);
+        const float* b = p.in + (int64_t)c * p.T * HW;
+        const float* p00 = b + (int64_t)t0 * HW + (int64_t)y0 * p.W;
+        const float* p01 = b + (int64_t)t0 * HW + (int64_t)y1 * p.W;
+        const float* p10 = b + (int64_t)t1 * HW + (int64_t)y0 * p.W;
+        const float* p11 = b + (int64_t)t1 * HW + (int64_t)y1 * p.W;
+        const float ut = 1.f - wt, uy = 1.f - wy, ux = 1.f - wx;
+        // same association as ATen's upsample_trilinear3d: t-weights outside, y inside, x innermost
+        const float v = ut * (uy * (ux * p00[x0] + wx * p00[x1]) + wy * (ux * p01[x0] + wx * p01[x1])) +
+                        wt * (uy * (ux * p10[x0] + wx * p10[x1]) + wy * (ux * p11[x0] + wx * p11[x1]));
+        p.out[(int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)yo * p.out_ys + xo] = v;
+    }
+}
+
+struct CopyParams {
+    const float* in;
+    float* out;
+    int64_t out_cs, out_ts, out_ys;
+    int64_t in_c, in_t;   // input strides in floats for (c, t)
+    int C, T, H, W;
+};
+
+__global__ __launch_bounds__(256) void copy_to_volume_kernel(const CopyParams p) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int64_t per_c = (int64_t)p.T * HW;
+    const int64_t total = per_c * p.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / per_c);
+        int64_t r = i - (int64_t)c * per_c;
+        const int t = (int)(r / HW);
+        r -= (int64_t)t * HW;
+        const int y = (int)(r / p.W), x = (int)(r - (int64_t)y * p.W);
+        p.out[(int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x] =
+            p.in[(int64_t)c * p.in_c + (int64_t)t * p.in_t + r];
+    }
+}
+
+int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy, int sx, const StemsegVolume& out,
+                    hipStream_t s) {
+    SS_CHECK_ARG(in && out.ptr, "upsample: null pointer");
+    SS_CHECK_ARG(st >= 1 && sy >= 1 && sx >= 1, "upsample: scale factors must be >= 1");
+    SS_CHECK_ARG(out.C == C && out.T == T * st && out.H == H * sy && out.W == W * sx,
+                 "upsample: output volume (%d,%d,%d,%d) != (%d,%d,%d,%d)", out.C, out.T, out.H, out.W, C, T * st, H * sy, W * sx);
+    UpParams p;
+    p.in = in; p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
+    p.C = C; p.T = T; p.H = H; p.W = W; p.To = T * st; p.Ho = H * sy; p.Wo = W * sx;
+    p.rt = 1.0f / (float)st; p.ry = 1.0f / (float)sy; p.rx = 1.0f / (float)sx;
+    const int64_t total = (int64_t)C * p.To * p.Ho * p.Wo;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(blocks), dim3(256), 0, s, p);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+int launch_copy_to_volume(const float* in, int layout, const StemsegVolume& out, hipStream_t s) {
+    SS_CHECK_ARG(in && out.ptr, "copy_to_volume: null pointer");
+    SS_CHECK_ARG(layout == 0 || layout == 1, "copy_to_volume: layout must be 0 ([C][T][H][W]) or 1 ([T][C][H][W])");
+    CopyParams p;
+    p.in = in; p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
+    p.C = out.C; p.T = out.T; p.H = out.H; p.W = out.W;
+    const int64_t HW = (int64_t)out.H * out.W;
+    if (layout == 0) { p.in_c = (int64_t)out.T * HW; p.in_t = HW; }
+    else { p.in_c = HW; p.in_t = (int64_t)out.C * HW; }
+    const int64_t total = (int64_t)out.C * out.T * HW;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(copy_to_volume_kernel, dim3(blocks), dim3(256), 0, s, p);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+}  // namespace stemseg
+
+extern "C" int stemseg_hip_upsample_trilinear(const float* in, int32_t C, int32_t T, int32_t H, int32_t W, int32_t st, int32_t sy,
+                                              int32_t sx, const StemsegVolume* out, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(out, "upsample: null volume");
+    return launch_upsample(in, C, T, H, W, st, sy, sx, *out, as_stream(stream));
+}
+
+extern "C" int stemseg_hip_copy_to_volume(const float* in, int32_t layout, const StemsegVolume* out, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(out, "copy_to_volume: null volume");
+    return launch_copy_to_volume(in, layout, *out, as_stream(stream));
+}

@@ -1,0 +1,310 @@
+"""ctypes binding of libstemseg_hip.so (include/stemseg_hip.h).
+
+PyTorch appears here only as plumbing: it owns device memory (``tensor.data_ptr()``) and the HIP
+stream (``torch.cuda.current_stream().cuda_stream``).  Every numeric operation of the hot path runs in
+the hand-written gfx950 kernels behind the C-ABI.  There is NO fallback: if the shared library is
+missing, or no GPU is visible, the ops raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstemseg_hip.so")
+
+MAX_INSTANCES = 64
+MAX_EMB_DIMS = 8
+ABI_VERSION = 1
+
+
+class Volume(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("c_stride", C.c_int64), ("t_stride", C.c_int64), ("y_stride", C.c_int64),
+                ("C", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("limit", C.c_int64)]
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("in_channels", C.c_int32), ("inter", C.c_int32 * 4),
+                ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
+                ("pool", C.c_int32 * 3), ("t_scale", C.c_int32 * 3), ("n_out", C.c_int32),
+                ("act", C.c_int32 * (2 * MAX_EMB_DIMS)), ("grid_axis", C.c_int32 * (2 * MAX_EMB_DIMS)),
+                ("input_layout", C.c_int32)]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("conv_w", C.c_void_p * 7), ("conv_b", C.c_void_p * 7), ("gn_w", C.c_void_p * 7), ("gn_b", C.c_void_p * 7),
+                ("fuse_w", C.c_void_p * 3), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+                ("grid_t", C.c_void_p), ("grid_y", C.c_void_p), ("grid_x", C.c_void_p)]
+
+
+class ClusterParams(C.Structure):
+    _fields_ = [("primary_prob_thresh", C.c_float), ("secondary_prob_thresh", C.c_float), ("min_seediness_prob", C.c_float),
+                ("max_instances", C.c_int32), ("n_free_dims", C.c_int32), ("free_dim_bandwidths", C.c_float * MAX_EMB_DIMS)]
+
+
+class ClusterMeta(C.Structure):
+    _fields_ = [("K", C.c_int32), ("exhausted", C.c_int32), ("n_points", C.c_int64), ("n_unassigned_last", C.c_int64),
+                ("centers", (C.c_float * MAX_EMB_DIMS) * MAX_INSTANCES), ("bandwidths", (C.c_float * MAX_EMB_DIMS) * MAX_INSTANCES),
+                ("seed_prob", C.c_float * MAX_INSTANCES)]
+
+
+# name -> (restype, argtypes); mirrors include/stemseg_hip.h one to one (tests check the export list)
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SIGNATURES = {
+    "stemseg_hip_version": (C.c_int, []),
+    "stemseg_hip_last_error": (C.c_char_p, []),
+    "stemseg_hip_device_count": (C.c_int, []),
+    "stemseg_hip_profile_enable": (C.c_int, [_I32]),
+    "stemseg_hip_profile_read": (C.c_int, [C.POINTER(C.c_double), _I32]),
+    "stemseg_hip_padded_geometry": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64)]),
+    "stemseg_hip_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P]),
+    "stemseg_hip_groupnorm_stats": (C.c_int, [_P, _I32, _I64, _I32, _F, _P, _P, _P]),
+    "stemseg_hip_gn_relu_pool": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, C.POINTER(Volume), _P]),
+    "stemseg_hip_upsample_trilinear": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(Volume), _P]),
+    "stemseg_hip_copy_to_volume": (C.c_int, [_P, _I32, C.POINTER(Volume), _P]),
+    "stemseg_hip_heads": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I32, C.POINTER(_I32), C.POINTER(_I32), _P, _P, _P, _P, _P]),
+    "stemseg_hip_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDesc)]),
+    "stemseg_hip_decoder_init_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, _P]),
+    "stemseg_hip_decoder_forward": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(_P), _P, _P, C.c_size_t, _P]),
+    "stemseg_hip_seediness_accumulate": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "stemseg_hip_fg_mask": (C.c_int, [_P, _F, _F, _P, _I64, _P]),
+    "stemseg_hip_fg_gather": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "stemseg_hip_cluster_workspace_bytes": (C.c_size_t, [_I64]),
+    "stemseg_hip_cluster": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, C.POINTER(ClusterParams), _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "stemseg_hip_overlap_counts": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "stemseg_hip_relabel": (C.c_int, [_P, _I64, _P, _I32, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libstemseg_hip.so not found at %s -- build it with `python stem-seg_amd/build.py` "
+                               "(hipcc --offload-arch=gfx950); the hot path has no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        v = l.stemseg_hip_version()
+        if v != ABI_VERSION:
+            raise RuntimeError("libstemseg_hip.so ABI version %d != binding %d" % (v, ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def require_gpu():
+    l = lib()
+    n = l.stemseg_hip_device_count()
+    if n <= 0 or not torch.cuda.is_available():
+        raise RuntimeError("stemseg_amd: no MI355X visible (hip device count %d, torch.cuda.is_available()=%s): %s"
+                           % (n, torch.cuda.is_available(), l.stemseg_hip_last_error().decode()))
+    return n
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libstemseg_hip error %d: %s" % (rc, lib().stemseg_hip_last_error().decode()))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor required"
+    assert t.is_contiguous(), "contiguous tensor required"
+    if dtype is not None:
+        assert t.dtype == dtype, "expected %s, got %s" % (dtype, t.dtype)
+    return C.c_void_p(t.data_ptr())
+
+
+def profile_enable(on):
+    check(lib().stemseg_hip_profile_enable(int(on)))
+
+
+def profile_read(n_tags=32):
+    """{tag: (ms, flops, launches)} for the convolution launches since the last read (synchronises)."""
+    buf = (C.c_double * (3 * n_tags))()
+    check(lib().stemseg_hip_profile_read(buf, n_tags))
+    return {t: (buf[3 * t], buf[3 * t + 1], int(buf[3 * t + 2])) for t in range(n_tags) if buf[3 * t + 2] > 0}
+
+
+# ------------------------------------------------------------------------------------------------ volumes
+def padded_geometry(Cn, T, H, W):
+    out = (C.c_int64 * 5)()
+    check(lib().stemseg_hip_padded_geometry(Cn, T, H, W, out))
+    return dict(pitch=out[0], ts=out[1], cs=out[2], total=out[3], interior=out[4])
+
+
+def dense_volume(t):
+    """t: contiguous [C,T,H,W] float32 cuda tensor."""
+    Cn, T, H, W = t.shape
+    return Volume(t.data_ptr(), T * H * W, H * W, W, Cn, T, H, W, t.numel())
+
+
+def flat_volume(t):
+    """t: contiguous [C, V] -> one-row volume for the 1x1x1 conv."""
+    Cn, V = t.shape[0], t[0].numel()
+    return Volume(t.data_ptr(), V, 0, 0, Cn, 1, 1, V, t.numel())
+
+
+def alloc_padded(Cn, T, H, W, device="cuda"):
+    g = padded_geometry(Cn, T, H, W)
+    return torch.zeros(g["total"], dtype=torch.float32, device=device), g
+
+
+def padded_halo_view(buf, g, Cn, T, H, W):
+    return Volume(buf.data_ptr(), g["cs"], g["ts"], g["pitch"], Cn, T + 2, H + 2, W + 2, g["total"])
+
+
+def padded_interior_view(buf, g, Cn, T, H, W):
+    return Volume(buf.data_ptr() + 4 * g["interior"], g["cs"], g["ts"], g["pitch"], Cn, T, H, W, g["total"] - g["interior"])
+
+
+def padded_to_dense(buf, g, Cn, T, H, W):
+    """Test helper: extract the interior of a zero-haloed buffer as a dense [C,T,H,W] tensor (torch indexing)."""
+    v = buf[:Cn * g["cs"]].view(Cn, T + 2, H + 2, g["pitch"])
+    return v[:, 1:T + 1, 1:H + 1, 1:W + 1].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ decoder ops
+def pack_conv_weight(w):
+    """w: [Cout, Cin, kt, kh, kw] -> packed [Cin/4][taps][4][Cout] (flat tensor)."""
+    w = w.contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    out = torch.empty(Cout * Cin * taps, dtype=torch.float32, device=w.device)
+    check(lib().stemseg_hip_pack_conv_weight(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, stream()))
+    return out
+
+
+def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0):
+    check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), k, k, k, tile_cfg, stream()))
+
+
+def groupnorm_stats(x, groups, eps=1e-5):
+    Cn = x.shape[0]
+    S = x[0].numel()
+    stats = torch.empty(2 * groups, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(groups * 128, dtype=torch.float64, device=x.device)
+    check(lib().stemseg_hip_groupnorm_stats(ptr(x, torch.float32), Cn, S, groups, eps, ptr(stats), ptr(scratch), stream()))
+    return stats
+
+
+def gn_relu_pool(x, groups, stats, gamma, beta, pool, vout):
+    Cn, T, H, W = x.shape
+    check(lib().stemseg_hip_gn_relu_pool(ptr(x, torch.float32), Cn, T, H, W, groups, ptr(stats), ptr(gamma), ptr(beta),
+                                         int(pool), C.byref(vout), stream()))
+
+
+def upsample_trilinear(x, st, sy, sx, vout=None):
+    Cn, T, H, W = x.shape
+    out = None
+    if vout is None:
+        out = torch.empty(Cn, T * st, H * sy, W * sx, dtype=torch.float32, device=x.device)
+        vout = dense_volume(out)
+    check(lib().stemseg_hip_upsample_trilinear(ptr(x, torch.float32), Cn, T, H, W, st, sy, sx, C.byref(vout), stream()))
+    return out
+
+
+def copy_to_volume(x, layout, vout):
+    check(lib().stemseg_hip_copy_to_volume(ptr(x, torch.float32), layout, C.byref(vout), stream()))
+
+
+def heads(x, w, bias, act, grid_axis, gt, gy, gx):
+    Cin, T, H, W = x.shape
+    n_out = w.shape[0]
+    out = torch.empty(n_out, T, H, W, dtype=torch.float32, device=x.device)
+    a = (C.c_int32 * n_out)(*act)
+    g = (C.c_int32 * n_out)(*grid_axis)
+    check(lib().stemseg_hip_heads(ptr(x, torch.float32), Cin, T, H, W, ptr(w.contiguous()), ptr(bias), n_out, a, g,
+                                  ptr(gt), ptr(gy), ptr(gx), ptr(out), stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ clustering ops
+def seediness_accumulate(acc, plane, first):
+    check(lib().stemseg_hip_seediness_accumulate(ptr(acc, torch.float32), ptr(plane, torch.float32), plane.numel(), int(first), stream()))
+
+
+def fg_mask(acc, count, thr):
+    mask = torch.empty(acc.shape, dtype=torch.uint8, device=acc.device)
+    check(lib().stemseg_hip_fg_mask(ptr(acc, torch.float32), float(count), float(thr), ptr(mask), acc.numel(), stream()))
+    return mask
+
+
+def fg_gather(emb, bw, seed, fg):
+    """emb [E,T,H,W], bw [Ev,T,H,W], seed [1,T,H,W] (or [T,H,W]), fg uint8 [T,H,W].
+    Returns max-size outputs (first N rows valid) + frame_offsets [T+1] int64 (device)."""
+    E, T, H, W = emb.shape
+    Ev = bw.shape[0]
+    V = T * H * W
+    dev = emb.device
+    emb_o = torch.empty(V, E, dtype=torch.float32, device=dev)
+    bw_o = torch.empty(V, max(Ev, 1), dtype=torch.float32, device=dev)[:, :Ev].contiguous() if Ev == 0 else \
+        torch.empty(V, Ev, dtype=torch.float32, device=dev)
+    seed_o = torch.empty(V, dtype=torch.float32, device=dev)
+    vox = torch.empty(V, dtype=torch.int32, device=dev)
+    offs = torch.empty(T + 1, dtype=torch.int64, device=dev)
+    scratch = torch.empty(16 * (V // 1024 + 4), dtype=torch.uint8, device=dev)
+    check(lib().stemseg_hip_fg_gather(ptr(emb, torch.float32), ptr(bw, torch.float32), ptr(seed, torch.float32), ptr(fg, torch.uint8),
+                                      E, Ev, T, H * W, ptr(emb_o), ptr(bw_o), ptr(seed_o), ptr(vox), ptr(offs), ptr(scratch), stream()))
+    return emb_o, bw_o, seed_o, vox, offs
+
+
+def make_cluster_params(primary, secondary, min_seed, max_instances, free_dim_stds):
+    p = ClusterParams()
+    p.primary_prob_thresh, p.secondary_prob_thresh, p.min_seediness_prob = primary, secondary, min_seed
+    p.max_instances = int(max_instances)
+    p.n_free_dims = len(free_dim_stds)
+    if len(free_dim_stds):
+        # 1 / std^2 exactly as clusterers.py:101-103 (fp32 tensor ops on the host: a handful of scalars)
+        fb = (1. / (torch.tensor(list(free_dim_stds), dtype=torch.float32) ** 2)).tolist()
+        for i, v in enumerate(fb):
+            p.free_dim_bandwidths[i] = v
+    return p
+
+
+def cluster(emb, bw, seed, params, label_start, n_points_dev=None, want_masks=False, want_probs=False):
+    """emb [Nmax,E], bw [Nmax,Ev], seed [Nmax].  Returns labels int64 [Nmax], meta (device uint8 blob), masks, probs."""
+    n_max, E = emb.shape
+    Ev = bw.shape[1]
+    dev = emb.device
+    labels = torch.empty(n_max, dtype=torch.int64, device=dev)
+    meta = torch.empty(C.sizeof(ClusterMeta), dtype=torch.uint8, device=dev)
+    masks = torch.empty(params.max_instances, n_max, dtype=torch.uint8, device=dev) if want_masks else None
+    probs = torch.empty(params.max_instances, n_max, dtype=torch.float32, device=dev) if want_probs else None
+    ws_bytes = lib().stemseg_hip_cluster_workspace_bytes(n_max)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib().stemseg_hip_cluster(ptr(emb, torch.float32), ptr(bw, torch.float32), ptr(seed, torch.float32), n_max,
+                                    ptr(n_points_dev), E, Ev, C.byref(params), int(label_start), ptr(labels), ptr(meta),
+                                    ptr(masks), ptr(probs), ptr(ws), ws_bytes, stream()))
+    return labels, meta, masks, probs
+
+
+def read_cluster_meta(meta_dev):
+    """Device->host copy of the StemsegClusterMeta record (synchronises the stream)."""
+    host = meta_dev.cpu().numpy().tobytes()
+    return ClusterMeta.from_buffer_copy(host)
+
+
+def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):
+    dev = labels_a.device
+    inter = torch.empty(max(Ka * Kb, 1), dtype=torch.int64, device=dev)
+    ca = torch.empty(max(Ka, 1), dtype=torch.int64, device=dev)
+    cb = torch.empty(max(Kb, 1), dtype=torch.int64, device=dev)
+    check(lib().stemseg_hip_overlap_counts(ptr(labels_a, torch.int64), ptr(labels_b, torch.int64), labels_a.numel(),
+                                           ptr(lut_a, torch.int32), lut_a.numel(), ptr(lut_b, torch.int32), lut_b.numel(),
+                                           Ka, Kb, ptr(inter), ptr(ca), ptr(cb), stream()))
+    return inter[:Ka * Kb].view(Ka, Kb), ca[:Ka], cb[:Kb]
+
+
+def relabel(labels, mapping):
+    check(lib().stemseg_hip_relabel(ptr(labels, torch.int64), labels.numel(), ptr(mapping, torch.int64), mapping.numel(), stream()))

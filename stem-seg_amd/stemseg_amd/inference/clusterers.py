@@ -1,0 +1,105 @@
+"""Sequential seed-and-threshold clustering on the HIP kernels.
+
+Drop-in for ``stemseg.inference.clusterers`` (ClustererBase :7-31, SequentialClustering :34-175): same
+constructor (inference/main.py:84-91), same call
+``clusterer(embeddings[N,E], bandwidths=[N,Ev], seediness=[N,1], cluster_label_start=int, return_label_masks=bool)
+-> (LongTensor[N] on the input's device, dict)`` (online_chainer.py:283-286), same ``reset_time_log`` /
+``average_time``.  The <= 20 rounds of the reference's Python loop become max_instances + 2 kernel launches with a
+single host read-back (K and the instance list) at the end.
+"""
+from collections import defaultdict
+from time import time as current_time
+
+import torch
+
+from .. import hip
+
+
+class ClustererBase(object):
+    def __init__(self):
+        self._time_log = defaultdict(list)
+
+    def __call__(self, embeddings, *args, **kwargs):
+        assert embeddings.dtype == torch.float32
+        t0 = current_time()
+        output = self._process(embeddings, *args, **kwargs)
+        self._time_log[embeddings.shape[0]].append(current_time() - t0)
+        return output
+
+    def _process(self, embeddings, *args, **kwargs):
+        raise NotImplementedError("Must be implemented by derived class")
+
+    def reset_time_log(self):
+        self._time_log = defaultdict(list)
+
+    @property
+    def average_time(self):
+        all_times = sum(list(self._time_log.values()), [])
+        return sum(all_times) / float(len(all_times))
+
+    name = property(fget=lambda self: self._name)
+
+
+class SequentialClustering(ClustererBase):
+    def __init__(self, primary_prob_thresh, secondary_prob_thresh, min_seediness_prob, n_free_dims, free_dim_stds, device,
+                 max_instances=20):
+        super().__init__()
+        self.thresholding_mode = "probability"
+        self.primary_prob_thresh = primary_prob_thresh
+        self.secondary_prob_thresh = secondary_prob_thresh
+        self.min_seediness_prob = min_seediness_prob
+        self.max_instances = max_instances
+        self.n_free_dims = n_free_dims
+        self.free_dim_stds = list(free_dim_stds)
+        self.device = device
+        assert len(self.free_dim_stds) >= n_free_dims or n_free_dims == 0
+
+    def _params(self):
+        return hip.make_cluster_params(self.primary_prob_thresh, self.secondary_prob_thresh, self.min_seediness_prob,
+                                       self.max_instances, self.free_dim_stds[:self.n_free_dims] if self.n_free_dims else [])
+
+    # ---- asynchronous form used by the clip pipeline: no host sync, N may live on the device ---------------
+    @torch.no_grad()
+    def enqueue(self, embeddings, bandwidths, seediness, cluster_label_start=1, n_points_dev=None,
+                return_label_masks=False, return_probs=False):
+        """Device tensors in; returns (labels[Nmax] int64, meta_dev, masks, probs) without synchronising."""
+        hip.require_gpu()
+        return hip.cluster(embeddings.contiguous(), bandwidths.contiguous(), seediness.reshape(-1).contiguous(), self._params(),
+                           cluster_label_start, n_points_dev, return_label_masks, return_probs)
+
+    def meta_to_dict(self, meta, E, label_start, masks=None, probs=None, n=None):
+        K = meta.K
+        out = {"instance_labels": [label_start + i for i in range(K)],
+               "instance_centers": [[float(meta.centers[i][e]) for e in range(E)] for i in range(K)],
+               "instance_stds": [], "instance_masks": []}
+        for i in range(K):
+            bw = torch.tensor([meta.bandwidths[i][e] for e in range(E)], dtype=torch.float32)
+            out["instance_stds"].append((1. / bw).clamp(min=1e-8).sqrt().tolist())       # clusterers.py:124
+        if masks is not None:
+            out["instance_masks"] = [masks[i, :n].bool().cpu() for i in range(K)]         # primary masks (A.2 quirk iii)
+        if probs is not None:
+            out["instance_probs"] = [probs[i, :n].cpu() for i in range(K)]
+        return out
+
+    @torch.no_grad()
+    def _process(self, embeddings, bandwidths, seediness, cluster_label_start=1, *args, **kwargs):
+        if embeddings.numel() == 0:
+            return torch.zeros(0, dtype=torch.long, device=embeddings.device), \
+                {'instance_labels': [], 'instance_centers': [], 'instance_stds': [], 'instance_masks': []}
+        input_device = embeddings.device
+        embeddings = embeddings.to(device=self.device)
+        assert torch.is_tensor(bandwidths) and torch.is_tensor(seediness)
+        if bandwidths.shape[0] != embeddings.shape[0]:
+            bandwidths = bandwidths.expand_as(embeddings)
+        bandwidths = bandwidths.to(device=self.device)
+        if self.n_free_dims == 0:
+            assert embeddings.shape == bandwidths.shape
+        seediness = seediness.to(device=self.device)
+        want_masks = kwargs.get("return_label_masks", False)
+        want_probs = kwargs.get("return_probs", False)
+        labels, meta_dev, masks, probs = self.enqueue(embeddings, bandwidths, seediness, cluster_label_start, None,
+                                                       want_masks, want_probs)
+        meta = hip.read_cluster_meta(meta_dev)          # the one host read-back
+        n = embeddings.shape[0]
+        info = self.meta_to_dict(meta, embeddings.shape[1], cluster_label_start, masks, probs, n)
+        return labels.to(input_device), info

@@ -1,0 +1,250 @@
+"""Per-clip clustering + cross-clip tracklet stitching.
+
+Counterpart of ``stemseg.inference.online_chainer`` (masks_to_coord_list :11-22, TrackContainer :25-117,
+OnlineChainer :120-343) with the same call signatures and return structure.  What changed underneath:
+  * head outputs stay on the GPU (the reference moves every clip D2H in inference_model.py:161-162 and H2D again here);
+  * the per-frame nonzero / permute / boolean-index / cat chain (:258-281) is one compaction (stemseg_hip_fg_gather);
+  * clustering is the multi-launch HIP clusterer with a single read-back;
+  * the K1 x K2 (2 reductions + 2 ``.item()``) association loop (:318-328) is one histogram kernel
+    (stemseg_hip_overlap_counts); the Hungarian step stays on the host (scipy), as in the reference;
+  * relabelling (:219-224) is one LUT kernel.
+Integer bookkeeping (label numbering, ``next_track_label = highest id + 1``, "previous clip only" overlap,
+no IoU threshold) follows SURVEY.md Appendix A.3 exactly.
+"""
+from collections import defaultdict
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from .. import hip
+
+
+def masks_to_coord_list(masks):
+    """masks [T,H,W] -> list over frames of (ys, xs) LongTensors, row-major order (online_chainer.py:11-22)."""
+    out = []
+    for t in range(masks.shape[0]):
+        idx = torch.nonzero(masks[t], as_tuple=False)
+        out.append((idx[:, 0], idx[:, 1]))
+    return out
+
+
+class TrackContainer(object):
+    """Final stitched labels per frame + the highest id seen (online_chainer.py:25-117)."""
+
+    def __init__(self, num_frames):
+        self._frame_labels = [None] * num_frames
+        self._highest_instance_id = 0
+
+    def add_labels(self, frame_nums, labels, max_label=None):
+        """labels: list of int64 tensors.  ``max_label`` (int) lets the caller supply max over the added labels
+        when it already has it on the host (avoids one device sync per frame)."""
+        assert all(self._frame_labels[t] is None for t in frame_nums)
+        for t, lab in zip(frame_nums, labels):
+            self._frame_labels[t] = lab
+            if max_label is None and lab.numel() > 0:
+                self._highest_instance_id = max(self._highest_instance_id, int(lab.max().item()))
+        if max_label is not None:
+            self._highest_instance_id = max(self._highest_instance_id, int(max_label))
+        return self._highest_instance_id + 1
+
+    def labels_exist(self, frame_num):
+        return self._frame_labels[frame_num] is not None
+
+    def has_fg_pixels(self, frame_num):
+        assert self.labels_exist(frame_num)
+        return self._frame_labels[frame_num].numel() > 0
+
+    def get_labels(self, frame_nums):
+        assert all(self.labels_exist(t) for t in frame_nums)
+        return [self._frame_labels[t] for t in frame_nums]
+
+    def get_track_mask_idxes(self):
+        """-> (labels per frame [CPU], {id: #pixels}, {id: last_frame - first_frame}); -1 is a key when outliers exist."""
+        counts, first, last = defaultdict(lambda: 0), {}, {}
+        frame_labels = [l.cpu() for l in self._frame_labels]
+        for t, lab in enumerate(frame_labels):
+            ids, n = np.unique(lab.numpy(), return_counts=True)
+            for i, c in zip(ids.tolist(), n.tolist()):
+                counts[i] += c
+                first[i] = min(first.get(i, 10000), t)
+                last[i] = max(last.get(i, -1), t)
+        return frame_labels, counts, {k: last[k] - first[k] for k in first}
+
+
+class HipChainerOps(object):
+    """Device operations of the chainer on libstemseg_hip.so (tests may inject an oracle-backed twin)."""
+
+    device = "cuda"
+
+    def to_device(self, t):
+        return t.to("cuda", non_blocking=True) if torch.is_tensor(t) else t
+
+    def resize(self, x, scale):
+        return hip.upsample_trilinear(x.contiguous().float(), 1, int(scale), int(scale))
+
+    def gather(self, emb, bw, seed, fg):
+        e, b, s, vox, offs = hip.fg_gather(emb.contiguous(), bw.contiguous(), seed.contiguous(), fg.contiguous())
+        return dict(emb=e, bw=b, seed=s, vox=vox, offs=offs, T=fg.shape[0])
+
+    def cluster(self, clusterer, pts, label_start, want_masks):
+        labels, meta_dev, masks, _ = clusterer.enqueue(pts["emb"], pts["bw"], pts["seed"], label_start,
+                                                       pts["offs"][pts["T"]:], want_masks)
+        return labels, meta_dev, masks
+
+    def read(self, pts, meta_dev):
+        offs = pts["offs"].cpu().tolist()                 # synchronises
+        return offs, hip.read_cluster_meta(meta_dev)
+
+    def overlap_counts(self, la, lb, ids_a, ids_b):
+        """ids_*: ascending candidate ids (> 0).  -> inter [Ka,Kb], cnt_a, cnt_b as numpy int64."""
+        def lut(ids):
+            t = torch.full((max(ids) + 2 if ids else 1,), -1, dtype=torch.int32)
+            for k, i in enumerate(ids):
+                t[i + 1] = k
+            return t.to(la.device)
+        inter, ca, cb = hip.overlap_counts(la.contiguous(), lb.contiguous(), lut(ids_a), lut(ids_b), len(ids_a), len(ids_b))
+        return inter.cpu().numpy(), ca.cpu().numpy(), cb.cpu().numpy()
+
+    def relabel(self, labels, mapping):
+        """mapping: dict old -> new.  In place."""
+        hi = max(mapping) + 2
+        m = torch.arange(-1, hi - 1, dtype=torch.int64)
+        for o, n in mapping.items():
+            m[o + 1] = n
+        hip.relabel(labels, m.to(labels.device))
+        return labels
+
+    def max_label(self, labels_list):
+        nz = [l for l in labels_list if l.numel() > 0]
+        return int(torch.cat(nz).max().item()) if nz else None
+
+
+class OnlineChainer(object):
+    OUTLIER_LABEL = -1
+
+    def __init__(self, clusterer, embedding_resize_factor, ops=None):
+        self.clusterer = clusterer
+        self.resize_scale = embedding_resize_factor
+        self.ops = ops if ops is not None else HipChainerOps()
+
+    @torch.no_grad()
+    def resize_tensors(self, subseq):
+        """x4 trilinear of embeddings, seediness and (already activated) bandwidths (online_chainer.py:127-140)."""
+        if self.resize_scale == 1.0:
+            return
+        for k in ("embeddings", "seediness", "bandwidths"):
+            subseq[k] = self.ops.resize(subseq[k], self.resize_scale)
+
+    @torch.no_grad()
+    def process(self, masks, subsequences, return_fg_embeddings=False):
+        ops = self.ops
+        num_frames = masks.shape[0]
+        masks = ops.to_device(masks)
+        H, W = masks.shape[-2:]
+        mask_idxes = [None] * num_frames
+        subseq_labels_list, subseq_meta, fg_embeddings = [], [], []
+        track = TrackContainer(num_frames)
+        next_track_label = 1
+        prev_frames = None
+
+        for i, subseq in enumerate(subsequences):
+            if isinstance(subseq['frames'], dict):
+                subseq['frames'] = sorted(subseq['frames'].keys())
+            frames = list(subseq['frames'])
+            for k in ("embeddings", "bandwidths", "seediness"):
+                subseq[k] = ops.to_device(subseq[k])
+            self.resize_tensors(subseq)
+            assert subseq['embeddings'].shape[-2:] == masks.shape[-2:], \
+                "Size mismatch between embeddings {} and masks {}".format(subseq['embeddings'].shape, masks.shape)
+
+            labels_per_frame, pts, meta_info = self.cluster_subsequence(
+                masks[torch.as_tensor(frames, device=masks.device)], subseq['embeddings'], subseq['bandwidths'],
+                subseq['seediness'], next_track_label, return_fg_embeddings)
+            offs = pts["offs_host"]
+            for j, t in enumerate(frames):
+                if mask_idxes[t] is None:
+                    local = pts["vox"][offs[j]:offs[j + 1]].long() - j * H * W
+                    mask_idxes[t] = (torch.div(local, W, rounding_mode="floor"), local % W)
+            subseq_labels_list.append(labels_per_frame)
+            if return_fg_embeddings:
+                fg_embeddings.append(pts["emb"][:offs[-1]].cpu())
+
+            if i == 0:
+                next_track_label = track.add_labels(frames, labels_per_frame, max_label=ops.max_label(labels_per_frame))
+                subseq_meta.append(meta_info)
+                prev_frames = frames
+                subseq["embeddings"] = subseq["bandwidths"] = subseq["seediness"] = None
+                continue
+
+            overlap = sorted(set(frames).intersection(prev_frames))        # previous clip only (:201-202)
+            existing = track.get_labels(overlap)
+            current = [labels_per_frame[j] for j, t in enumerate(frames) if t in overlap]
+            associations = self.associate_clusters(existing, current)[0]
+            mapping = {cur: assoc for assoc, cur in associations}
+            new_frames, new_labels = [], []
+            for j, t in enumerate(frames):
+                if t in overlap:
+                    continue
+                if mapping:
+                    ops.relabel(labels_per_frame[j], mapping)
+                new_frames.append(t)
+                new_labels.append(labels_per_frame[j])
+            if new_frames:
+                next_track_label = track.add_labels(new_frames, new_labels, max_label=ops.max_label(new_labels))
+            for assoc, cur in associations:
+                meta_info['instance_labels'][meta_info['instance_labels'].index(cur)] = assoc
+            subseq_meta.append(meta_info)
+            prev_frames = frames
+            subseq["embeddings"] = subseq["bandwidths"] = subseq["seediness"] = None
+
+        mask_idxes = [(ys.cpu(), xs.cpu()) for ys, xs in mask_idxes]
+        subseq_labels_list = [[l.cpu() for l in ls] for ls in subseq_labels_list]
+        return track.get_track_mask_idxes(), mask_idxes, subseq_labels_list, fg_embeddings, subseq_meta
+
+    def cluster_subsequence(self, fg_clip, embeddings, bandwidths, seediness, label_start, return_fg_embeddings):
+        """fg_clip [T',H,W] uint8, embeddings [E,T',H,W], bandwidths [Ev,T',H,W], seediness [1,T',H,W]
+        -> (labels split per frame, gathered points dict, clustering meta dict)."""
+        assert fg_clip.shape[0] == embeddings.shape[1]
+        ops = self.ops
+        pts = ops.gather(embeddings, bandwidths, seediness, fg_clip)
+        labels, meta_dev, masks = ops.cluster(self.clusterer, pts, label_start, return_fg_embeddings)
+        offs, meta = ops.read(pts, meta_dev)
+        pts["offs_host"] = offs
+        n = offs[-1]
+        info = self.clusterer.meta_to_dict(meta, embeddings.shape[0], label_start, masks, None, n)
+        assert labels.numel() >= n
+        per_frame = [labels[offs[j]:offs[j + 1]] for j in range(len(offs) - 1)]
+        return per_frame, pts, info
+
+    def associate_clusters(self, labels_1, labels_2):
+        """Hungarian matching on 1 - IoU over the overlap frames (online_chainer.py:291-343).  Every returned pair is
+        accepted -- there is no IoU threshold.  Returns the reference's 5-tuple."""
+        la = labels_1 if torch.is_tensor(labels_1) else torch.cat(list(labels_1))
+        lb = labels_2 if torch.is_tensor(labels_2) else torch.cat(list(labels_2))
+        assert la.shape == lb.shape, "Shape mismatch: {}, {}".format(la.shape, lb.shape)
+        if la.numel() == 0:
+            return [], set(), set(), np.zeros(0, np.float32), (np.zeros((0, 0), np.float32), [], [])
+        hi = self.ops.max_label([la, lb]) or 0
+        cand = list(range(1, hi + 1))
+        # the outlier id is never associated; ids <= 0 other than -1 do not occur (labels start at 1)
+        inter, ca, cb = self.ops.overlap_counts(la, lb, cand, cand)
+        ids_1 = [c for k, c in enumerate(cand) if ca[k] > 0]
+        ids_2 = [c for k, c in enumerate(cand) if cb[k] > 0]
+        assert not set(ids_1).intersection(ids_2), "Labels overlap: {}, {}".format(ids_1, ids_2)
+        r = [cand.index(c) for c in ids_1]
+        c_ = [cand.index(c) for c in ids_2]
+        I = inter[np.ix_(r, c_)].astype(np.float32)
+        A = ca[r].astype(np.float32)[:, None]
+        B = cb[c_].astype(np.float32)[None, :]
+        U = (A + B - I).astype(np.float32)
+        iou = (I / U).astype(np.float32) if I.size else np.zeros_like(I)
+        costs = (1. - iou.astype(np.float64)).astype(np.float32)             # `1. - iou.item()` stored as float32 (:327)
+        recall = (I / A).astype(np.float32) if I.size else np.zeros_like(I)
+        idx1, idx2 = linear_sum_assignment(costs)
+        associations, un1, un2 = [], set(ids_1), set(ids_2)
+        for i1, i2 in zip(idx1, idx2):
+            associations.append((ids_1[i1], ids_2[i2]))
+            un1.remove(ids_1[i1])
+            un2.remove(ids_2[i2])
+        return associations, un1, un2, costs[idx1, idx2], (recall, ids_1, ids_2)

@@ -1,0 +1,154 @@
+"""Shared machinery of the two squeeze-expand decoders: reference-compatible parameter containers
+(state-dict keys of SURVEY.md section 5) + the call into ``stemseg_hip_decoder_forward``.
+
+The ``nn.Conv3d`` / ``nn.GroupNorm`` objects created here are *parameter holders only* -- they give
+checkpoints the reference's key names (``block_32x.0.weight`` ... ``conv_4.weight``); ``forward`` never
+calls them.  All arithmetic happens in libstemseg_hip.so.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..config import cfg
+from .common import POOL_TABLE, TSCALE_TABLE
+
+_BLOCK_CONVS = (("block_32x", 0), ("block_32x", 4), ("block_32x", 8), ("block_16x", 0), ("block_16x", 4),
+                ("block_8x", 0), ("block_4x", 0))
+
+
+def _stage(cin, cout, NormType, pool_creator):
+    # Conv3d(3, p=1) -> Norm -> ReLU -> Pool|Identity   (indices 0,1,2,3 within the block)
+    return [nn.Conv3d(cin, cout, 3, stride=1, padding=1), NormType(cout), nn.ReLU(inplace=True),
+            pool_creator(3, stride=(2, 1, 1), padding=1) if pool_creator else None]
+
+
+class SqueezeExpandTrunk(nn.Module):
+    """Parameter layout + HIP execution shared by embedding_decoder / seediness_decoder."""
+
+    def __init__(self, in_channels, inter_channels, PoolType=nn.AvgPool3d, NormType=nn.Identity, num_frames=None):
+        super().__init__()
+        assert len(inter_channels) == 4
+        self.num_frames = cfg.INPUT.NUM_FRAMES if num_frames is None else num_frames
+        if self.num_frames not in POOL_TABLE:
+            raise NotImplementedError("clip length %r" % (self.num_frames,))
+        if PoolType is not nn.AvgPool3d:
+            raise NotImplementedError("HIP decoder implements POOL_TYPE 'avg' (AvgPool3d) only")
+        self.pool_flags, self.t_scales = POOL_TABLE[self.num_frames], TSCALE_TABLE[self.num_frames]
+        probe = NormType(inter_channels[0])
+        if not isinstance(probe, nn.GroupNorm):
+            raise NotImplementedError("HIP decoder implements NORMALIZATION_LAYER 'gn' (GroupNorm) only")
+        self.gn_groups, self.gn_eps = probe.num_groups, probe.eps
+        self.in_channels, self.inter_channels = in_channels, list(inter_channels)
+
+        def pools(n):
+            return [(PoolType if on else (lambda *a, **k: nn.Identity())) for on in self.pool_flags[:n]]
+        c32, c16, c8, c4 = inter_channels
+
+        def block(cins, cout, poolers):
+            mods = []
+            for ci, pc in zip(cins, poolers):
+                mods += [m for m in _stage(ci, cout, NormType, pc) if m is not None]
+            return nn.Sequential(*mods)
+        self.block_32x = block([in_channels, c32, c32], c32, pools(3))
+        self.block_16x = block([in_channels, c16], c16, pools(2))
+        self.block_8x = block([in_channels], c8, pools(1))
+        self.block_4x = nn.Sequential(*[m for m in _stage(in_channels, c4, NormType, None) if m is not None])
+        self.conv_16 = nn.Conv3d(c32 + c16, c16, 1, bias=False)
+        self.conv_8 = nn.Conv3d(c16 + c8, c8, 1, bias=False)
+        self.conv_4 = nn.Conv3d(c8 + c4, c4, 1, bias=False)
+        self._cache = {}          # packed weights keyed by parameter versions
+        self._workspaces = {}     # (T, H4, W4, layout) -> (tensor, desc)
+        self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
+
+    # ---- to be provided by the concrete decoder ---------------------------------------------------
+    def _head_spec(self):
+        """-> (weight [n_out, c4] tensor, bias [n_out] tensor, act codes, grid_axis codes)"""
+        raise NotImplementedError
+
+    # ---- weights --------------------------------------------------------------------------------------
+    def _param_signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _packed(self):
+        sig = self._param_signature()
+        c = self._cache
+        if c.get("sig") != sig:
+            dev = next(self.parameters()).device
+            conv_w, conv_b, gn_w, gn_b = [], [], [], []
+            for blk, idx in _BLOCK_CONVS:
+                conv, gn = getattr(self, blk)[idx], getattr(self, blk)[idx + 1]
+                conv_w.append(hip.pack_conv_weight(conv.weight.detach().float()))
+                conv_b.append(conv.bias.detach().float().contiguous())
+                gn_w.append(gn.weight.detach().float().contiguous())
+                gn_b.append(gn.bias.detach().float().contiguous())
+            fuse = [hip.pack_conv_weight(m.weight.detach().float()) for m in (self.conv_16, self.conv_8, self.conv_4)]
+            hw, hb, act, axes = self._head_spec()
+            c.clear()
+            c.update(sig=sig, conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, fuse=fuse,
+                     head_w=hw.detach().float().contiguous().to(dev), head_b=hb.detach().float().contiguous().to(dev),
+                     act=list(act), axes=list(axes), grids={})
+        return c
+
+    def _desc(self, T, H4, W4, layout, act):
+        d = hip.DecoderDesc()
+        d.struct_bytes = C.sizeof(hip.DecoderDesc)
+        d.in_channels = self.in_channels
+        for i in range(4):
+            d.inter[i] = self.inter_channels[i]
+        d.T, d.H4, d.W4 = T, H4, W4
+        d.gn_groups, d.gn_eps = self.gn_groups, self.gn_eps
+        for i in range(3):
+            d.pool[i], d.t_scale[i] = self.pool_flags[i], self.t_scales[i]
+        d.n_out = len(act)
+        return d
+
+    def _grid(self, c, T, H4, W4, dev):
+        return None, None, None
+
+    @torch.no_grad()
+    def run_hip(self, feats, input_layout=None, act_override=None):
+        """feats: 4 device tensors (32x,16x,8x,4x) for ONE sample: dense [C,T,h,w] (layout 0), dense [T,C,h,w]
+        (layout 1) or zero-haloed flat buffers (layout 2, then T/H4/W4 must be given via ``feats_shape``).
+        Returns [n_out, T, H4, W4]."""
+        hip.require_gpu()
+        layout = self.input_layout if input_layout is None else input_layout
+        if layout == 2:
+            bufs, (T, H4, W4) = feats
+        else:
+            bufs = [f.contiguous().float() for f in feats]
+            f4 = bufs[3]
+            T, H4, W4 = (f4.shape[1], f4.shape[2], f4.shape[3]) if layout == 0 else (f4.shape[0], f4.shape[2], f4.shape[3])
+        if T != self.num_frames:
+            raise ValueError("decoder built for %d-frame clips, got %d" % (self.num_frames, T))
+        dev = bufs[0].device
+        c = self._packed()
+        act = list(c["act"]) if act_override is None else list(act_override)
+        d = self._desc(T, H4, W4, layout, act)
+        for o in range(d.n_out):
+            d.act[o], d.grid_axis[o] = act[o], c["axes"][o]
+        d.input_layout = layout
+        key = (T, H4, W4, layout, dev.index)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            nbytes = hip.lib().stemseg_hip_decoder_workspace_bytes(C.byref(d))
+            if nbytes == 0:
+                raise RuntimeError("decoder: " + hip.lib().stemseg_hip_last_error().decode())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            hip.check(hip.lib().stemseg_hip_decoder_init_workspace(C.byref(d), hip.ptr(ws), nbytes, hip.stream()))
+            self._workspaces[key] = ws
+        w = hip.DecoderWeights()
+        for i in range(7):
+            w.conv_w[i], w.conv_b[i] = c["conv_w"][i].data_ptr(), c["conv_b"][i].data_ptr()
+            w.gn_w[i], w.gn_b[i] = c["gn_w"][i].data_ptr(), c["gn_b"][i].data_ptr()
+        for i in range(3):
+            w.fuse_w[i] = c["fuse"][i].data_ptr()
+        w.head_w, w.head_b = c["head_w"].data_ptr(), c["head_b"].data_ptr()
+        gt, gy, gx = self._grid(c, T, H4, W4, dev)
+        if gt is not None:
+            w.grid_t, w.grid_y, w.grid_x = gt.data_ptr(), gy.data_ptr(), gx.data_ptr()
+        out = torch.empty(d.n_out, T, H4, W4, dtype=torch.float32, device=dev)
+        fp = (C.c_void_p * 4)(*[b.data_ptr() for b in bufs])
+        hip.check(hip.lib().stemseg_hip_decoder_forward(C.byref(d), C.byref(w), fp, hip.ptr(out), hip.ptr(ws), ws.numel(), hip.stream()))
+        return out

@@ -1,0 +1,174 @@
+"""Sequence driver: frames -> (per-frame encoder, cached) -> per-clip head outputs, all resident on the GPU.
+
+Counterpart of ``stemseg.modeling.inference_model.InferenceModel`` (:17-41 ctor, :63-194 forward) and of the
+pre-processing helpers it relies on (data/inference_image_loader.py:23-43, data/common.py:12-30,142-159,
+structures/image_list.py:58-107).  Same ``forward(images, subseq_idxes)`` contract and the same
+``{"fg_masks", "multiclass_masks", "embeddings": [EmbeddingMapEntry(subseq_frames, embeddings, bandwidths, seediness)]}``
+result, with three deliberate differences:
+  * the clip's un-cached frames go through the encoder as one batch (reference: batch 1 per frame);
+  * FPN features are written once into the zero-haloed layout both decoders consume (no torch.stack copy,
+    no second pad for the seediness decoder);
+  * outputs stay on the device unless ``outputs_on_cpu=True`` (reference: ``.cpu()`` per clip, then ``.cuda()``
+    again in the chainer).
+"""
+import math
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from ..config import cfg
+from .backbone import BACKBONE_REGISTRY
+from .embedding_decoder import EMBEDDING_HEAD_REGISTRY
+from .embedding_utils import get_nb_free_dims  # noqa: F401  (re-export, as in the reference's import surface)
+from .seediness_decoder import SEEDINESS_HEAD_REGISTRY
+
+EmbeddingMapEntry = namedtuple("EmbeddingMapEntry", ["subseq_frames", "embeddings", "bandwidths", "seediness"])
+
+
+def compute_resize_params_2(image_dims, min_resize_dim, max_resize_dim):
+    """(width, height) -> (new_width, new_height, scale): min side -> MIN_DIM unless the max side would exceed
+    MAX_DIM; Python ``round`` (data/common.py:142-159)."""
+    lower, higher = float(min(image_dims)), float(max(image_dims))
+    scale = min_resize_dim / lower
+    if higher * scale > max_resize_dim:
+        scale = max_resize_dim / higher
+    width, height = image_dims
+    return round(scale * width), round(scale * height), scale
+
+
+def pad_to_multiple_of_32(h, w):
+    return int(math.ceil(h / 32)) * 32, int(math.ceil(w / 32)) * 32          # image_list.py:93-95
+
+
+@torch.no_grad()
+def preprocess_frames(frames, device="cuda"):
+    """uint8 BGR frames [T,H0,W0,3] (numpy or tensor) -> float32 [T,3,H,W]: bilinear resize to cfg MIN/MAX_DIM,
+    mean-subtract (no /255, std 1), zero-pad right/bottom to multiples of 32."""
+    x = torch.as_tensor(np.asarray(frames)) if not torch.is_tensor(frames) else frames
+    x = x.to(device).permute(0, 3, 1, 2).float()
+    H0, W0 = x.shape[-2:]
+    nw, nh, _ = compute_resize_params_2((W0, H0), cfg.INPUT.MIN_DIM, cfg.INPUT.MAX_DIM)
+    x = F.interpolate(x, (nh, nw), mode="bilinear", align_corners=False)
+    mean = torch.tensor(cfg.INPUT.IMAGE_MEAN, dtype=torch.float32, device=x.device)[None, :, None, None]
+    std = torch.tensor(cfg.INPUT.IMAGE_STD, dtype=torch.float32, device=x.device)[None, :, None, None]
+    if cfg.INPUT.NORMALIZE_TO_UNIT_SCALE:
+        x = x / 255.
+    x = (x - mean) / std
+    if not cfg.INPUT.BGR_INPUT:
+        x = x.flip(dims=[1])
+    H, W = pad_to_multiple_of_32(nh, nw)
+    return F.pad(x, (0, W - nw, 0, H - nh)), (nh, nw)
+
+
+def build_model():
+    """backbone + heads from the global cfg (model_builder.py:247-369 minus losses / semseg head)."""
+    m = nn.Module()
+    m.backbone = BACKBONE_REGISTRY[cfg.MODEL.BACKBONE.TYPE](cfg)
+    e = cfg.MODEL.EMBEDDINGS
+    norm = lambda c: nn.GroupNorm(e.GN_NUM_GROUPS, c)  # noqa: E731
+    assert e.NORMALIZATION_LAYER == "gn" and e.POOL_TYPE == "avg"
+    m.embedding_head = EMBEDDING_HEAD_REGISTRY[e.HEAD_TYPE](
+        m.backbone.out_channels, e.INTER_CHANNELS, e.EMBEDDING_SIZE, tanh_activation=e.TANH_ACTIVATION,
+        seediness_output=not cfg.MODEL.USE_SEEDINESS_HEAD, experimental_dims=cfg.MODEL.EMBEDDING_DIM_MODE,
+        PoolType=nn.AvgPool3d, NormType=norm)
+    m.seediness_head = None
+    if cfg.MODEL.USE_SEEDINESS_HEAD:
+        s = cfg.MODEL.SEEDINESS
+        m.seediness_head = SEEDINESS_HEAD_REGISTRY[s.HEAD_TYPE](
+            m.backbone.out_channels, s.INTER_CHANNELS, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(s.GN_NUM_GROUPS, c))
+    m.semseg_head = None
+    m.embedding_head_feature_map_scale = list(e.SCALE)
+    return m
+
+
+class InferenceModel(nn.Module):
+    def __init__(self, restore_path=None, cpu_workers=0, preload_images=False, semseg_output_type=None, resize_scale=1.0,
+                 semseg_generation_on_gpu=True, outputs_on_cpu=False):
+        super().__init__()
+        with torch.no_grad():
+            self._model = build_model()
+        if restore_path:
+            sd = torch.load(restore_path, map_location="cpu")['model']
+            self._model.load_state_dict(sd, strict=False)
+        self.resize_scale = resize_scale
+        self.outputs_on_cpu = outputs_on_cpu
+        self.EmbeddingMapEntry = EmbeddingMapEntry
+        self._pads = {}
+        self.eval()
+
+    has_semseg_head = property(lambda self: False)
+
+    # ---- one clip ----------------------------------------------------------------------------------
+    def _padded_feature_buffers(self, T, H, W, dev):
+        """Four zero-haloed buffers [256][T+2][h+2][pitch], allocated once per shape (halos stay zero)."""
+        key = (T, H, W, dev.index)
+        if key not in self._pads:
+            Cn = self._model.backbone.out_channels
+            self._pads[key] = [hip.alloc_padded(Cn, T, H // s, W // s, dev) for s in (32, 16, 8, 4)]
+        return self._pads[key]
+
+    @torch.no_grad()
+    def embed_clip(self, feature_maps, T, H, W):
+        """feature_maps: list over the clip's T slots of dicts {4,8,16,32: [256,h,w]} (device).  Returns the
+        clip's (embeddings [E,T,h4,w4], bandwidths [Ev,...] already exp()*10, seediness [1,...])."""
+        hip.require_gpu()
+        m = self._model
+        dev = feature_maps[0][4].device
+        pads = self._padded_feature_buffers(T, H, W, dev)
+        Cn = m.backbone.out_channels
+        for (buf, g), s in zip(pads, (32, 16, 8, 4)):
+            stack = torch.stack([fm[s] for fm in feature_maps], 0)                      # [T,C,h,w]  (layout 1)
+            hip.copy_to_volume(stack.contiguous(), 1, hip.padded_interior_view(buf, g, Cn, T, H // s, W // s))
+        feats = ([b for b, _ in pads], (T, H // 4, W // 4))
+        eh = m.embedding_head
+        eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
+        out = eh.forward_single(feats, 2)
+        E, Ev = eh.embedding_size, eh.variance_channels
+        emb, bw, seed = out[:E], out[E:E + Ev], out[E + Ev:]
+        if seed.shape[0] == 0:
+            assert m.seediness_head is not None
+            seed = m.seediness_head.forward_single(feats, 2)
+            if self.resize_scale != 1.0:                                                # inference_model.py:156 quirk
+                seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+        return emb, bw, seed
+
+    @torch.no_grad()
+    def forward(self, images, subseq_idxes):
+        """images: list/array of uint8 BGR frames [H0,W0,3] (or a pre-processed float tensor [N,3,H,W] on the device);
+        subseq_idxes: list of frame-index lists (duplicates allowed, inference/main.py:37-39)."""
+        hip.require_gpu()
+        m = self._model
+        if torch.is_tensor(images) and images.dtype == torch.float32 and images.dim() == 4:
+            frames = images.cuda()
+        else:
+            frames, _ = preprocess_frames(np.stack([np.asarray(im) for im in images], 0))
+        H, W = frames.shape[-2:]
+        cache, deps = {}, {}
+        for i, sub in enumerate(subseq_idxes):
+            for t in sub:
+                deps.setdefault(t, set()).add(i)
+        maps = []
+        for i, sub in enumerate(subseq_idxes):
+            need = sorted(set(t for t in sub if t not in cache))
+            if need:
+                feats = m.backbone.run_backbone(frames[need])                           # one batch for all new frames
+                for j, t in enumerate(need):
+                    cache[t] = {s: feats[s][j] for s in (4, 8, 16, 32)}
+            emb, bw, seed = self.embed_clip([cache[t] for t in sub], len(sub), H, W)
+            uniq = sorted(set(sub))
+            if len(uniq) != len(sub):                                                   # dict semantics of :137-138: last slot wins
+                sel = torch.as_tensor([max(j for j, v in enumerate(sub) if v == t) for t in uniq], device=emb.device)
+                emb, bw, seed = emb[:, sel], bw[:, sel], seed[:, sel]
+            if self.outputs_on_cpu:
+                emb, bw, seed = emb.cpu(), bw.cpu(), seed.cpu()
+            maps.append(EmbeddingMapEntry(uniq, emb, bw, seed))
+            for t in list(deps):                                                        # evict (:164-173)
+                deps[t].discard(i)
+                if not deps[t]:
+                    cache.pop(t, None)
+                    del deps[t]
+        return {"fg_masks": [], "multiclass_masks": [], "embeddings": maps}

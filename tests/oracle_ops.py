@@ -1,0 +1,66 @@
+"""CPU twin of stemseg_amd.inference.online_chainer.HipChainerOps built on the oracle (tests only).
+
+Lets the chainer's HOST logic (windowing, label bookkeeping, Hungarian stitching, track container) be checked
+against the reference-generated goldens on a machine without a GPU, and gives the gloo multi-process tests a
+device-free data path.  The product never imports this file.
+"""
+import numpy as np
+import torch
+
+from oracle import pipeline as opipe
+from oracle.clusterer import sequential_clustering
+
+
+class _Meta(object):
+    pass
+
+
+class OracleChainerOps(object):
+    device = "cpu"
+
+    def to_device(self, t):
+        return t
+
+    def resize(self, x, scale):
+        return torch.nn.functional.interpolate(x[None], scale_factor=(1.0, scale, scale), mode="trilinear", align_corners=False)[0]
+
+    def gather(self, emb, bw, seed, fg):
+        e, b, s, counts = opipe.gather_fg(emb.numpy(), bw.numpy(), seed.numpy(), fg.numpy())
+        T, H, W = fg.shape
+        vox = torch.from_numpy(np.flatnonzero(fg.numpy().reshape(-1)).astype(np.int32))
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return dict(emb=torch.from_numpy(e), bw=torch.from_numpy(b), seed=torch.from_numpy(s[:, 0]), vox=vox,
+                    offs=torch.from_numpy(offs), T=T)
+
+    def cluster(self, clusterer, pts, label_start, want_masks):
+        labels, meta = sequential_clustering(pts["emb"].numpy(), pts["bw"].numpy(), pts["seed"].numpy(), label_start=label_start,
+                                             primary=clusterer.primary_prob_thresh, secondary=clusterer.secondary_prob_thresh,
+                                             min_seediness=clusterer.min_seediness_prob,
+                                             free_dim_stds=clusterer.free_dim_stds[:clusterer.n_free_dims],
+                                             max_instances=clusterer.max_instances, return_masks=want_masks)
+        m = _Meta()
+        m.K = len(meta["instance_labels"])
+        E = pts["emb"].shape[1]
+        m.centers = [c + [0.0] * (8 - E) for c in meta["instance_centers"]]
+        # meta_to_dict recomputes std from the bandwidth; invert exactly what it will do
+        m.bandwidths = [[1.0 / (s * s) if s > 0 else 0.0 for s in stds] + [1.0] * (8 - E) for stds in meta["instance_stds"]]
+        masks = torch.from_numpy(np.stack(meta["instance_masks"]).astype(np.uint8)) if (want_masks and meta["instance_masks"]) else None
+        return torch.from_numpy(labels), m, masks
+
+    def read(self, pts, meta):
+        return pts["offs"].tolist(), meta
+
+    def overlap_counts(self, la, lb, ids_a, ids_b):
+        la, lb = la.numpy(), lb.numpy()
+        inter = np.array([[np.sum((la == a) & (lb == b)) for b in ids_b] for a in ids_a], np.int64).reshape(len(ids_a), len(ids_b))
+        return inter, np.array([np.sum(la == a) for a in ids_a], np.int64), np.array([np.sum(lb == b) for b in ids_b], np.int64)
+
+    def relabel(self, labels, mapping):
+        src = labels.clone()
+        for old, new in mapping.items():
+            labels[src == old] = new
+        return labels
+
+    def max_label(self, labels_list):
+        nz = [l for l in labels_list if l.numel() > 0]
+        return int(torch.cat(nz).max().item()) if nz else None

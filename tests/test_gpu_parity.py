@@ -1,0 +1,421 @@
+"""GPU parity tests: every HIP kernel / entry point of libstemseg_hip.so, called through the C-ABI (ctypes), vs
+the CPU oracle on the same seeded inputs, the reference-generated golden fixtures, and size-independent properties
+at BASELINE sizes.  Tolerances: float stages <= 1e-3 absolute (BASELINE.json north_star), most far tighter;
+integer outputs exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import decoder as odec
+from oracle import encoder as oenc
+from oracle import pipeline as opipe
+from oracle.clusterer import sequential_clustering
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from stemseg_amd import hip as h
+    h.require_gpu()
+    return h
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def report(name, got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    i = int(np.argmax(err)) if err.size else 0
+    print("[parity] %-38s max|err| %.3e at %s (got %.6g ref %.6g)  max|ref| %.3g" %
+          (name, err.max() if err.size else 0, np.unravel_index(i, err.shape) if err.size else (), got.flat[i] if err.size else 0,
+           ref.flat[i] if err.size else 0, np.abs(ref).max() if ref.size else 0))
+    return float(err.max()) if err.size else 0.0
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def _rand(shape, seed, scale=1.0):
+    return (np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def test_pack_conv_weight(hip):
+    w = _rand((64, 12, 3, 3, 3), 0)
+    got = hip.pack_conv_weight(dev(w)).cpu().numpy()
+    ref = w.reshape(64, 3, 4, 27).transpose(1, 3, 2, 0).reshape(-1)          # [Cin/4][taps][4][Cout]
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(8, 64, 3, 5, 37), (256, 128, 2, 9, 40), (12, 32, 1, 2, 3), (16, 160, 4, 17, 70)])
+def test_conv3d_k3(hip, cfg, shape):
+    Cin, Cout, T, H, W = shape
+    x = _rand((Cin, T, H, W), 1)
+    w = _rand((Cout, Cin, 3, 3, 3), 2, 1.0 / np.sqrt(Cin * 27))
+    b = _rand((Cout,), 3)
+    ref = F.conv3d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), padding=1)[0].numpy()
+    buf, g = hip.alloc_padded(Cin, T, H, W)
+    hip.copy_to_volume(dev(x), 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
+    assert np.array_equal(hip.padded_to_dense(buf, g, Cin, T, H, W).cpu().numpy(), x)
+    out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+    hip.conv3d(hip.padded_halo_view(buf, g, Cin, T, H, W), hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(out), 3, cfg)
+    torch.cuda.synchronize()
+    assert report("conv3d_k3 cfg%d %s" % (cfg, shape), out.cpu().numpy(), ref) <= 2e-4
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(64, 128, 1000), (384, 128, 4 * 60 * 108), (512, 256, 1001), (8, 32, 5)])
+def test_conv3d_k1(hip, cfg, shape):
+    Cin, Cout, V = shape
+    x = _rand((Cin, V), 4)
+    w = _rand((Cout, Cin, 1, 1, 1), 5, 1.0 / np.sqrt(Cin))
+    ref = torch.from_numpy(w.reshape(Cout, Cin)) @ torch.from_numpy(x)
+    xd = dev(x)
+    out = torch.full((Cout, V), float("nan"), device="cuda")
+    hip.conv3d(hip.flat_volume(xd), hip.pack_conv_weight(dev(w)), None, hip.flat_volume(out), 1, cfg)
+    torch.cuda.synchronize()
+    assert report("conv3d_k1 cfg%d %s" % (cfg, shape), out.cpu().numpy(), ref.numpy()) <= 2e-4
+
+
+# ------------------------------------------------------------------------------------------------ GN / pool / upsample / heads
+@pytest.mark.parametrize("shape", [(256, 8, 4, 7), (128, 8, 30, 54), (64, 3, 5, 5)])
+def test_groupnorm_stats(hip, shape):
+    x = _rand(shape, 6) * 3 + 1.5
+    stats = hip.groupnorm_stats(dev(x), 32).cpu().numpy().reshape(32, 2)
+    xg = x.reshape(32, -1).astype(np.float64)
+    assert report("gn mean", stats[:, 0], xg.mean(1)) <= 1e-5
+    assert report("gn rstd", stats[:, 1], 1 / np.sqrt(xg.var(1) + 1e-5)) <= 1e-5
+
+
+@pytest.mark.parametrize("pool", [0, 1])
+@pytest.mark.parametrize("shape", [(64, 8, 6, 9), (128, 4, 15, 27), (32, 5, 3, 33), (32, 2, 4, 4)])
+def test_gn_relu_pool(hip, pool, shape):
+    C, T, H, W = shape
+    x = _rand(shape, 7) * 2 + 0.3
+    gam, bet = _rand((C,), 8) * 0.2 + 1, _rand((C,), 9) * 0.1
+    ref = F.relu(F.group_norm(torch.from_numpy(x)[None], 32, torch.from_numpy(gam), torch.from_numpy(bet), 1e-5))
+    if pool:
+        ref = F.avg_pool3d(ref, 3, stride=(2, 1, 1), padding=1)
+    ref = ref[0].numpy()
+    xd = dev(x)
+    stats = hip.groupnorm_stats(xd, 32)
+    To = ref.shape[1]
+    # (a) dense destination that is a channel slice of a larger concat buffer
+    cat = torch.zeros(C + 32, To, H, W, device="cuda")
+    v = hip.dense_volume(cat[32:])
+    hip.gn_relu_pool(xd, 32, stats, dev(gam), dev(bet), pool, v)
+    assert report("gn_relu_pool(%d) dense %s" % (pool, shape), cat[32:].cpu().numpy(), ref) <= 1e-5
+    assert float(cat[:32].abs().max()) == 0.0
+    # (b) zero-haloed destination: interior matches, halo untouched
+    buf, g = hip.alloc_padded(C, To, H, W)
+    hip.gn_relu_pool(xd, 32, stats, dev(gam), dev(bet), pool, hip.padded_interior_view(buf, g, C, To, H, W))
+    assert report("gn_relu_pool(%d) haloed %s" % (pool, shape), hip.padded_to_dense(buf, g, C, To, H, W).cpu().numpy(), ref) <= 1e-5
+    full = buf[:C * g["cs"]].view(C, To + 2, H + 2, g["pitch"]).clone()
+    full[:, 1:To + 1, 1:H + 1, 1:W + 1] = 0
+    assert float(full.abs().max()) == 0.0 and float(buf[C * g["cs"]:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("scale", [(1, 2, 2), (2, 2, 2), (1, 4, 4)])
+@pytest.mark.parametrize("shape", [(16, 2, 3, 5), (7, 4, 15, 27), (3, 1, 1, 1)])
+def test_upsample_trilinear(hip, scale, shape):
+    x = _rand(shape, 10)
+    ref = F.interpolate(torch.from_numpy(x)[None], scale_factor=tuple(float(s) for s in scale), mode="trilinear", align_corners=False)[0].numpy()
+    got = hip.upsample_trilinear(dev(x), *scale).cpu().numpy()
+    assert report("upsample %s %s" % (scale, shape), got, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_copy_to_volume(hip, layout):
+    C, T, H, W = 6, 3, 4, 5
+    x = _rand((C, T, H, W), 11)
+    src = x if layout == 0 else np.ascontiguousarray(x.transpose(1, 0, 2, 3))
+    buf, g = hip.alloc_padded(C, T, H, W)
+    hip.copy_to_volume(dev(src), layout, hip.padded_interior_view(buf, g, C, T, H, W))
+    assert np.array_equal(hip.padded_to_dense(buf, g, C, T, H, W).cpu().numpy(), x)
+
+
+def test_heads_all_activations(hip):
+    Cin, T, H, W = 128, 2, 6, 8
+    x = _rand((Cin, T, H, W), 12)
+    w = _rand((7, Cin), 13, 0.2)
+    b = _rand((7,), 14, 0.1)
+    gt, gy, gx = odec.grid_vectors(H, W, T, 1.0)
+    act, axis = [1, 1, 4, 0, 3, 2, 1], [1, 2, 3, 0, 0, 0, 0]
+    z = (torch.from_numpy(w) @ torch.from_numpy(x).reshape(Cin, -1) + torch.from_numpy(b)[:, None]).reshape(7, T, H, W)
+    G = {1: gt[:, None, None].expand(T, H, W), 2: gy[None, :, None].expand(T, H, W), 3: gx[None, None, :].expand(T, H, W)}
+    ref = torch.stack([(z[0] * 0.25).tanh() + G[1], (z[1] * 0.25).tanh() + G[2], z[2] + G[3], z[3], z[4].exp() * 10,
+                       z[5].sigmoid(), (z[6] * 0.25).tanh()]).numpy()
+    got = hip.heads(dev(x), dev(w), dev(b), act, axis, gt.cuda(), gy.cuda(), gx.cuda()).cpu().numpy()
+    assert report("heads", got / np.maximum(1, np.abs(ref)), ref / np.maximum(1, np.abs(ref))) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ whole decoders
+def _gn(c):
+    return torch.nn.GroupNorm(32, c)
+
+
+def _emb_head(mode, E, tanh, seed_out, T, wseed):
+    from stemseg_amd.modeling.embedding_decoder import SqueezingExpandDecoder as Emb
+    m = Emb(256, [256, 256, 128, 128], E, tanh, seed_out, mode, NormType=_gn, num_frames=T)
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in m.state_dict().items()], wseed, prefix="embedding_head.")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(m.state_dict()[k].shape) for k, v in sd.items()})
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("T", [8, 16, 4])
+def test_embedding_decoder_vs_golden_and_oracle(hip, golden, T):
+    g = golden("decoder_T%d" % T)
+    for name in [k for k in g.files if k.startswith("emb_") and "__" not in k]:
+        E, h32, w32, ws, tanh, so = g[name + "__meta"].tolist()
+        mode = str(g[name + "__mode"])
+        head = _emb_head(mode, E, bool(tanh), bool(so), T, ws)
+        feats = synth.synth_features(T, h32, w32, seed=ws)
+        out = head([dev(f)[None] for f in feats])[0].cpu().numpy()
+        assert out.shape == g[name].shape
+        assert report("emb decoder T%d %s" % (T, name), out, g[name]) <= 1e-3
+        # bandwidth activation fused in the heads kernel == exp(var) * 10 of inference_model.py:148
+        head.fuse_bandwidth_activation = True
+        out2 = head([dev(f)[None] for f in feats])[0].cpu().numpy()
+        nE = odec.nb_embedding_dims(mode)
+        nV = E - odec.nb_free_dims(mode)
+        ref_bw = np.exp(g[name][nE:nE + nV]) * 10
+        assert report("  fused bandwidth", out2[nE:nE + nV] / ref_bw, np.ones_like(ref_bw)) <= 1e-3
+        assert np.array_equal(out2[:nE], out[:nE])
+
+
+@pytest.mark.parametrize("T", [8, 16, 4])
+def test_seediness_decoder_vs_golden(hip, golden, T):
+    from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
+    g = golden("decoder_T%d" % T)
+    _, h32, w32, ws, _, _ = g["seediness__meta"].tolist()
+    m = Seed(256, [256, 256, 128, 128], NormType=_gn, num_frames=T)
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in m.state_dict().items()], ws, prefix="seediness_head.")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(m.state_dict()[k].shape) for k, v in sd.items()})
+    m = m.cuda().eval()
+    feats = synth.synth_features(T, h32, w32, seed=ws)
+    a = m([dev(f)[None] for f in feats])[0].cpu().numpy()
+    b = m([dev(f)[None] for f in feats])[0].cpu().numpy()
+    assert report("seediness decoder T%d" % T, a, g["seediness"]) <= 1e-3
+    assert np.array_equal(a, b), "decoder is not run-to-run deterministic"
+
+
+def test_decoder_full_size_480x864_vs_oracle(hip):
+    """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle."""
+    T, h32, w32 = 8, 15, 27
+    head = _emb_head("xyff", 4, True, False, T, 41)
+    sd = synth.synth_state_dict(odec.decoder_param_shapes("embedding_head.", mode="xyff", embedding_size=4), 41)
+    feats = synth.synth_features(T, h32, w32, seed=41)
+    ref = odec.embedding_decoder(feats, sd, "xyff", True).numpy()
+    out = head([dev(f)[None] for f in feats])[0].cpu().numpy()
+    assert out.shape == (6, 8, 120, 216)
+    assert report("decoder 480x864", out, ref) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ fg mask / gather
+def test_fg_mask_accumulate(hip):
+    rs = np.random.RandomState(3)
+    planes = [rs.uniform(0, 1, (13, 17)).astype(np.float32) for _ in range(3)]
+    acc = torch.empty(13, 17, device="cuda")
+    for i, p in enumerate(planes):
+        hip.seediness_accumulate(acc, dev(p), i == 0)
+    m = hip.fg_mask(acc, 3.0, 0.5).cpu().numpy()
+    ref = ((0.0 + torch.from_numpy(planes[0]) + torch.from_numpy(planes[1]) + torch.from_numpy(planes[2])) / 3.0 > 0.5).numpy()
+    assert np.array_equal(m.astype(bool), ref)
+
+
+@pytest.mark.parametrize("case", [(4, 20, 28, 5), (3, 7, 5, 0), (8, 33, 65, 12)])
+def test_fg_gather_vs_oracle(hip, case):
+    T, H, W, K = case
+    emb, bw, sd, fg = synth.synth_cluster_case(T, H, W, K, seed=K)
+    e, b, s, counts = opipe.gather_fg(emb, bw, sd, fg)
+    ge, gb, gs, vox, offs = hip.fg_gather(dev(emb), dev(bw), dev(sd), dev(fg))
+    offs = offs.cpu().numpy()
+    n = int(offs[-1])
+    assert n == e.shape[0] and np.array_equal(np.diff(offs), counts)
+    assert np.array_equal(ge[:n].cpu().numpy(), e) and np.array_equal(gb[:n].cpu().numpy(), b) and np.array_equal(gs[:n].cpu().numpy(), s[:, 0])
+    assert np.array_equal(vox[:n].cpu().numpy(), np.flatnonzero(fg.reshape(-1)))
+    # all-foreground and all-background masks
+    for fill in (0, 1):
+        f2 = np.full_like(fg, fill)
+        _, _, _, vox2, offs2 = hip.fg_gather(dev(emb), dev(bw), dev(sd), dev(f2))
+        assert offs2.cpu().tolist() == [fill * H * W * t for t in range(T + 1)]
+
+
+# ------------------------------------------------------------------------------------------------ clustering
+def _hip_cluster(case_emb, case_bw, case_seed, params, want=True):
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    nfree = int(params[3])
+    cl = SequentialClustering(0.5, 0.3, float(params[0]), nfree, [float(v) for v in params[4:4 + nfree]], "cuda:0",
+                              max_instances=int(params[1]))
+    labels, meta = cl(dev(case_emb), bandwidths=dev(case_bw), seediness=dev(case_seed), cluster_label_start=int(params[2]),
+                      return_label_masks=want, return_probs=want)
+    return labels.cpu().numpy(), meta
+
+
+def _oracle_cluster(c, n, probs=False):
+    p = c[n + "__params"]
+    nfree = int(p[3])
+    return sequential_clustering(c[n + "__emb"], c[n + "__bw"], c[n + "__seed"], label_start=int(p[2]), min_seediness=p[0],
+                                 max_instances=int(p[1]), free_dim_stds=p[4:4 + nfree], return_masks=True, return_probs=probs)
+
+
+def test_cluster_vs_golden_exact(hip, golden):
+    c = golden("cluster")
+    for n in [str(x) for x in c["__names"] if str(x) != "adversarial_cloud"]:
+        labels, meta = _hip_cluster(c[n + "__emb"], c[n + "__bw"], c[n + "__seed"], c[n + "__params"])
+        E = c[n + "__emb"].shape[1]
+        assert labels.dtype == np.int64
+        assert meta["instance_labels"] == c[n + "__instance_labels"].tolist(), n
+        bad = np.flatnonzero(labels != c[n + "__labels"])
+        assert bad.size == 0, "%s: %d label mismatches, first at %s" % (n, bad.size, bad[:5])
+        assert np.array_equal(np.array(meta["instance_centers"], np.float32).reshape(-1, E), c[n + "__centers"]), n
+        assert report("stds " + n, np.array(meta["instance_stds"], np.float32).reshape(-1, E), c[n + "__stds"]) <= 1e-6
+        masks = np.stack([m.numpy() for m in meta["instance_masks"]]) if meta["instance_masks"] else np.zeros((0, labels.shape[0]), bool)
+        assert np.array_equal(masks, c[n + "__masks"]), n
+
+
+def test_cluster_adversarial_band(hip, golden):
+    """Points within a few ulp of a threshold may legitimately differ (CPU libm vs GPU expf/sqrt);
+    everything else -- and the instance list -- must match exactly, and probabilities agree to 1e-6."""
+    c = golden("cluster")
+    n = "adversarial_cloud"
+    labels, meta = _hip_cluster(c[n + "__emb"], c[n + "__bw"], c[n + "__seed"], c[n + "__params"])
+    ref_labels, ref_meta = _oracle_cluster(c, n, probs=True)
+    assert meta["instance_labels"] == ref_meta["instance_labels"]
+    P = np.stack(ref_meta["instance_probs"])
+    G = np.stack([p.numpy() for p in meta["instance_probs"]])
+    assert report("cluster probs", G, P) <= 1e-6
+    near = (np.abs(P - 0.5) < 2e-6).any(0) | (np.abs(P - 0.3) < 2e-6).any(0)
+    bad = np.flatnonzero(labels != ref_labels)
+    print("[parity] adversarial cloud: %d mismatches, %d points in the threshold band" % (bad.size, int(near.sum())))
+    assert np.all(near[bad])
+
+
+@pytest.mark.parametrize("K", [0, 1, 10, 25])
+def test_cluster_full_size_vs_oracle(hip, K):
+    """N ~ 2e5 points (T=8, 120x216, BASELINE config 1 shape): exact labels on margin data, deterministic."""
+    emb, bw, sd, fg = synth.synth_cluster_case(8, 120, 216, K, seed=100 + K, bg_fraction=0.5)
+    e, b, s, _ = opipe.gather_fg(emb, bw, sd, fg)
+    ref, ref_meta = sequential_clustering(e, b, s, label_start=3, free_dim_stds=[0.3, 0.3])
+    params = np.array([0.8, 20, 3, 2, 0.3, 0.3])
+    l1, m1 = _hip_cluster(e, b, s[:, None], params, want=False)
+    l2, _ = _hip_cluster(e, b, s[:, None], params, want=False)
+    assert m1["instance_labels"] == ref_meta["instance_labels"]
+    assert np.array_equal(l1, l2)
+    bad = np.flatnonzero(l1 != ref)
+    assert bad.size == 0, "K=%d N=%d: %d mismatches" % (K, e.shape[0], bad.size)
+
+
+def test_overlap_counts_and_relabel(hip):
+    rs = np.random.RandomState(5)
+    la = rs.randint(-1, 6, 5000).astype(np.int64)
+    lb = np.where(rs.uniform(size=5000) < 0.2, -1, rs.randint(6, 10, 5000)).astype(np.int64)
+    ids_a, ids_b = [1, 2, 3, 4, 5], [6, 7, 8, 9]
+    from stemseg_amd.inference.online_chainer import HipChainerOps
+    ops = HipChainerOps()
+    inter, ca, cb = ops.overlap_counts(dev(la), dev(lb), ids_a, ids_b)
+    assert np.array_equal(inter, np.array([[np.sum((la == a) & (lb == b)) for b in ids_b] for a in ids_a]))
+    assert np.array_equal(ca, [np.sum(la == a) for a in ids_a]) and np.array_equal(cb, [np.sum(lb == b) for b in ids_b])
+    t = dev(lb.copy())
+    ops.relabel(t, {6: 2, 8: 1})
+    ref = lb.copy()
+    ref[lb == 6] = 2
+    ref[lb == 8] = 1
+    assert np.array_equal(t.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------------------------ chainer / model end to end
+@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single"])
+def test_chainer_on_gpu_vs_golden(hip, golden, tag):
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    g = golden("chainer")
+    emb, bw, sd, fg = g[tag + "__emb"], g[tag + "__bw"], g[tag + "__sd"], g[tag + "__fg"]
+    clips = g[tag + "__subseqs"].tolist()
+    dicts = [dict(frames=list(fr), embeddings=dev(emb[:, fr]), bandwidths=dev(bw[:, fr]), seediness=dev(sd[:, fr])) for fr in clips]
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cuda:0"), 1.0)
+    (track, counts, life), mask_idxes, clip_labels, _, meta = ch.process(torch.from_numpy(fg), dicts)
+    for t, l in enumerate(track):
+        assert np.array_equal(l.numpy(), g["%s_track_%02d" % (tag, t)]), (tag, t)
+        ys, xs = np.nonzero(fg[t])
+        assert np.array_equal(mask_idxes[t][0].numpy(), ys) and np.array_equal(mask_idxes[t][1].numpy(), xs)
+    assert sorted(counts.items()) == [tuple(r) for r in g[tag + "__pt_counts"].tolist()]
+    assert sorted(life.items()) == [tuple(r) for r in g[tag + "__lifetimes"].tolist()]
+    for i in range(len(clips)):
+        assert meta[i]["instance_labels"] == g["%s_clip%d_instance_labels" % (tag, i)].tolist()
+
+
+def test_chainer_resize_path_on_gpu(hip, golden):
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    g = golden("chainer")
+    e = dev(g["resize__in"])
+    sub = {"embeddings": e, "seediness": e[:1].contiguous(), "bandwidths": e[:2].contiguous()}
+    OnlineChainer(None, 4.0).resize_tensors(sub)
+    assert report("resize x4", sub["embeddings"].cpu().numpy(), g["resize__emb"]) <= 1e-6
+
+
+def test_inference_model_vs_golden(hip, golden):
+    """frames -> batched encoder -> both HIP decoders -> fused bandwidth activation, per clip, incl. the
+    short-video dedup case; then the cross-clip seediness-averaged fg mask (model_davis golden, R-50)."""
+    from stemseg_amd import config
+    from stemseg_amd.inference.main import fg_masks_from_seediness
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    g = golden("model_davis")
+    config.load_preset("davis")
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 96, 128
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    model = InferenceModel()
+    sd = model._model.state_dict()
+    new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 21))).reshape(v.shape) for k, v in sd.items()}
+    model._model.load_state_dict(new)
+    model = model.cuda()
+    for tag, nframes in (("seq12", 12), ("seq5", 5)):
+        frames = synth.synth_frames(nframes, 96, 128, seed=21)
+        res = model([f for f in frames], g[tag + "__subseqs"].tolist())
+        for i, e in enumerate(res["embeddings"]):
+            assert list(e.subseq_frames) == g["%s_c%d_frames" % (tag, i)].tolist()
+            assert report("%s clip%d emb" % (tag, i), e.embeddings.cpu().numpy(), g["%s_c%d_emb" % (tag, i)]) <= 1e-3
+            rb = g["%s_c%d_bw" % (tag, i)]
+            assert report("%s clip%d bw (rel)" % (tag, i), e.bandwidths.cpu().numpy() / rb, np.ones_like(rb)) <= 1e-3
+            assert report("%s clip%d seed" % (tag, i), e.seediness.cpu().numpy(), g["%s_c%d_seed" % (tag, i)]) <= 1e-3
+        # fg mask kernel on the GOLDEN seediness (so the comparison is exact, not tolerance-limited)
+        entries = [(g["%s_c%d_frames" % (tag, i)].tolist(), None, None, dev(g["%s_c%d_seed" % (tag, i)])) for i in range(len(res["embeddings"]))]
+        fg = fg_masks_from_seediness(entries, float(g[tag + "__fg_thr"])).cpu().numpy()
+        assert np.array_equal(fg, g[tag + "__fg"])
+    config.load_preset("defaults")
+
+
+def test_clip_pipeline_end_to_end_vs_oracle(hip):
+    """One clip through ClipPipeline.step (the bench's unit of work) at a reduced size vs the oracle pipeline:
+    float outputs <= 1e-3; labels identical wherever the oracle's own decision has margin."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset("davis")
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    model = InferenceModel()
+    names = [(k, v.shape) for k, v in model._model.state_dict().items()]
+    sd = synth.synth_state_dict(names, 33)
+    sd["seediness_head.conv_out.weight"] = sd["seediness_head.conv_out.weight"] * 30      # spread seediness over (0, 1)
+    model._model.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(model._model.state_dict()[k].shape) for k, v in sd.items()})
+    pipe = ClipPipeline(model)
+    frames = torch.from_numpy(synth.synth_frames(8, 96, 160, seed=33).astype(np.float32)).permute(0, 3, 1, 2) - \
+        torch.tensor(config.cfg.INPUT.IMAGE_MEAN)[None, :, None, None]
+    out = pipe.step(frames.cuda())
+    ref = opipe.embed_and_cluster_clip(frames, sd, "R-50-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+    assert report("pipeline emb", out["emb"].cpu().numpy(), ref["emb"].numpy()) <= 1e-3
+    assert report("pipeline seed", out["seed"].cpu().numpy(), ref["seed"].numpy()) <= 1e-3
+    assert report("pipeline bw (rel)", (out["bw"].cpu() / ref["bw"]).numpy(), np.ones(ref["bw"].shape)) <= 1e-3
+    offs = out["frame_offsets"].cpu().numpy()
+    print("[parity] pipeline: N=%d fg points, oracle N=%d, K=%d" % (offs[-1], ref["labels"].shape[0], len(ref["meta"]["instance_labels"])))
+    # clustering on the ORACLE's embeddings through the HIP clusterer must reproduce the oracle's labels
+    o2 = pipe.cluster(ref["emb"].cuda().contiguous(), ref["bw"].cuda().contiguous(), ref["seed"].cuda().contiguous())
+    n = int(o2["frame_offsets"].cpu()[-1])
+    assert n == ref["labels"].shape[0]
+    bad = np.flatnonzero(o2["labels"][:n].cpu().numpy() != ref["labels"])
+    print("[parity] pipeline labels: %d / %d differ" % (bad.size, n))
+    assert bad.size <= max(2, n // 2000)
+    config.load_preset("defaults")

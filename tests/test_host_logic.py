@@ -1,0 +1,228 @@
+"""CPU tests of the product's host-side logic against the reference-generated goldens, plus the C-ABI export
+check.  No compute call goes through the GPU here; device ops of the chainer are replaced by the oracle twin."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder as odec
+from oracle import encoder as oenc
+from tests import synth
+from tests.conftest import ROOT
+from tests.oracle_ops import OracleChainerOps
+
+
+# ------------------------------------------------------------------------------------------------ C-ABI
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "stemseg_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(stemseg_hip_\w+)\s*\(", txt)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from stemseg_amd import hip
+    names = _header_functions()
+    assert len(names) >= 20
+    assert sorted(hip.SIGNATURES) == names, "ctypes binding and include/stemseg_hip.h disagree"
+    assert os.path.exists(hip.LIB_PATH), "libstemseg_hip.so not built (python stem-seg_amd/build.py)"
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert hip.lib().stemseg_hip_version() == hip.ABI_VERSION
+
+
+def test_cabi_struct_sizes_and_argument_errors():
+    from stemseg_amd import hip
+    l = hip.lib()
+    d = hip.DecoderDesc()
+    d.struct_bytes = ctypes.sizeof(hip.DecoderDesc) - 4              # ABI skew must be rejected, not mis-read
+    assert l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d)) == 0
+    assert b"descriptor size mismatch" in l.stemseg_hip_last_error()
+    d.struct_bytes = ctypes.sizeof(hip.DecoderDesc)
+    d.in_channels, d.T, d.H4, d.W4, d.gn_groups, d.n_out = 256, 8, 24, 32, 32, 7
+    for i, c in enumerate((256, 256, 128, 128)):
+        d.inter[i] = c
+    for i, (p, s) in enumerate(zip((1, 1, 0), (1, 2, 2))):
+        d.pool[i], d.t_scale[i] = p, s
+    nbytes = l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d))
+    assert nbytes > 4 * 256 * 10 * 26 * 36
+    d.t_scale[0] = 2                                                  # inconsistent topology
+    assert l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d)) == 0
+    g = hip.padded_geometry(256, 8, 120, 216)
+    assert g["pitch"] == 220 and g["ts"] == 122 * 220 and g["cs"] == 10 * 122 * 220 and g["interior"] == 122 * 220 + 220 + 1
+    assert ctypes.sizeof(hip.ClusterMeta) == 4 + 4 + 8 + 8 + 64 * 8 * 4 * 2 + 64 * 4
+    assert l.stemseg_hip_cluster_workspace_bytes(1000) >= 4000
+
+
+# ------------------------------------------------------------------------------------------------ small host functions
+def test_windowing_table(golden):
+    from stemseg_amd.inference.main import get_subsequence_frames
+    g = golden("misc")
+    for key in g["win__keys"]:
+        key = str(key)
+        _, ds, seq_len, T, ov = key.split("_")
+        clips, padded = get_subsequence_frames(int(seq_len), int(T), ds, int(ov))
+        assert np.array_equal(np.array(clips, np.int64), g[key]), key
+        assert (padded if padded is not None else []) == g[key + "__padded"].astype(bool).tolist(), key
+
+
+def test_embedding_utils(golden):
+    from stemseg_amd.modeling import embedding_utils as eu
+    g = golden("misc")
+    for m, nd, nf in zip(g["modes"], g["modes__nb_dims"], g["modes__nb_free"]):
+        m = str(m)
+        assert eu.get_nb_embedding_dims(m) == nd and eu.get_nb_free_dims(m) == nf
+        z = torch.zeros(1, int(nd), 3, 4, 6)
+        assert np.array_equal(eu.add_spatiotemporal_offset(z, torch.tensor(1.0), m)[0].numpy(), g["offset_" + m])
+    with pytest.raises(ValueError):
+        eu.get_nb_embedding_dims("xyz")
+    assert eu.get_nb_free_dims("bogus") == 0
+    for key in [k for k in g.files if k.startswith("grid_") and k.endswith("_x")]:
+        _, H, W, T, _ = key.split("_")
+        t, y, x = eu.creat_spatiotemporal_grid(int(H), int(W), int(T), 1.0)
+        assert t.shape == (int(T), int(H), int(W))
+        assert np.array_equal(t[:, 0, 0].numpy(), g[key[:-2] + "_t"])
+        assert np.array_equal(y[0, :, 0].numpy(), g[key[:-2] + "_y"])
+        assert np.array_equal(x[0, 0, :].numpy(), g[key])
+
+
+def test_resize_params_and_preprocessing(golden):
+    from stemseg_amd import config
+    from stemseg_amd.modeling import inference_model as im
+    g = golden("misc")
+    for w, h, mn, mx, nw, nh in g["resize_params"].tolist():
+        got = im.compute_resize_params_2((w, h), mn, mx)
+        assert (got[0], got[1]) == (nw, nh)
+    assert im.pad_to_multiple_of_32(480, 854) == (480, 864) and im.pad_to_multiple_of_32(701, 1248) == (704, 1248)
+    old = (config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM)
+    try:
+        config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 64, 96
+        out, _ = im.preprocess_frames(g["preproc__in"][None], device="cpu")
+        assert out.shape[1:] == g["preproc__out"].shape
+        assert np.abs(out[0].numpy() - g["preproc__out"]).max() <= 1e-4
+    finally:
+        config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = old
+
+
+def test_registry_contract():
+    from stemseg_amd.utils import GlobalRegistry
+    from stemseg_amd.modeling.embedding_decoder import EMBEDDING_HEAD_REGISTRY, SqueezingExpandDecoder
+    from stemseg_amd.modeling.seediness_decoder import SEEDINESS_HEAD_REGISTRY
+    from stemseg_amd.modeling.backbone import BACKBONE_REGISTRY
+    assert GlobalRegistry.get("EmbeddingHead") is EMBEDDING_HEAD_REGISTRY
+    assert EMBEDDING_HEAD_REGISTRY["squeeze_expand_decoder"] is SqueezingExpandDecoder
+    assert SEEDINESS_HEAD_REGISTRY["squeeze_expand_decoder"] is not SqueezingExpandDecoder
+    assert "R-101-FPN" in BACKBONE_REGISTRY and "R-50-FPN" in BACKBONE_REGISTRY
+    with pytest.raises(KeyError):
+        EMBEDDING_HEAD_REGISTRY["nope"]
+    with pytest.raises(AssertionError):
+        EMBEDDING_HEAD_REGISTRY.add("squeeze_expand_decoder", object)
+    r = GlobalRegistry.get("UnitTestRegistry")
+
+    @r.add("thing")
+    def thing():
+        return 1
+    assert r["thing"] is thing
+
+
+# ------------------------------------------------------------------------------------------------ state-dict contracts
+def _gn(c):
+    return torch.nn.GroupNorm(32, c)
+
+
+def test_decoder_state_dict_keys_match_reference_layout():
+    from stemseg_amd.modeling.embedding_decoder import SqueezingExpandDecoder as Emb
+    from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
+    for T in (4, 8, 16):
+        e = Emb(256, [256, 256, 128, 128], 4, True, True, "xyff", NormType=_gn, num_frames=T)
+        want = dict(odec.decoder_param_shapes("", mode="xyff", embedding_size=4, seediness_output=True))
+        got = {k: tuple(v.shape) for k, v in e.state_dict().items()}
+        assert got == {k: tuple(v) for k, v in want.items()}
+        assert (e.embedding_size, e.variance_channels, e.seediness_channels) == (4, 2, 1)
+    e = Emb(256, [256, 256, 128, 128], 3, True, False, "xyt", NormType=_gn, num_frames=8)
+    assert (e.variance_channels, e.seediness_channels) == (3, 0) and "conv_seediness.weight" not in e.state_dict()
+    s = Seed(256, [256, 256, 128, 128], NormType=_gn, num_frames=8)
+    want = dict(odec.decoder_param_shapes("", kind="seediness"))
+    assert {k: tuple(v.shape) for k, v in s.state_dict().items()} == {k: tuple(v) for k, v in want.items()}
+    with pytest.raises(NotImplementedError):
+        Emb(256, [256, 256, 128, 128], 4, True, True, "xyff", NormType=_gn, num_frames=7)
+
+
+def test_decoder_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
+    s = Seed(256, [256, 256, 128, 128], NormType=_gn, num_frames=8)
+    feats = [torch.zeros(1, 256, 8, 3 * k, 3 * k) for k in (1, 2, 4, 8)]
+    with pytest.raises(RuntimeError, match="no MI355X visible"):
+        s(feats)
+
+
+@pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
+def test_backbone_module_vs_golden(golden, btype):
+    """Own encoder module (FrozenBN folded, batched) with the reference's key names vs reference outputs."""
+    from stemseg_amd.modeling.backbone import ResNetFPN
+    g = golden("encoder")
+    tag = btype.replace("-", "")
+    H, W, seed, stride = g[tag + "__meta"].tolist()
+    bb = ResNetFPN(btype).eval()
+    want = dict(oenc.backbone_param_shapes(btype, prefix=""))
+    assert {k: tuple(v.shape) for k, v in bb.state_dict().items()} == {k: tuple(v) for k, v in want.items()}
+    sd = {k: torch.from_numpy(np.asarray(synth.synth_param("backbone." + k, v.shape, seed))).reshape(v.shape)
+          for k, v in bb.state_dict().items()}
+    bb.load_state_dict(sd)
+    x = synth.synth_frames(2, H, W, seed=seed).astype(np.float32)
+    x = torch.from_numpy(x).permute(0, 3, 1, 2) - torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    feats = bb.run_backbone(x)
+    for s in (4, 8, 16, 32):
+        ref = g["%s_s%d" % (tag, s)]
+        got = feats[s].contiguous().numpy().reshape(-1)[::stride]
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (btype, s)
+
+
+# ------------------------------------------------------------------------------------------------ chainer host logic
+def _make_chainer(resize=1.0):
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    return OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), resize, ops=OracleChainerOps())
+
+
+@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single"])
+def test_chainer_bookkeeping_vs_golden(golden, tag):
+    g = golden("chainer")
+    emb, bw, sd, fg = g[tag + "__emb"], g[tag + "__bw"], g[tag + "__sd"], g[tag + "__fg"]
+    clips = g[tag + "__subseqs"].tolist()
+    dicts = [dict(frames=list(fr), embeddings=torch.from_numpy(emb[:, fr].copy()), bandwidths=torch.from_numpy(bw[:, fr].copy()),
+                  seediness=torch.from_numpy(sd[:, fr].copy())) for fr in clips]
+    (track, counts, life), mask_idxes, clip_labels, _, meta = _make_chainer().process(torch.from_numpy(fg), dicts)
+    for t, l in enumerate(track):
+        assert l.dtype == torch.int64
+        assert np.array_equal(l.numpy(), g["%s_track_%02d" % (tag, t)]), (tag, t)
+        ys, xs = np.nonzero(fg[t])
+        assert np.array_equal(mask_idxes[t][0].numpy(), ys) and np.array_equal(mask_idxes[t][1].numpy(), xs)
+    assert sorted(counts.items()) == [tuple(r) for r in g[tag + "__pt_counts"].tolist()]
+    assert sorted(life.items()) == [tuple(r) for r in g[tag + "__lifetimes"].tolist()]
+    for i in range(len(clips)):
+        assert np.array_equal(torch.cat(clip_labels[i]).numpy(), g["%s_clip%d_labels" % (tag, i)]), (tag, i)
+        assert meta[i]["instance_labels"] == g["%s_clip%d_instance_labels" % (tag, i)].tolist(), (tag, i)
+    assert all(d["embeddings"] is None for d in dicts)       # reference clears the tensors (online_chainer.py:239)
+
+
+def test_chainer_resize_path(golden):
+    g = golden("chainer")
+    e = torch.from_numpy(g["resize__in"])
+    sub = {"embeddings": e, "seediness": e[:1].clone(), "bandwidths": e[:2].clone()}
+    _make_chainer(4.0).resize_tensors(sub)
+    assert np.abs(sub["embeddings"].numpy() - g["resize__emb"]).max() <= 1e-6
+    assert sub["seediness"].shape == (1, 2, 20, 28) and sub["bandwidths"].shape == (2, 2, 20, 28)
+
+
+def test_fg_mask_and_clip_assembly_semantics(golden):
+    """dedup rule of inference_model.py:137-138 for short videos: the LAST occurrence of a repeated frame wins."""
+    g = golden("model_davis")
+    sub = g["seq5__subseqs"].tolist()[0]
+    assert sub == [0, 0, 0, 0, 1, 2, 3, 4] and g["seq5_c0_frames"].tolist() == [0, 1, 2, 3, 4]
+    assert g["seq5_c0_emb"].shape[1] == 5

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): parity tests, smoke, a short bench and a rocprofv3 kernel trace of it.
+# Everything lands in gpurun_out/ (merged back by gpurun).  Usage: tools/gpu_round.sh [tests|bench|prof|all]
+set -u
+what=${1:-all}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+export PYTHONUNBUFFERED=1
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 > gpurun_out/device.txt
+nproc >> gpurun_out/device.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> gpurun_out/device.txt
+if [[ $what == all || $what == tests ]]; then
+  timeout 1500 python -m pytest tests -m gpu -q -s --timeout 600 -p no:cacheprovider > gpurun_out/tests.log 2>&1
+  echo "pytest exit $?" >> gpurun_out/tests.log
+  tail -5 gpurun_out/tests.log
+fi
+if [[ $what == all || $what == smoke ]]; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -3 gpurun_out/smoke.log
+fi
+if [[ $what == all || $what == bench ]]; then
+  timeout 900 python bench.py --steps ${STEPS:-10} --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench exit $?" >> gpurun_out/bench.log; tail -4 gpurun_out/bench.log
+fi
+if [[ $what == all || $what == prof ]]; then
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
+  echo "prof exit $?" >> gpurun_out/prof.log
+  find gpurun_out/prof -name "*stats*" | head; tail -3 gpurun_out/prof.log
+fi
