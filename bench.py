@@ -87,7 +87,8 @@ def cpu_baseline(sd, frames_cpu):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned against reference-generated goldens)
     on the host cores: ONE clip of the same workload, 1 timed run (no warm-up; ~10-30 s)."""
     from oracle import pipeline as opipe
-    n = os.cpu_count() or 1
+    # more threads than ~32 make torch's CPU conv / GroupNorm path slower on the 2-socket host (141 s with 256)
+    n = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n)
     t0 = time.time()
     out = opipe.embed_and_cluster_clip(frames_cpu, sd, BACKBONE, "xyff", 4, True, free_dim_stds=[0.3, 0.3])
