@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Steady-state per-step kernel breakdown from a rocprofv3 rocpd trace of bench.py: uses the last `n` steps, a step
+being delimited by every 2nd launch of the big 3x3x3 conv tile (block_4x of the two decoders).
+Usage: tools/prof_steady.py results.db [n_steps]"""
+import sqlite3
+import sys
+
+c = sqlite3.connect(sys.argv[1])
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+rows = c.execute("select name, start, end, grid_x, grid_y, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
+big = [r for r in rows if "conv_igemm" in r[0] and "<3, 3, 3, 4, 4, 2, 1, 4, 1>" in r[0]]
+assert len(big) >= 2 * (n + 1), "not enough steps in the trace"
+t0, t1 = big[-2 * n - 1][2], big[-1][2]
+agg = {}
+for name, s, e, gx, gy, wx, lds, vg in rows:
+    if s < t0 or e > t1:
+        continue
+    short = name.split("(")[0]
+    if "conv_igemm" in name:
+        short = "conv_igemm<%s> grid=%dx%d" % (name.split("ConvCfg<")[1].split(">")[0], gx // wx, gy)
+    short = short.replace("void ", "").replace("stemseg::", "")
+    if len(short) > 100:
+        short = short[:97] + "..."
+    a = agg.setdefault(short, [0, 0.0, lds, vg])
+    a[0] += 1
+    a[1] += (e - s) / 1e3
+tot = sum(a[1] for a in agg.values())
+print("# steady state: %d steps, wall %.2f ms/step, kernel-busy %.2f ms/step" % (n, (t1 - t0) / 1e6 / n, tot / 1e3 / n))
+print("%-102s %9s %11s %10s %6s %7s %5s" % ("kernel", "calls/stp", "us/step", "avg_us", "%", "lds", "vgpr"))
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("%-102s %9.1f %11.1f %10.1f %6.2f %7d %5d" % (k, a[0] / n, a[1] / n, a[1] / a[0], 100 * a[1] / tot, a[2], a[3]))
