@@ -137,6 +137,10 @@ typedef struct StemsegDecoderDesc {
     int32_t act[STEMSEG_MAX_EMB_DIMS * 2];        /* per output channel, see stemseg_hip_heads          */
     int32_t grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
     int32_t input_layout;        /* 0: [C][T][h][w] dense, 1: [T][C][h][w] dense, 2: already zero-haloed     */
+    int32_t concurrency;         /* 0: every launch on the caller's stream.  k >= 1: the 32x / 16x / 8x branches run
+                                    on the library's internal stream set (k-1) % 4 beside the 4x branch (fork / join by
+                                    events on the caller's stream; the call is still stream-ordered for the caller).
+                                    Decoders that may overlap (embedding + seediness) should use different sets.     */
 } StemsegDecoderDesc;
 
 typedef struct StemsegDecoderWeights {

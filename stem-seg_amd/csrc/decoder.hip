@@ -59,7 +59,7 @@ struct DecoderPlan {
     int h[4], w[4];                 // 32x, 16x, 8x, 4x
     int Ta1, Ta2, Ta3, Tb1, Tb2, Tc1, T16, T8;
     // workspace offsets in floats
-    int64_t pin[4], D, P32b, P32c, X32, cat16, P16b, X16, cat8, X8, cat4, X4, stats, gn_scratch, total;
+    int64_t pin[4], D[4], P32b, P32c, X32, cat16, P16b, X16, cat8, X8, cat4, X4, stats[4], gn_scratch[4], total;
 };
 
 static inline int pooled(int T, int on) { return on ? (T + 1) / 2 : T; }
@@ -89,12 +89,11 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     int64_t off = 0;
     auto take = [&](int64_t floats) { int64_t o = off; off += round_up(floats, 64); return o; };
     for (int i = 0; i < 4; ++i) p.pin[i] = (d->input_layout == 2) ? -1 : take(PaddedGeom(p.cin, p.T, p.h[i], p.w[i]).total);
-    int64_t dmax = 0;
-    dmax = std::max<int64_t>(dmax, (int64_t)p.c32 * p.T * p.h[0] * p.w[0]);
-    dmax = std::max<int64_t>(dmax, (int64_t)p.c16 * p.T * p.h[1] * p.w[1]);
-    dmax = std::max<int64_t>(dmax, (int64_t)p.c8 * p.T * p.h[2] * p.w[2]);
-    dmax = std::max<int64_t>(dmax, (int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
-    p.D = take(dmax);
+    // one dense conv-output scratch per branch: the four branches run concurrently on their own streams
+    p.D[0] = take((int64_t)p.c32 * p.T * p.h[0] * p.w[0]);
+    p.D[1] = take((int64_t)p.c16 * p.T * p.h[1] * p.w[1]);
+    p.D[2] = take((int64_t)p.c8 * p.T * p.h[2] * p.w[2]);
+    p.D[3] = take((int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
     p.P32b = take(PaddedGeom(p.c32, p.Ta1, p.h[0], p.w[0]).total);
     p.P32c = take(PaddedGeom(p.c32, p.Ta2, p.h[0], p.w[0]).total);
     p.X32 = take((int64_t)p.c32 * p.Ta3 * p.h[0] * p.w[0]);
@@ -105,11 +104,39 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     p.X8 = take((int64_t)p.c8 * p.T8 * p.h[2] * p.w[2]);
     p.cat4 = take((int64_t)(p.c8 + p.c4) * p.T * p.h[3] * p.w[3]);
     p.X4 = take((int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
-    p.stats = take(2 * 64);
-    p.gn_scratch = take(2 * 64 * 128);   // doubles: groups(<=64) * GN_SPLIT(64) * 2
+    for (int i = 0; i < 4; ++i) {
+        p.stats[i] = take(2 * 64);
+        p.gn_scratch[i] = take(2 * 64 * 128);   // doubles: groups(<=64) * GN_SPLIT(64) * 2
+    }
     p.total = off;
     SS_CHECK_ARG(p.G <= 64, "decoder: gn_groups > 64");
     return STEMSEG_OK;
+}
+
+// ---- internal branch streams: the 32x / 16x / 8x branches of a decoder are independent until the fuse convs ----
+constexpr int STREAM_SETS = 4;
+struct BranchStreams {
+    bool ok = false;
+    hipStream_t s[3];
+    hipEvent_t start, done[3];
+};
+static BranchStreams g_streams[16][STREAM_SETS];   // [device][set]
+static std::mutex g_streams_mu;
+
+static BranchStreams* get_streams(int set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    BranchStreams& b = g_streams[dev][((set % STREAM_SETS) + STREAM_SETS) % STREAM_SETS];
+    if (!b.ok) {
+        for (int i = 0; i < 3; ++i) {
+            if (hipStreamCreateWithFlags(&b.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&b.start, hipEventDisableTiming) != hipSuccess) return nullptr;
+        b.ok = true;
+    }
+    return &b;
 }
 
 // channel slice [c0, c0+C) of a dense [Ctot][T][H][W] buffer
@@ -217,11 +244,18 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
 
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
-    float* D = ws + p.D;
-    float* stats = ws + p.stats;
-    double* scratch = reinterpret_cast<double*>(ws + p.gn_scratch);
     const float eps = desc->gn_eps;
     const int G = p.G, T = p.T;
+    float* D[4]; float* stats[4]; double* scratch[4];
+    for (int i = 0; i < 4; ++i) {
+        D[i] = ws + p.D[i];
+        stats[i] = ws + p.stats[i];
+        scratch[i] = reinterpret_cast<double*>(ws + p.gn_scratch[i]);
+    }
+    // Branch streams: main stream runs the 4x branch (65 % of the FLOPs); 32x / 16x / 8x run beside it and join at
+    // the fuse convolutions.  concurrency == 0 keeps everything on the caller's stream.
+    BranchStreams* bs = desc->concurrency ? get_streams(desc->concurrency - 1) : nullptr;
+    hipStream_t s32 = bs ? bs->s[0] : s, s16 = bs ? bs->s[1] : s, s8 = bs ? bs->s[2] : s;
 
     // 0. inputs into the zero-haloed layout (skipped when the caller already provides it)
     float* pin[4];
@@ -233,44 +267,54 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
             if (rc) return rc;
         }
     }
-    // 1. block_32x: three conv/GN/ReLU(/pool) stages  (embedding_decoder.py:20-35)
+    if (bs) {
+        SS_HIP(hipEventRecord(bs->start, s));
+        for (int i = 0; i < 3; ++i) SS_HIP(hipStreamWaitEvent(bs->s[i], bs->start, 0));
+    }
+    // 1. block_32x on s32: three conv/GN/ReLU(/pool) stages (embedding_decoder.py:20-35), then upsample into cat16[0:c32]
     rc = conv_gn(padded_halo_view(pin[0], p.cin, T, p.h[0], p.w[0]), wts->conv_w[0], wts->conv_b[0], wts->gn_w[0], wts->gn_b[0], p.c32, T,
-                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D, stats, scratch, G, eps, s);
+                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), wts->conv_w[1], wts->conv_b[1], wts->gn_w[1], wts->gn_b[1], p.c32,
-                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D, stats, scratch, G, eps, s);
+                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), wts->conv_w[2], wts->conv_b[2], wts->gn_w[2], wts->gn_b[2], p.c32,
-                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D, stats, scratch, G, eps, s);
+                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32);
     if (rc) return rc;
-    // 2. 32x -> 16x: upsample into cat16[0:c32], block_16x into cat16[c32:], 1x1x1 fuse  (:112-117)
     rc = launch_upsample(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2,
-                         slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s);
+                         slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s32);
     if (rc) return rc;
+    if (bs) SS_HIP(hipEventRecord(bs->done[0], s32));
+    // 2. block_16x on s16 into cat16[c32:], join 32x, 1x1x1 fuse, upsample into cat8[0:c16]  (:112-117)
     rc = conv_gn(padded_halo_view(pin[1], p.cin, T, p.h[1], p.w[1]), wts->conv_w[3], wts->conv_b[3], wts->gn_w[3], wts->gn_b[3], p.c16, T,
-                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D, stats, scratch, G, eps, s);
+                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), wts->conv_w[4], wts->conv_b[4], wts->gn_w[4], wts->gn_b[4], p.c16,
-                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D, stats, scratch, G, eps, s);
+                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16);
     if (rc) return rc;
     const int64_t V16 = (int64_t)p.T16 * p.h[1] * p.w[1], V8 = (int64_t)p.T8 * p.h[2] * p.w[2], V4 = (int64_t)T * p.h[3] * p.w[3];
-    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s);
+    if (bs) SS_HIP(hipStreamWaitEvent(s16, bs->done[0], 0));
+    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16);
     if (rc) return rc;
-    // 3. 16x -> 8x  (:119-123)
     rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
-                         slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s);
+                         slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16);
     if (rc) return rc;
+    if (bs) SS_HIP(hipEventRecord(bs->done[1], s16));
+    // 3. block_8x on s8 into cat8[c16:], join 16x, fuse, upsample into cat4[0:c8]  (:119-123)
     rc = conv_gn(padded_halo_view(pin[2], p.cin, T, p.h[2], p.w[2]), wts->conv_w[5], wts->conv_b[5], wts->gn_w[5], wts->gn_b[5], p.c8, T, p.h[2],
-                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D, stats, scratch, G, eps, s);
+                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8);
     if (rc) return rc;
-    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s);
+    if (bs) SS_HIP(hipStreamWaitEvent(s8, bs->done[1], 0));
+    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8);
     if (rc) return rc;
-    // 4. 8x -> 4x  (:125-129)
-    rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s);
+    rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8);
     if (rc) return rc;
+    if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
+    // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D, stats, scratch, G, eps, s);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, s);
     if (rc) return rc;
+    if (bs) SS_HIP(hipStreamWaitEvent(s, bs->done[2], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, s);
     if (rc) return rc;
     // 5. heads (:131-143)

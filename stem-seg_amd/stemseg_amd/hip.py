@@ -28,7 +28,7 @@ class DecoderDesc(C.Structure):
                 ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
                 ("pool", C.c_int32 * 3), ("t_scale", C.c_int32 * 3), ("n_out", C.c_int32),
                 ("act", C.c_int32 * (2 * MAX_EMB_DIMS)), ("grid_axis", C.c_int32 * (2 * MAX_EMB_DIMS)),
-                ("input_layout", C.c_int32)]
+                ("input_layout", C.c_int32), ("concurrency", C.c_int32)]
 
 
 class DecoderWeights(C.Structure):

@@ -61,6 +61,7 @@ class SqueezeExpandTrunk(nn.Module):
         self._cache = {}          # packed weights keyed by parameter versions
         self._workspaces = {}     # (T, H4, W4, layout) -> (tensor, desc)
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
+        self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
 
     # ---- to be provided by the concrete decoder ---------------------------------------------------
     def _head_spec(self):
@@ -129,6 +130,7 @@ class SqueezeExpandTrunk(nn.Module):
         for o in range(d.n_out):
             d.act[o], d.grid_axis[o] = act[o], c["axes"][o]
         d.input_layout = layout
+        d.concurrency = int(self.concurrency)
         key = (T, H4, W4, layout, dev.index)
         ws = self._workspaces.get(key)
         if ws is None:

@@ -126,15 +126,35 @@ class InferenceModel(nn.Module):
         feats = ([b for b, _ in pads], (T, H // 4, W // 4))
         eh = m.embedding_head
         eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
+        seed = None
+        if eh.seediness_channels == 0:
+            # the seediness decoder shares nothing with the embedding decoder but its (read-only) inputs: run it on a
+            # side stream (its own branch-stream set) so the two decoders fill the chip together
+            assert m.seediness_head is not None
+            main = torch.cuda.current_stream()
+            side = self._side_stream(dev)
+            side.wait_stream(main)
+            m.seediness_head.concurrency = 2
+            with torch.cuda.stream(side):
+                seed = m.seediness_head.forward_single(feats, 2)
+                if self.resize_scale != 1.0:                                            # inference_model.py:156 quirk
+                    seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         out = eh.forward_single(feats, 2)
         E, Ev = eh.embedding_size, eh.variance_channels
-        emb, bw, seed = out[:E], out[E:E + Ev], out[E + Ev:]
-        if seed.shape[0] == 0:
-            assert m.seediness_head is not None
-            seed = m.seediness_head.forward_single(feats, 2)
-            if self.resize_scale != 1.0:                                                # inference_model.py:156 quirk
-                seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+        emb, bw = out[:E], out[E:E + Ev]
+        if seed is None:
+            seed = out[E + Ev:]
+        else:
+            main.wait_stream(side)
+            seed.record_stream(main)
         return emb, bw, seed
+
+    def _side_stream(self, dev):
+        if getattr(self, "_side", None) is None:
+            self._side = {}
+        if dev.index not in self._side:
+            self._side[dev.index] = torch.cuda.Stream(device=dev)
+        return self._side[dev.index]
 
     @torch.no_grad()
     def forward(self, images, subseq_idxes):

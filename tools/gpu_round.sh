@@ -25,3 +25,11 @@ if [[ $what == all || $what == prof ]]; then
   echo "prof exit $?" >> gpurun_out/prof.log
   find gpurun_out/prof -name "*stats*" | head; tail -3 gpurun_out/prof.log
 fi
+if [[ $what == pmc ]]; then
+  # PMC passes on the dominant kernel only, counters in their own runs (no trace domains besides kernel-trace)
+  for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+    tag=$(echo $c | tr ' ' '_' | cut -c1-40)
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_conv.py 3 ${PMC_CFG:-0}) > gpurun_out/pmc_$tag.log 2>&1
+    echo "pmc $tag exit $?"; tail -2 gpurun_out/pmc_$tag.log
+  done
+fi
