@@ -1,0 +1,1 @@
+from stemseg_amd.modeling.backbone import BACKBONE_REGISTRY, build_resnet_fpn_backbone  # noqa: F401
