@@ -84,9 +84,13 @@ int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32_t Cout, in
 /* out[co,t,y,x] = bias[co] + sum_{ci,dt,dy,dx} W[co,ci,dt,dy,dx] * in[ci, t+dt, y+dy, x+dx]
  * "valid" cross-correlation: `in` is the haloed volume (in->T = out->T + kt-1, likewise H, W), so
  * Conv3d(k=3, padding=1) of embedding_decoder.py:21 is `in` = zero-haloed layout.  (kt,kh,kw) is
- * (3,3,3) or (1,1,1).  bias may be NULL.  tile_cfg: 0 = auto, 1..3 = force a tile shape (tuning). */
+ * (3,3,3) or (1,1,1).  bias may be NULL.  tile_cfg: 0 = auto, 1..3 = force a tile shape (tuning).
+ * splitk_scratch (may be NULL): device scratch of splitk_scratch_floats floats; when a layer yields too few
+ * workgroups to fill the chip the input channels are split over up to 16 workgroups per tile, partial sums go to the
+ * scratch (k * Cout*T*H*W floats) and a second kernel reduces them in fixed order (+ bias) into `out`. */
 int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
-                       int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, void* stream);
+                       int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
+                       int64_t splitk_scratch_floats, void* stream);
 
 /* GroupNorm statistics over a dense [C][S] tensor (S = T*H*W), `groups` contiguous channel groups:
  * stats[2g] = mean, stats[2g+1] = 1/sqrt(biased_var + eps).  scratch: >= groups*128 doubles. */

@@ -76,7 +76,7 @@ void profile_end(void* handle, hipStream_t s);
 
 // ---- internal kernel launchers shared between api.hip and decoder.hip -------------------------
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
-                  int kt, int kh, int kw, int tile_cfg, hipStream_t s);
+                  int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0);
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s);
 int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
                         const float* beta, int pool, const StemsegVolume& out, hipStream_t s);

@@ -36,6 +36,8 @@ struct ConvKParams {
     int Cin, Cout, T, H, W;
     int tiles_x, tiles_y;
     int vec4;
+    int chunks_per_split;        // split-K: blockIdx.z handles channel chunks [z*cps, (z+1)*cps)
+    int64_t out_split_stride;    // floats between the partial-sum slabs of consecutive splits
 };
 
 template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_>
@@ -69,7 +71,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int half = lane >> 5, l31 = lane & 31;
 
-    int bx = blockIdx.x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only), so give every XCD a
+    // contiguous run of tiles -- neighbouring tiles share halo rows / t-planes through that XCD's L2.
+    int bx;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y;
@@ -96,7 +104,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
 
-    for (int c0 = 0; c0 < p.Cin; c0 += C::CK) {
+    const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
+    const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
+    for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
         __syncthreads();   // everyone is done reading the previous chunk
         // ---- stage the input halo tile --------------------------------------------------------
         if (p.vec4) {
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         const int y = y0 + s / C::COLS;
         const int x = x0 + (s % C::COLS) * 32 + l31;
         if (y < p.H && x < p.W) {
-            float* o = p.out + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+            float* o = p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi) {
 #pragma unroll
@@ -198,6 +208,29 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
                 }
             }
         }
+    }
+}
+
+// split-K epilogue: out[c,t,y,x] = bias[c] + sum_z partial[z][c][t][y][x]   (fixed order -> deterministic)
+struct SplitReduceParams {
+    const float* partial;
+    const float* bias;
+    float* out;
+    int64_t out_cs, out_ts, out_ys, slab;
+    int C, T, H, W, ksplit;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReduceParams p) {
+    const int64_t HW = (int64_t)p.H * p.W, per_c = (int64_t)p.T * HW, total = per_c * p.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / per_c);
+        int64_t r = i - (int64_t)c * per_c;
+        const int t = (int)(r / HW);
+        r -= (int64_t)t * HW;
+        const int y = (int)(r / p.W), x = (int)(r - (int64_t)y * p.W);
+        float acc = p.partial[i];
+        for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
+        if (p.bias) acc += p.bias[c];
+        p.out[(int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x] = acc;
     }
 }
 
@@ -225,14 +258,34 @@ using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8>;  // 128 co x 256 voxels
 using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4>; // 128 co x 128 voxels
 
 template <class C>
-static int launch_cfg(ConvKParams p, hipStream_t s) {
+static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats) {
     p.tiles_x = (int)ceil_div(p.W, C::COLS * 32);
     p.tiles_y = (int)ceil_div(p.H, C::ROWS);
-    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT));
+    // split-K over the input-channel chunks when the layer alone cannot give every CU two workgroups
+    const int nchunks = (int)ceil_div(p.Cin, C::CK);
+    const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.T * ceil_div(p.Cout, C::MT);
+    const int64_t slab = (int64_t)p.Cout * p.T * p.H * p.W;
+    int ksplit = 1;
+    while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= 640 && slab * ksplit * 2 <= scratch_floats) ksplit *= 2;
+    p.chunks_per_split = (int)ceil_div(nchunks, ksplit);
+    ksplit = (int)ceil_div(nchunks, p.chunks_per_split);
+    SplitReduceParams rp;
+    if (ksplit > 1) {
+        rp.partial = scratch; rp.bias = p.bias; rp.out = p.out; rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys;
+        rp.slab = slab; rp.C = p.Cout; rp.T = p.T; rp.H = p.H; rp.W = p.W; rp.ksplit = ksplit;
+        p.out = scratch; p.bias = nullptr;
+        p.out_cs = (int64_t)p.T * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
+        p.out_split_stride = slab;
+    } else p.out_split_stride = 0;
+    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT), (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
     const int tag = C::TAPS == 1 ? 10 + C::NSEG : C::ROWS;   // 8/4/2: 3x3x3 tile rows, 18/14: 1x1x1
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
+    if (ksplit > 1) {
+        const int64_t total = slab;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s, rp);
+    }
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
@@ -244,7 +297,7 @@ static int64_t num_workgroups(int Cout, int T, int H, int W) {
 }
 
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
-                  int kt, int kh, int kw, int tile_cfg, hipStream_t s) {
+                  int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats) {
     SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
     const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1);
     SS_CHECK_ARG(k3 || k1, "conv3d: kernel %dx%dx%d unsupported (3x3x3 or 1x1x1)", kt, kh, kw);
@@ -269,14 +322,14 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K3Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
             else cfg = 3;
         }
-        if (cfg == 1) return launch_cfg<K3Big>(p, s);
-        if (cfg == 2) return launch_cfg<K3Med>(p, s);
-        return launch_cfg<K3Small>(p, s);
+        if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
+        if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats);
+        return launch_cfg<K3Small>(p, s, scratch, scratch_floats);
     }
     int cfg = tile_cfg;
     if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) ? 1 : 2;
-    if (cfg == 1) return launch_cfg<K1Big>(p, s);
-    return launch_cfg<K1Small>(p, s);
+    if (cfg == 1) return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
+    return launch_cfg<K1Small>(p, s, scratch, scratch_floats);
 }
 
 }  // namespace stemseg
@@ -293,8 +346,9 @@ extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32
 }
 
 extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
-                                  int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, void* stream) {
+                                  int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
+                                  int64_t splitk_scratch_floats, void* stream) {
     using namespace stemseg;
     SS_CHECK_ARG(in && out, "conv3d: null volume");
-    return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream));
+    return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream), splitk_scratch, splitk_scratch_floats);
 }

@@ -58,7 +58,7 @@ SIGNATURES = {
     "stemseg_hip_profile_read": (C.c_int, [C.POINTER(C.c_double), _I32]),
     "stemseg_hip_padded_geometry": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64)]),
     "stemseg_hip_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
-    "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P]),
+    "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, _P]),
     "stemseg_hip_groupnorm_stats": (C.c_int, [_P, _I32, _I64, _I32, _F, _P, _P, _P]),
     "stemseg_hip_gn_relu_pool": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, C.POINTER(Volume), _P]),
     "stemseg_hip_upsample_trilinear": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(Volume), _P]),
@@ -185,8 +185,10 @@ def pack_conv_weight(w):
     return out
 
 
-def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0):
-    check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), k, k, k, tile_cfg, stream()))
+def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None):
+    n = 0 if splitk_scratch is None else splitk_scratch.numel()
+    check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), k, k, k, tile_cfg,
+                                   ptr(splitk_scratch), n, stream()))
 
 
 def groupnorm_stats(x, groups, eps=1e-5):

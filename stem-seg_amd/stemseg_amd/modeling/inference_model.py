@@ -98,6 +98,7 @@ class InferenceModel(nn.Module):
         self.outputs_on_cpu = outputs_on_cpu
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
+        self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
         self.eval()
 
     has_semseg_head = property(lambda self: False)
@@ -127,7 +128,14 @@ class InferenceModel(nn.Module):
         eh = m.embedding_head
         eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
         seed = None
-        if eh.seediness_channels == 0:
+        eh.concurrency = 1 if self.overlap_decoders else 0
+        if eh.seediness_channels == 0 and not self.overlap_decoders:
+            m.seediness_head.concurrency = 0
+            seed = m.seediness_head.forward_single(feats, 2)
+            if self.resize_scale != 1.0:
+                seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+            main = None
+        elif eh.seediness_channels == 0:
             # the seediness decoder shares nothing with the embedding decoder but its (read-only) inputs: run it on a
             # side stream (its own branch-stream set) so the two decoders fill the chip together
             assert m.seediness_head is not None
@@ -144,7 +152,7 @@ class InferenceModel(nn.Module):
         emb, bw = out[:E], out[E:E + Ev]
         if seed is None:
             seed = out[E + Ev:]
-        else:
+        elif main is not None:
             main.wait_stream(side)
             seed.record_stream(main)
         return emb, bw, seed

@@ -64,6 +64,16 @@ def test_conv3d_k3(hip, cfg, shape):
     hip.conv3d(hip.padded_halo_view(buf, g, Cin, T, H, W), hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(out), 3, cfg)
     torch.cuda.synchronize()
     assert report("conv3d_k3 cfg%d %s" % (cfg, shape), out.cpu().numpy(), ref) <= 2e-4
+    # split-K path (input channels spread over up to 16 workgroups per tile, fixed-order reduction): same result, and
+    # run-to-run deterministic
+    scratch = torch.full((16 * Cout * T * H * W,), float("nan"), device="cuda")
+    outs = []
+    for _ in range(2):
+        o = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        hip.conv3d(hip.padded_halo_view(buf, g, Cin, T, H, W), hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(o), 3, cfg, scratch)
+        outs.append(o.cpu().numpy())
+    assert report("conv3d_k3 split-K cfg%d %s" % (cfg, shape), outs[0], ref) <= 2e-4
+    assert np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2])
