@@ -88,9 +88,18 @@ int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32_t Cout, in
  * splitk_scratch (may be NULL): device scratch of splitk_scratch_floats floats; when a layer yields too few
  * workgroups to fill the chip the input channels are split over up to 16 workgroups per tile, partial sums go to the
  * scratch (k * Cout*T*H*W floats) and a second kernel reduces them in fixed order (+ bias) into `out`. */
+typedef struct StemsegConvEpilogue {
+    int32_t      relu;             /* max(v, 0) last                                                                     */
+    const float* residual;         /* NULL or a tensor added before the ReLU, addressed at the OUTPUT's (c,t,y,x) with: */
+    int64_t      res_c_stride, res_t_stride, res_y_stride;
+    int32_t      decode_H, decode_W; /* > 0: the 1x1x1 conv runs on a flat [C][V] input (in->T = in->H = 1, in->W = V) and
+                                        voxel v is stored at (t,y,x) = (v/(H*W), (v/W)%H, v%W) of `out` (e.g. dense -> haloed) */
+} StemsegConvEpilogue;
+/* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).
+ * epilogue may be NULL (plain conv + bias). */
 int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
                        int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
-                       int64_t splitk_scratch_floats, void* stream);
+                       int64_t splitk_scratch_floats, const StemsegConvEpilogue* epilogue, void* stream);
 
 /* GroupNorm statistics over a dense [C][S] tensor (S = T*H*W), `groups` contiguous channel groups:
  * stats[2g] = mean, stats[2g+1] = 1/sqrt(biased_var + eps).  scratch: >= groups*128 doubles. */
@@ -168,6 +177,38 @@ int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc, void* wor
 int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* weights,
                                 const float* const feats[4], float* out,
                                 void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2-D encoder: ResNet-50/101 + FPN over the T frames of a clip (backbone/resnet.py:105-113, fpn.py:47-69,
+ * model_builder.py:154-169).  FrozenBatchNorm (make_layers.py:51-63) is folded into conv weight / bias by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+#define STEMSEG_MAX_ENCODER_BLOCKS 40
+
+typedef struct StemsegEncoderDesc {
+    int32_t struct_bytes;        /* = sizeof(StemsegEncoderDesc)                                        */
+    int32_t blocks[4];           /* bottleneck blocks per stage: R-50 {3,4,6,3}, R-101 {3,4,23,3}       */
+    int32_t T, H, W;             /* frames per call and padded frame size (multiples of 32)              */
+    int32_t out_channels;        /* 256                                                                  */
+} StemsegEncoderDesc;
+
+typedef struct StemsegEncoderWeights {
+    const float* stem_w;         /* [147][64] tap-major ((c*7+dy)*7+dx), BN folded */
+    const float* stem_b;         /* [64] */
+    /* per bottleneck block, in network order; conv weights in the packed layout of stemseg_hip_pack_conv_weight */
+    const float* conv1_w[STEMSEG_MAX_ENCODER_BLOCKS];   const float* conv1_b[STEMSEG_MAX_ENCODER_BLOCKS];
+    const float* conv2_w[STEMSEG_MAX_ENCODER_BLOCKS];   const float* conv2_b[STEMSEG_MAX_ENCODER_BLOCKS];
+    const float* conv3_w[STEMSEG_MAX_ENCODER_BLOCKS];   const float* conv3_b[STEMSEG_MAX_ENCODER_BLOCKS];
+    const float* down_w[STEMSEG_MAX_ENCODER_BLOCKS];    const float* down_b[STEMSEG_MAX_ENCODER_BLOCKS];   /* first block of a stage only */
+    const float* fpn_inner_w[4]; const float* fpn_inner_b[4];     /* fpn_inner1..4 (levels 4x, 8x, 16x, 32x) */
+    const float* fpn_layer_w[4]; const float* fpn_layer_b[4];
+} StemsegEncoderWeights;
+
+size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* desc);
+int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
+/* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[0..3]: the four FPN maps (4x, 8x, 16x, 32x) as volumes
+ * [256][T][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed inputs (then no copy is needed). */
+int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEncoderWeights* weights, const float* frames,
+                                const StemsegVolume out[4], void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Clustering side.

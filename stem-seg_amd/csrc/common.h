@@ -75,8 +75,15 @@ void* profile_begin(int tag, double work, hipStream_t s);   // returns NULL when
 void profile_end(void* handle, hipStream_t s);
 
 // ---- internal kernel launchers shared between api.hip and decoder.hip -------------------------
+struct ConvEpilogue {            // fused into the conv epilogue (or the split-K reduce): v = acc + bias (+ res) ; relu
+    int relu = 0;
+    const float* res = nullptr;  // residual, addressed with (res_cs, res_ts, res_ys) at the output's (c, t, y, x)
+    int64_t res_cs = 0, res_ts = 0, res_ys = 0;
+    int dec_H = 0, dec_W = 0;    // > 0: 1x1x1 conv launched on a flat [C][V] input; voxel v -> (v / (H*W), (v / W) % H, v % W)
+};
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
-                  int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0);
+                  int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0,
+                  const ConvEpilogue* epi = nullptr);
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s);
 int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
                         const float* beta, int pool, const StemsegVolume& out, hipStream_t s);

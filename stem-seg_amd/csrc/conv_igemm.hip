@@ -38,6 +38,11 @@ struct ConvKParams {
     int vec4;
     int chunks_per_split;        // split-K: blockIdx.z handles channel chunks [z*cps, (z+1)*cps)
     int64_t out_split_stride;    // floats between the partial-sum slabs of consecutive splits
+    // fused epilogue (encoder): + residual, ReLU; optional decode of a flat voxel index into (t, y, x)
+    int relu;
+    const float* res;
+    int64_t res_cs, res_ts, res_ys;
+    int dec_H, dec_W;
 };
 
 template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_>
@@ -195,15 +200,27 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         const int y = y0 + s / C::COLS;
         const int x = x0 + (s % C::COLS) * 32 + l31;
         if (y < p.H && x < p.W) {
-            float* o = p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+            int64_t off, roff = 0;
+            if (p.dec_W > 0) {      // flat [C][V] launch: x is the voxel index, decode it for the destination layout
+                const int hw = p.dec_H * p.dec_W;
+                const int t2 = x / hw, r2 = x - t2 * hw, y2 = r2 / p.dec_W, x2 = r2 - y2 * p.dec_W;
+                off = (int64_t)t2 * p.out_ts + (int64_t)y2 * p.out_ys + x2;
+                roff = (int64_t)t2 * p.res_ts + (int64_t)y2 * p.res_ys + x2;
+            } else {
+                off = (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+                roff = (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x;
+            }
+            float* o = p.out + (int64_t)blockIdx.z * p.out_split_stride + off;
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co_base + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (co < p.Cout) {
-                        const float bv = p.bias ? p.bias[co] : 0.f;
-                        o[(int64_t)co * p.out_cs] = acc[mi][ni][r] + bv;
+                        float v = acc[mi][ni][r] + (p.bias ? p.bias[co] : 0.f);
+                        if (p.res) v += p.res[(int64_t)co * p.res_cs + roff];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        o[(int64_t)co * p.out_cs] = v;
                     }
                 }
             }
@@ -211,25 +228,29 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     }
 }
 
-// split-K epilogue: out[c,t,y,x] = bias[c] + sum_z partial[z][c][t][y][x]   (fixed order -> deterministic)
+// split-K epilogue: out[c,t,y,x] = act(bias[c] + res + sum_z partial[z][c][v])   (fixed order -> deterministic)
 struct SplitReduceParams {
     const float* partial;
     const float* bias;
+    const float* res;
     float* out;
-    int64_t out_cs, out_ts, out_ys, slab;
-    int C, T, H, W, ksplit;
+    int64_t out_cs, out_ts, out_ys, res_cs, res_ts, res_ys, slab;
+    int C, H, W, ksplit, relu;     // (H, W): how to split the flat voxel index into (t, y, x)
+    int64_t V;
 };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReduceParams p) {
-    const int64_t HW = (int64_t)p.H * p.W, per_c = (int64_t)p.T * HW, total = per_c * p.C;
+    const int64_t HW = (int64_t)p.H * p.W, total = p.V * p.C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i / per_c);
-        int64_t r = i - (int64_t)c * per_c;
+        const int c = (int)(i / p.V);
+        int64_t r = i - (int64_t)c * p.V;
         const int t = (int)(r / HW);
         r -= (int64_t)t * HW;
         const int y = (int)(r / p.W), x = (int)(r - (int64_t)y * p.W);
         float acc = p.partial[i];
         for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
         if (p.bias) acc += p.bias[c];
+        if (p.res) acc += p.res[(int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x];
+        if (p.relu) acc = fmaxf(acc, 0.f);
         p.out[(int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x] = acc;
     }
 }
@@ -256,6 +277,12 @@ using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1>;   // 128 co x (4 rows x 32 col
 using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1>; // 128 co x (2 rows x 32 cols)
 using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8>;  // 128 co x 256 voxels
 using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4>; // 128 co x 128 voxels
+using K1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8>;  //  64 co x 256 voxels
+// 2-D convolutions of the encoder: the frames of a clip are the T axis, KT = 1
+using K2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
+using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1>;   // 128 co x (4 rows x 32 cols)
+using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1>; // 128 co x (2 rows x 32 cols)
+using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1>;   //  64 co x (8 rows x 32 cols)
 
 template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats) {
@@ -271,15 +298,18 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     ksplit = (int)ceil_div(nchunks, p.chunks_per_split);
     SplitReduceParams rp;
     if (ksplit > 1) {
-        rp.partial = scratch; rp.bias = p.bias; rp.out = p.out; rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys;
-        rp.slab = slab; rp.C = p.Cout; rp.T = p.T; rp.H = p.H; rp.W = p.W; rp.ksplit = ksplit;
-        p.out = scratch; p.bias = nullptr;
+        rp.partial = scratch; rp.bias = p.bias; rp.res = p.res; rp.out = p.out;
+        rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys; rp.res_cs = p.res_cs; rp.res_ts = p.res_ts; rp.res_ys = p.res_ys;
+        rp.slab = slab; rp.C = p.Cout; rp.V = (int64_t)p.T * p.H * p.W; rp.ksplit = ksplit; rp.relu = p.relu;
+        rp.H = p.dec_W > 0 ? p.dec_H : p.H; rp.W = p.dec_W > 0 ? p.dec_W : p.W;
+        // partial slabs are dense in the launch's own tile coordinates; the whole epilogue moves to the reduce kernel
+        p.out = scratch; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.dec_H = p.dec_W = 0;
         p.out_cs = (int64_t)p.T * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
         p.out_split_stride = slab;
     } else p.out_split_stride = 0;
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT), (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
-    const int tag = C::TAPS == 1 ? 10 + C::NSEG : C::ROWS;   // 8/4/2: 3x3x3 tile rows, 18/14: 1x1x1
+    const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + C::ROWS : C::ROWS);   // 8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
     if (ksplit > 1) {
@@ -297,18 +327,29 @@ static int64_t num_workgroups(int Cout, int T, int H, int W) {
 }
 
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
-                  int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats) {
+                  int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats, const ConvEpilogue* epi) {
     SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
-    const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1);
-    SS_CHECK_ARG(k3 || k1, "conv3d: kernel %dx%dx%d unsupported (3x3x3 or 1x1x1)", kt, kh, kw);
-    SS_CHECK_ARG(in.T == out.T + kt - 1 && in.H == out.H + kh - 1 && in.W == out.W + kw - 1,
-                 "conv3d: input extents (%d,%d,%d) must be output (%d,%d,%d) + kernel - 1", in.T, in.H, in.W, out.T, out.H, out.W);
+    const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1), k2 = (kt == 1 && kh == 3 && kw == 3);
+    SS_CHECK_ARG(k3 || k1 || k2, "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3 or 1x1x1)", kt, kh, kw);
+    const bool flat = epi && epi->dec_W > 0;
+    if (flat) {
+        SS_CHECK_ARG(k1 && in.T == 1 && in.H == 1 && epi->dec_H > 0 && (int64_t)out.T * out.H * out.W == in.W &&
+                     out.H == epi->dec_H && out.W == epi->dec_W, "conv3d: flat-decode epilogue needs a 1x1x1 conv on a [C][V] input with V == T*H*W of `out`");
+    } else {
+        SS_CHECK_ARG(in.T == out.T + kt - 1 && in.H == out.H + kh - 1 && in.W == out.W + kw - 1,
+                     "conv3d: input extents (%d,%d,%d) must be output (%d,%d,%d) + kernel - 1", in.T, in.H, in.W, out.T, out.H, out.W);
+    }
     SS_CHECK_ARG(in.C % 4 == 0 && out.C % 32 == 0, "conv3d: Cin %% 4 == 0 and Cout %% 32 == 0 required (got %d, %d)", in.C, out.C);
     ConvKParams p;
     p.in = in.ptr; p.in_cs = in.c_stride; p.in_ts = in.t_stride; p.in_ys = in.y_stride; p.in_limit = in.limit; p.in_H = in.H;
     p.wpk = packed_w; p.bias = bias;
     p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
     p.Cin = in.C; p.Cout = out.C; p.T = out.T; p.H = out.H; p.W = out.W;
+    if (flat) { p.T = 1; p.H = 1; p.W = in.W; }
+    p.relu = epi ? epi->relu : 0;
+    p.res = epi ? epi->res : nullptr;
+    p.res_cs = epi ? epi->res_cs : 0; p.res_ts = epi ? epi->res_ts : 0; p.res_ys = epi ? epi->res_ys : 0;
+    p.dec_H = flat ? epi->dec_H : 0; p.dec_W = flat ? epi->dec_W : 0;
     p.tiles_x = p.tiles_y = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(in.ptr) % 16 == 0) && (in.c_stride % 4 == 0) &&
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
@@ -326,6 +367,19 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats);
         return launch_cfg<K3Small>(p, s, scratch, scratch_floats);
     }
+    if (k2) {
+        if (p.Cout <= 64) return launch_cfg<K2M64>(p, s, scratch, scratch_floats);
+        int cfg = tile_cfg;
+        if (cfg <= 0 || cfg > 3) {
+            if (num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= 512) cfg = 1;
+            else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
+            else cfg = 3;
+        }
+        if (cfg == 1) return launch_cfg<K2Big>(p, s, scratch, scratch_floats);
+        if (cfg == 2) return launch_cfg<K2Med>(p, s, scratch, scratch_floats);
+        return launch_cfg<K2Small>(p, s, scratch, scratch_floats);
+    }
+    if (p.Cout <= 64) return launch_cfg<K1M64>(p, s, scratch, scratch_floats);
     int cfg = tile_cfg;
     if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) ? 1 : 2;
     if (cfg == 1) return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
@@ -347,8 +401,14 @@ extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32
 
 extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
                                   int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
-                                  int64_t splitk_scratch_floats, void* stream) {
+                                  int64_t splitk_scratch_floats, const StemsegConvEpilogue* epilogue, void* stream) {
     using namespace stemseg;
     SS_CHECK_ARG(in && out, "conv3d: null volume");
-    return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream), splitk_scratch, splitk_scratch_floats);
+    ConvEpilogue e;
+    if (epilogue) {
+        e.relu = epilogue->relu; e.res = epilogue->residual; e.res_cs = epilogue->res_c_stride; e.res_ts = epilogue->res_t_stride;
+        e.res_ys = epilogue->res_y_stride; e.dec_H = epilogue->decode_H; e.dec_W = epilogue->decode_W;
+    }
+    return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream), splitk_scratch, splitk_scratch_floats,
+                         epilogue ? &e : nullptr);
 }

@@ -1,0 +1,328 @@
+// 2-D encoder (ResNet-50/101 + FPN) on the same fp32-MFMA implicit-GEMM core as the decoder.
+//
+// Reference: /root/reference/stemseg/modeling/backbone/resnet.py:105-113 (ResNet.forward), :263-282 (Bottleneck,
+// stride in the first 1x1), :292-304 (stem + max-pool), fpn.py:47-69 (FPN.forward), make_layers.py:51-63
+// (FrozenBatchNorm2d, folded into weight/bias by the host once), model_builder.py:154-169 (run_backbone).
+//
+// MI355X-first choices
+//   * a clip's T frames are the T axis of one [C][T][H][W] volume, so every 2-D convolution is the decoder's conv
+//     kernel with KT = 1 and the FPN outputs land directly in the [C][T][h][w] (optionally zero-haloed) layout the 3-D
+//     decoders consume -- no per-frame launches, no torch.stack, no pad copy;
+//   * bias (= folded BN shift), ReLU and the residual add live in the conv epilogue: a bottleneck block is 3 (4 with a
+//     projection shortcut) launches instead of conv + BN + ReLU + add chains;
+//   * 1x1 convs run on the flat [C][V] view (aligned 16-B rows regardless of W); when their consumer is a 3x3 conv the
+//     epilogue decodes the voxel index and writes the interior of a zero-haloed 2-D layout [C][T][h+2][pitch];
+//   * stride-2 1x1 convs (first block of layers 2-4, conv1 and the shortcut) read one shared 2x-subsampled copy;
+//   * layers with few voxels (layer3/4: 12 960 / 3 240 voxels) use the conv kernel's split-K to fill 256 CUs.
+#include "common.h"
+#include <algorithm>
+
+namespace stemseg {
+
+// zero-haloed 2-D layout: [C][T][H+2][pitch], halo only in H and W
+struct Padded2D {
+    int64_t pitch, ts, cs, total, interior;
+    Padded2D() = default;
+    Padded2D(int C, int T, int H, int W) {
+        pitch = round_up((int64_t)W + 2, 4);
+        ts = (int64_t)(H + 2) * pitch;
+        cs = (int64_t)T * ts;
+        total = (int64_t)C * cs + 64;
+        interior = pitch + 1;
+    }
+};
+static inline StemsegVolume halo2d_view(float* base, int C, int T, int H, int W) {
+    Padded2D g(C, T, H, W);
+    return make_volume(base, g.cs, g.ts, g.pitch, C, T, H + 2, W + 2, g.total);
+}
+static inline StemsegVolume interior2d_view(float* base, int C, int T, int H, int W) {
+    Padded2D g(C, T, H, W);
+    return make_volume(base + g.interior, g.cs, g.ts, g.pitch, C, T, H, W, g.total - g.interior);
+}
+static inline StemsegVolume flat_view(float* base, int C, int64_t V) { return make_volume(base, V, 0, 0, C, 1, 1, (int)V, (int64_t)C * V); }
+
+// ---- stem: conv 7x7 stride 2 pad 3 (3 -> 64) + bias + ReLU, direct VALU kernel (1 % of the encoder FLOPs) ----------
+// block = 8 x 64 output pixels of one frame, all 64 channels; thread = 2 pixels (x, x+32) x 64 channels.
+constexpr int ST_ROWS = 8, ST_COLS = 64, ST_PR = 2 * ST_ROWS + 5, ST_PC = 2 * ST_COLS + 5, ST_PCP = 136;
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ frames, const float* __restrict__ w_tap_major,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int T, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * ST_PR * ST_PCP + 147 * 64];
+    float* patch = lds;
+    float* wl = lds + 3 * ST_PR * ST_PCP;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = (Wo + ST_COLS - 1) / ST_COLS, tiles_y = (Ho + ST_ROWS - 1) / ST_ROWS;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int t = b / tiles_y;
+    const int oy0 = ty * ST_ROWS, ox0 = tx * ST_COLS;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    for (int i = threadIdx.x; i < 147 * 64; i += 256) wl[i] = w_tap_major[i];
+    for (int i = threadIdx.x; i < 3 * ST_PR * ST_PC; i += 256) {
+        const int xx = i % ST_PC;
+        int r = i / ST_PC;
+        const int yy = r % ST_PR, c = r / ST_PR;
+        const int iy = iy0 + yy, ix = ix0 + xx;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = frames[(((int64_t)t * 3 + c) * H + iy) * W + ix];
+        patch[(c * ST_PR + yy) * ST_PCP + xx] = v;
+    }
+    __syncthreads();
+    const int py = threadIdx.x >> 5, px = threadIdx.x & 31;    // pixels (py, px) and (py, px + 32)
+    float acc0[64], acc1[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+    for (int c = 0; c < 3; ++c)
+        for (int dy = 0; dy < 7; ++dy) {
+            const float* prow = patch + (c * ST_PR + 2 * py + dy) * ST_PCP + 2 * px;
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) {
+                const float v0 = prow[dx], v1 = prow[dx + 64];
+                const float4* w4 = reinterpret_cast<const float4*>(wl + ((c * 7 + dy) * 7 + dx) * 64);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 wv = w4[k];      // broadcast LDS read
+                    acc0[4 * k + 0] = fmaf(wv.x, v0, acc0[4 * k + 0]); acc1[4 * k + 0] = fmaf(wv.x, v1, acc1[4 * k + 0]);
+                    acc0[4 * k + 1] = fmaf(wv.y, v0, acc0[4 * k + 1]); acc1[4 * k + 1] = fmaf(wv.y, v1, acc1[4 * k + 1]);
+                    acc0[4 * k + 2] = fmaf(wv.z, v0, acc0[4 * k + 2]); acc1[4 * k + 2] = fmaf(wv.z, v1, acc1[4 * k + 2]);
+                    acc0[4 * k + 3] = fmaf(wv.w, v0, acc0[4 * k + 3]); acc1[4 * k + 3] = fmaf(wv.w, v1, acc1[4 * k + 3]);
+                }
+            }
+        }
+    const int oy = oy0 + py;
+    if (oy < Ho) {
+        const int64_t plane = (int64_t)Ho * Wo;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            float* o = out + ((int64_t)k * T + t) * plane + (int64_t)oy * Wo;
+            const float bv = bias[k];
+            if (ox0 + px < Wo) o[ox0 + px] = fmaxf(acc0[k] + bv, 0.f);
+            if (ox0 + px + 32 < Wo) o[ox0 + px + 32] = fmaxf(acc1[k] + bv, 0.f);
+        }
+    }
+}
+
+// max-pool 3x3 stride 2 pad 1 over every [c][t] plane (resnet.py:303)
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = planes * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int y = (int)(r % Ho);
+        const int64_t pl = r / Ho;
+        const float* p = in + pl * H * W;
+        float m = -INFINITY;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * y + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * x + dx;
+                if (xx < 0 || xx >= W) continue;
+                m = fmaxf(m, p[(int64_t)yy * W + xx]);
+            }
+        }
+        out[i] = m;
+    }
+}
+
+// out[pl][y][x] = in[pl][2y][2x]   (shared input of a stride-2 block's conv1 and projection shortcut)
+__global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = planes * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        int64_t r = i / Wo;
+        const int y = (int)(r % Ho);
+        const int64_t pl = r / Ho;
+        out[i] = in[pl * H * W + (int64_t)(2 * y) * W + 2 * x];
+    }
+}
+
+// FPN top-down path (fpn.py:64-66): fine += bilinear_x2(coarse), both zero-haloed 2-D layouts, align_corners = False
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int64_t planes, int H, int W,
+                                                              int64_t f_ts, int64_t f_pitch, int64_t c_ts, int64_t c_pitch) {
+    const int Hc = H / 2, Wc = W / 2;
+    const int64_t total = planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        int64_t r = i / W;
+        const int y = (int)(r % H);
+        const int64_t pl = r / H;
+        float sy = 0.5f * ((float)y + 0.5f) - 0.5f, sx = 0.5f * ((float)x + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < Hc - 1 ? 1 : 0), x1 = x0 + (x0 < Wc - 1 ? 1 : 0);
+        const float wy = sy - (float)y0, wx = sx - (float)x0;
+        const float* c = coarse + pl * c_ts;
+        const float v = (1.f - wy) * ((1.f - wx) * c[y0 * c_pitch + x0] + wx * c[y0 * c_pitch + x1]) +
+                        wy * ((1.f - wx) * c[y1 * c_pitch + x0] + wx * c[y1 * c_pitch + x1]);
+        fine[pl * f_ts + (int64_t)y * f_pitch + x] += v;
+    }
+}
+
+static int grid1d(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 256 * 16)); }
+
+struct EncoderPlan {
+    int T, H, W, nblk[4], total_blocks;
+    int h[4], w[4];            // 4x, 8x, 16x, 32x
+    int64_t V[4];
+    int64_t S0, X1, A, B, Cst[4], M1, M2, DS, XS, L[4], SK, SKfloats, total;
+};
+
+static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
+    SS_CHECK_ARG(d, "encoder: null descriptor");
+    SS_CHECK_ARG(d->struct_bytes == (int32_t)sizeof(StemsegEncoderDesc), "encoder: descriptor size mismatch (%d vs %d): ABI skew",
+                 d->struct_bytes, (int)sizeof(StemsegEncoderDesc));
+    SS_CHECK_ARG(d->T >= 1 && d->H >= 32 && d->W >= 32 && d->H % 32 == 0 && d->W % 32 == 0, "encoder: T=%d H=%d W=%d (H, W multiples of 32)", d->T, d->H, d->W);
+    p.T = d->T; p.H = d->H; p.W = d->W;
+    p.total_blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        SS_CHECK_ARG(d->blocks[i] >= 1 && d->blocks[i] <= 64, "encoder: blocks[%d]=%d", i, d->blocks[i]);
+        p.nblk[i] = d->blocks[i];
+        p.total_blocks += d->blocks[i];
+        p.h[i] = d->H >> (2 + i); p.w[i] = d->W >> (2 + i);
+        p.V[i] = (int64_t)d->T * p.h[i] * p.w[i];
+    }
+    SS_CHECK_ARG(p.total_blocks <= STEMSEG_MAX_ENCODER_BLOCKS, "encoder: more than %d bottleneck blocks", STEMSEG_MAX_ENCODER_BLOCKS);
+    int64_t off = 0;
+    auto take = [&](int64_t floats) { int64_t o = off; off += round_up(floats, 64); return o; };
+    p.S0 = take(64 * 4 * p.V[0]);
+    p.X1 = take(64 * p.V[0]);
+    p.A = take(256 * p.V[0]);
+    p.B = take(256 * p.V[0]);
+    int64_t m1 = 0;
+    for (int i = 0; i < 4; ++i) {
+        p.Cst[i] = take((int64_t)(256 << i) * p.V[i]);
+        m1 = std::max(m1, Padded2D(64 << i, p.T, p.h[i], p.w[i]).total);
+    }
+    p.M1 = take(m1);
+    p.M2 = take(64 * p.V[0]);
+    p.DS = take(256 * p.V[0]);
+    p.XS = take(256 * p.V[1]);
+    for (int i = 0; i < 4; ++i) p.L[i] = take(Padded2D(256, p.T, p.h[i], p.w[i]).total);
+    p.SKfloats = 32ll << 20;
+    p.SK = take(p.SKfloats);
+    p.total = off;
+    return STEMSEG_OK;
+}
+
+}  // namespace stemseg
+
+using namespace stemseg;
+
+extern "C" size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* desc) {
+    EncoderPlan p;
+    if (make_encoder_plan(desc, p) != STEMSEG_OK) return 0;
+    return (size_t)p.total * sizeof(float);
+}
+
+extern "C" int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream) {
+    EncoderPlan p;
+    int rc = make_encoder_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(workspace) % 256 == 0), "encoder: workspace must be 256-byte aligned");
+    if (ws_bytes < (size_t)p.total * sizeof(float)) {
+        set_error("encoder: workspace too small (%zu < %zu bytes)", ws_bytes, (size_t)p.total * sizeof(float));
+        return STEMSEG_E_WORKSPACE;
+    }
+    // only the zero-haloed buffers need it, but one memset keeps the rule simple
+    SS_HIP(hipMemsetAsync(workspace, 0, (size_t)p.total * sizeof(float), as_stream(stream)));
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEncoderWeights* wts, const float* frames,
+                                           const StemsegVolume out[4], void* workspace, size_t ws_bytes, void* stream) {
+    EncoderPlan p;
+    int rc = make_encoder_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(wts && frames && out && workspace, "encoder_forward: null pointer");
+    if (ws_bytes < (size_t)p.total * sizeof(float)) {
+        set_error("encoder: workspace too small (%zu < %zu bytes)", ws_bytes, (size_t)p.total * sizeof(float));
+        return STEMSEG_E_WORKSPACE;
+    }
+    SS_CHECK_ARG(wts->stem_w && wts->stem_b, "encoder_forward: null stem weights");
+    for (int i = 0; i < 4; ++i) {
+        SS_CHECK_ARG(out[i].ptr && out[i].C == desc->out_channels && out[i].T == p.T && out[i].H == p.h[i] && out[i].W == p.w[i],
+                     "encoder_forward: output volume %d must be [%d][%d][%d][%d]", i, desc->out_channels, p.T, p.h[i], p.w[i]);
+        SS_CHECK_ARG(wts->fpn_inner_w[i] && wts->fpn_inner_b[i] && wts->fpn_layer_w[i] && wts->fpn_layer_b[i], "encoder_forward: null FPN weights %d", i);
+    }
+    SS_CHECK_ARG(desc->out_channels == 256, "encoder: out_channels must be 256");
+    hipStream_t s = as_stream(stream);
+    float* ws = reinterpret_cast<float*>(workspace);
+    const int T = p.T;
+
+    // stem (resnet.py:292-304)
+    {
+        const int Ho = p.H / 2, Wo = p.W / 2;
+        const int blocks = (int)(ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T);
+        hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        SS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid1d(64 * p.V[0])), dim3(256), 0, s, (const float*)(ws + p.S0), ws + p.X1, (int64_t)64 * T, Ho, Wo);
+        SS_LAUNCH_CHECK();
+    }
+    // residual stages (resnet.py:105-113)
+    float* x = ws + p.X1;
+    int cin = 64, bi = 0;
+    for (int st = 0; st < 4; ++st) {
+        const int mid = 64 << st, cout = 256 << st, h = p.h[st], w = p.w[st];
+        const int64_t V = p.V[st];
+        for (int b = 0; b < p.nblk[st]; ++b, ++bi) {
+            const bool first = (b == 0), stride2 = first && st > 0;
+            SS_CHECK_ARG(wts->conv1_w[bi] && wts->conv1_b[bi] && wts->conv2_w[bi] && wts->conv2_b[bi] && wts->conv3_w[bi] && wts->conv3_b[bi],
+                         "encoder_forward: null weights for block %d", bi);
+            SS_CHECK_ARG(!first || (wts->down_w[bi] && wts->down_b[bi]), "encoder_forward: block %d needs a projection shortcut", bi);
+            float* xin = x;
+            if (stride2) {
+                hipLaunchKernelGGL(subsample2_kernel, dim3(grid1d((int64_t)cin * V)), dim3(256), 0, s, (const float*)x, ws + p.XS, (int64_t)cin * T, 2 * h, 2 * w);
+                SS_LAUNCH_CHECK();
+                xin = ws + p.XS;
+            }
+            float* y = (b == p.nblk[st] - 1) ? ws + p.Cst[st] : ((b & 1) ? ws + p.B : ws + p.A);
+            ConvEpilogue e1;                    // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
+            e1.relu = 1; e1.dec_H = h; e1.dec_W = w;
+            rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1, mid, T, h, w), 1, 1, 1, 0, s,
+                               ws + p.SK, p.SKfloats, &e1);
+            if (rc) return rc;
+            ConvEpilogue e2;                    // conv2 (3x3) + bn2 + relu -> dense
+            e2.relu = 1;
+            rc = launch_conv3d(halo2d_view(ws + p.M1, mid, T, h, w), wts->conv2_w[bi], wts->conv2_b[bi], dense_volume(ws + p.M2, mid, T, h, w), 1, 3, 3, 0, s,
+                               ws + p.SK, p.SKfloats, &e2);
+            if (rc) return rc;
+            const float* idt = xin;
+            if (first) {                        // projection shortcut: 1x1 (stride folded into xin) + bn
+                rc = launch_conv3d(flat_view(xin, cin, V), wts->down_w[bi], wts->down_b[bi], flat_view(ws + p.DS, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats,
+                                   nullptr);
+                if (rc) return rc;
+                idt = ws + p.DS;
+            }
+            ConvEpilogue e3;                    // conv3 + bn3 + identity + relu
+            e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0;
+            rc = launch_conv3d(flat_view(ws + p.M2, mid, V), wts->conv3_w[bi], wts->conv3_b[bi], flat_view(y, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats, &e3);
+            if (rc) return rc;
+            x = y;
+            cin = cout;
+        }
+    }
+    // FPN (fpn.py:47-69), coarsest level first
+    for (int k = 3; k >= 0; --k) {
+        const int h = p.h[k], w = p.w[k];
+        ConvEpilogue e;
+        e.dec_H = h; e.dec_W = w;
+        rc = launch_conv3d(flat_view(ws + p.Cst[k], 256 << k, p.V[k]), wts->fpn_inner_w[k], wts->fpn_inner_b[k], interior2d_view(ws + p.L[k], 256, T, h, w), 1, 1, 1, 0, s,
+                           ws + p.SK, p.SKfloats, &e);
+        if (rc) return rc;
+        if (k < 3) {
+            Padded2D gf(256, T, h, w), gc(256, T, p.h[k + 1], p.w[k + 1]);
+            hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid1d(256 * p.V[k])), dim3(256), 0, s, ws + p.L[k] + gf.interior,
+                               (const float*)(ws + p.L[k + 1] + gc.interior), (int64_t)256 * T, h, w, gf.ts, gf.pitch, gc.ts, gc.pitch);
+            SS_LAUNCH_CHECK();
+        }
+        rc = launch_conv3d(halo2d_view(ws + p.L[k], 256, T, h, w), wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, nullptr);
+        if (rc) return rc;
+    }
+    return STEMSEG_OK;
+}

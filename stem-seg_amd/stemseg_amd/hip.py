@@ -37,6 +37,29 @@ class DecoderWeights(C.Structure):
                 ("grid_t", C.c_void_p), ("grid_y", C.c_void_p), ("grid_x", C.c_void_p)]
 
 
+MAX_ENCODER_BLOCKS = 40
+
+
+class ConvEpilogue(C.Structure):
+    _fields_ = [("relu", C.c_int32), ("residual", C.c_void_p), ("res_c_stride", C.c_int64), ("res_t_stride", C.c_int64),
+                ("res_y_stride", C.c_int64), ("decode_H", C.c_int32), ("decode_W", C.c_int32)]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("blocks", C.c_int32 * 4), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("out_channels", C.c_int32)]
+
+
+_BLK = C.c_void_p * MAX_ENCODER_BLOCKS
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [("stem_w", C.c_void_p), ("stem_b", C.c_void_p),
+                ("conv1_w", _BLK), ("conv1_b", _BLK), ("conv2_w", _BLK), ("conv2_b", _BLK), ("conv3_w", _BLK), ("conv3_b", _BLK),
+                ("down_w", _BLK), ("down_b", _BLK),
+                ("fpn_inner_w", C.c_void_p * 4), ("fpn_inner_b", C.c_void_p * 4), ("fpn_layer_w", C.c_void_p * 4), ("fpn_layer_b", C.c_void_p * 4)]
+
+
 class ClusterParams(C.Structure):
     _fields_ = [("primary_prob_thresh", C.c_float), ("secondary_prob_thresh", C.c_float), ("min_seediness_prob", C.c_float),
                 ("max_instances", C.c_int32), ("n_free_dims", C.c_int32), ("free_dim_bandwidths", C.c_float * MAX_EMB_DIMS)]
@@ -58,7 +81,10 @@ SIGNATURES = {
     "stemseg_hip_profile_read": (C.c_int, [C.POINTER(C.c_double), _I32]),
     "stemseg_hip_padded_geometry": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64)]),
     "stemseg_hip_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
-    "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, _P]),
+    "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
+    "stemseg_hip_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
+    "stemseg_hip_encoder_init_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, _P]),
+    "stemseg_hip_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), _P, C.POINTER(Volume * 4), _P, C.c_size_t, _P]),
     "stemseg_hip_groupnorm_stats": (C.c_int, [_P, _I32, _I64, _I32, _F, _P, _P, _P]),
     "stemseg_hip_gn_relu_pool": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, C.POINTER(Volume), _P]),
     "stemseg_hip_upsample_trilinear": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(Volume), _P]),
@@ -185,10 +211,21 @@ def pack_conv_weight(w):
     return out
 
 
-def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None):
+def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None, epilogue=None):
+    """k: int (k x k x k) or a (kt, kh, kw) tuple; epilogue: dict(relu=, residual=tensor, res_strides=(c,t,y), decode=(H,W))."""
     n = 0 if splitk_scratch is None else splitk_scratch.numel()
-    check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), k, k, k, tile_cfg,
-                                   ptr(splitk_scratch), n, stream()))
+    kt, kh, kw = (k, k, k) if isinstance(k, int) else k
+    e = None
+    if epilogue is not None:
+        e = ConvEpilogue()
+        e.relu = int(epilogue.get("relu", 0))
+        r = epilogue.get("residual")
+        if r is not None:
+            e.residual = r.data_ptr()
+            e.res_c_stride, e.res_t_stride, e.res_y_stride = epilogue["res_strides"]
+        e.decode_H, e.decode_W = epilogue.get("decode", (0, 0))
+    check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), kt, kh, kw, tile_cfg,
+                                   ptr(splitk_scratch), n, C.byref(e) if e is not None else None, stream()))
 
 
 def groupnorm_stats(x, groups, eps=1e-5):

@@ -1,30 +1,30 @@
-"""2-D encoder: ResNet-50/101 (FrozenBN, stride in the first 1x1) + FPN, batched over the clip's frames.
+"""2-D encoder: ResNet-50/101 (FrozenBN, stride in the first 1x1) + FPN on the HIP implicit-GEMM kernels.
 
 Counterpart of the reference's stemseg/modeling/backbone/* (ResNet resnet.py:49-113, Bottleneck :194-282,
 BaseStem :285-304, FPN fpn.py:8-69, FrozenBatchNorm2d make_layers.py:37-63) and of
 TrainingModel.run_backbone (model_builder.py:154-169).  State-dict keys follow the reference
 (``body.stem.conv1.weight``, ``body.layerL.B.{conv1,bn1,...}``, ``fpn.fpn_{inner,layer}K.{weight,bias}``) so real
-checkpoints load.
+checkpoints load; the ``nn.Conv2d`` / ``FrozenBatchNorm2d`` objects are parameter holders only.
 
-Round-1 status: the convolutions of this stage still run on stock
-PyTorch-ROCm ops (MIOpen); what is already MI355X-specific is the schedule -- all T frames of a clip go through
-as ONE batch (the reference runs eight batch-1 passes, inference_model.py:99-102) and every FrozenBN (eps = 0,
-make_layers.py:43) is folded into its convolution's weight/bias once at load time, so no BN kernels run.
-Replacing these convs with the implicit-GEMM MFMA kernel of csrc/conv_igemm.hip is the next step.
+Execution (``stemseg_hip_encoder_forward``, csrc/encoder.hip): all T frames of a clip form the T axis of one
+[C][T][H][W] volume, every FrozenBN (eps = 0, make_layers.py:43) is folded into its convolution once at load time, and
+bias / ReLU / residual add run in the conv epilogue.  The four FPN maps come out channel-major ([256][T][h][w]) -- or
+are written straight into the decoders' zero-haloed input buffers (``run_backbone_into``).
 """
+import ctypes as C
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from .. import hip
 from ..utils.global_registry import GlobalRegistry
 
 STAGE_BLOCKS = {"R-50-FPN": (3, 4, 6, 3), "R-101-FPN": (3, 4, 23, 3)}
 
 
 class FrozenBatchNorm2d(nn.Module):
-    """Per-channel affine with fixed statistics (make_layers.py:37-63); holds buffers, folded away at run time."""
+    """Per-channel affine with fixed statistics (make_layers.py:37-63); holds buffers, folded away at load time."""
 
     def __init__(self, n, epsilon=0.0):
         super().__init__()
@@ -37,10 +37,6 @@ class FrozenBatchNorm2d(nn.Module):
     def scale_shift(self):
         scale = self.weight * (self.running_var + self.epsilon).rsqrt()
         return scale, self.bias - self.running_mean * scale
-
-    def forward(self, x):
-        s, b = self.scale_shift()
-        return x * s.reshape(1, -1, 1, 1) + b.reshape(1, -1, 1, 1)
 
 
 def _conv(cin, cout, k, stride=1, bias=False):
@@ -94,79 +90,123 @@ class _FPN(nn.Module):
 
 
 class ResNetFPN(nn.Module):
-    """``forward([N,3,H,W]) -> tuple of 4 maps, highest resolution first`` (fpn.py:67-69)."""
+    """``forward([N,3,H,W]) -> tuple of 4 maps [N,256,H/s,W/s], highest resolution first`` (fpn.py:67-69)."""
 
     def __init__(self, backbone_type="R-101-FPN", out_channels=256):
         super().__init__()
         if backbone_type not in STAGE_BLOCKS:
             raise KeyError(backbone_type)       # "X-101-FPN" is registered but has no stage spec (resnet.py:352-355)
-        self.body = _Body(STAGE_BLOCKS[backbone_type])
+        self.stage_blocks = STAGE_BLOCKS[backbone_type]
+        self.body = _Body(self.stage_blocks)
         self.fpn = _FPN(out_channels)
         self.out_channels, self.is_3d = out_channels, False
-        self._folded, self._sig = None, None
-        self.channels_last = True
+        self._packed, self._sig, self._ws = None, None, {}
 
-    # ---- FrozenBN folding: w' = w * s[:,None,None,None], b' = shift  (exact because eps == 0 changes nothing) ----
+    # ---- FrozenBN folding: w' = w * scale[:, None, None, None], b' = shift (exact: eps == 0) -------------------
     def _signature(self):
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     @staticmethod
     def _fold(conv, bn):
         s, b = bn.scale_shift()
-        return (conv.weight * s.reshape(-1, 1, 1, 1)).detach(), b.detach()
+        return (conv.weight * s.reshape(-1, 1, 1, 1)).detach().float(), b.detach().float()
 
-    def _prepare(self):
-        sig = self._signature()
-        if self._sig == sig:
-            return self._folded
-        f = {}
-        mf = torch.channels_last if self.channels_last else torch.contiguous_format
-
-        def put(name, w, b):
-            f[name] = (w.contiguous(memory_format=mf), None if b is None else b.contiguous())
-        put("stem", *self._fold(self.body.stem.conv1, self.body.stem.bn1))
+    def blocks(self):
         for li in (1, 2, 3, 4):
-            for bi, blk in enumerate(getattr(self.body, "layer%d" % li)):
-                p = "l%d.%d." % (li, bi)
-                put(p + "1", *self._fold(blk.conv1, blk.bn1))
-                put(p + "2", *self._fold(blk.conv2, blk.bn2))
-                put(p + "3", *self._fold(blk.conv3, blk.bn3))
-                if blk.downsample is not None:
-                    put(p + "d", *self._fold(blk.downsample[0], blk.downsample[1]))
+            for blk in getattr(self.body, "layer%d" % li):
+                yield blk
+
+    @torch.no_grad()
+    def folded_state(self):
+        """{name: (weight [Cout,Cin,kh,kw], bias [Cout])} with every FrozenBN folded in; plain tensor math, no conv."""
+        f = OrderedDict()
+        f["stem"] = self._fold(self.body.stem.conv1, self.body.stem.bn1)
+        for i, blk in enumerate(self.blocks()):
+            f["b%d.conv1" % i] = self._fold(blk.conv1, blk.bn1)
+            f["b%d.conv2" % i] = self._fold(blk.conv2, blk.bn2)
+            f["b%d.conv3" % i] = self._fold(blk.conv3, blk.bn3)
+            if blk.downsample is not None:
+                f["b%d.down" % i] = self._fold(blk.downsample[0], blk.downsample[1])
         for k in (1, 2, 3, 4):
             for kind in ("inner", "layer"):
                 m = getattr(self.fpn, "fpn_%s%d" % (kind, k))
-                put("fpn_%s%d" % (kind, k), m.weight.detach(), m.bias.detach())
-        self._folded, self._sig = f, sig
+                f["fpn_%s%d" % (kind, k)] = (m.weight.detach().float(), m.bias.detach().float())
         return f
+
+    def _pack(self):
+        sig = self._signature()
+        if self._sig == sig:
+            return self._packed
+        hip.require_gpu()
+        f = self.folded_state()
+        keep = []                           # device tensors referenced by raw pointers below
+        w = hip.EncoderWeights()
+
+        def dev(t):
+            t = t.contiguous().cuda()
+            keep.append(t)
+            return t
+
+        def packed(name):
+            wt, b = f[name]
+            pw, pb = hip.pack_conv_weight(dev(wt)), dev(b)
+            keep.append(pw)
+            return pw.data_ptr(), pb.data_ptr()
+        sw, sb = f["stem"]
+        w.stem_w = dev(sw.reshape(64, 147).t()).data_ptr()
+        w.stem_b = dev(sb).data_ptr()
+        for i, blk in enumerate(self.blocks()):
+            w.conv1_w[i], w.conv1_b[i] = packed("b%d.conv1" % i)
+            w.conv2_w[i], w.conv2_b[i] = packed("b%d.conv2" % i)
+            w.conv3_w[i], w.conv3_b[i] = packed("b%d.conv3" % i)
+            if blk.downsample is not None:
+                w.down_w[i], w.down_b[i] = packed("b%d.down" % i)
+        for k in (1, 2, 3, 4):
+            w.fpn_inner_w[k - 1], w.fpn_inner_b[k - 1] = packed("fpn_inner%d" % k)
+            w.fpn_layer_w[k - 1], w.fpn_layer_b[k - 1] = packed("fpn_layer%d" % k)
+        self._packed, self._sig = (w, keep), sig
+        return self._packed
+
+    def _desc(self, T, H, W):
+        d = hip.EncoderDesc()
+        d.struct_bytes = C.sizeof(hip.EncoderDesc)
+        for i, n in enumerate(self.stage_blocks):
+            d.blocks[i] = n
+        d.T, d.H, d.W, d.out_channels = T, H, W, self.out_channels
+        return d
+
+    @torch.no_grad()
+    def run_backbone_into(self, frames, out_volumes):
+        """frames: float32 [T,3,H,W] on the device; out_volumes: 4 ``hip.Volume`` (4x, 8x, 16x, 32x), each
+        [256][T][H/s][W/s] -- e.g. the interiors of the decoders' zero-haloed inputs."""
+        hip.require_gpu()
+        frames = frames.contiguous().float()
+        T, _, H, W = frames.shape
+        w, _keep = self._pack()
+        d = self._desc(T, H, W)
+        key = (T, H, W, frames.device.index)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = hip.lib().stemseg_hip_encoder_workspace_bytes(C.byref(d))
+            if nbytes == 0:
+                raise RuntimeError("encoder: " + hip.lib().stemseg_hip_last_error().decode())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=frames.device)
+            hip.check(hip.lib().stemseg_hip_encoder_init_workspace(C.byref(d), hip.ptr(ws), nbytes, hip.stream()))
+            self._ws[key] = ws
+        vols = (hip.Volume * 4)(*out_volumes)
+        hip.check(hip.lib().stemseg_hip_encoder_forward(C.byref(d), C.byref(w), hip.ptr(frames), C.byref(vols), hip.ptr(ws), ws.numel(), hip.stream()))
+
+    @torch.no_grad()
+    def forward_channel_major(self, frames):
+        """-> 4 dense tensors [256, T, H/s, W/s] (s = 4, 8, 16, 32)."""
+        T, _, H, W = frames.shape
+        outs = [torch.empty(self.out_channels, T, H // s, W // s, dtype=torch.float32, device=frames.device) for s in (4, 8, 16, 32)]
+        self.run_backbone_into(frames, [hip.dense_volume(o) for o in outs])
+        return outs
 
     @torch.no_grad()
     def forward(self, x):
-        f = self._prepare()
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
-        w, b = f["stem"]
-        x = F.relu_(F.conv2d(x, w, b, stride=2, padding=3))
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        feats = []
-        for li in (1, 2, 3, 4):
-            for bi, blk in enumerate(getattr(self.body, "layer%d" % li)):
-                p = "l%d.%d." % (li, bi)
-                idt = x
-                out = F.relu_(F.conv2d(x, *f[p + "1"], stride=blk.stride))
-                out = F.relu_(F.conv2d(out, *f[p + "2"], padding=1))
-                out = F.conv2d(out, *f[p + "3"])
-                if blk.downsample is not None:
-                    idt = F.conv2d(x, *f[p + "d"], stride=blk.stride)
-                x = F.relu_(out.add_(idt))
-            feats.append(x)
-        last = F.conv2d(feats[3], *f["fpn_inner4"])
-        results = [F.conv2d(last, *f["fpn_layer4"], padding=1)]
-        for k in (3, 2, 1):
-            top = F.interpolate(last, scale_factor=2, mode="bilinear", align_corners=False)
-            last = F.conv2d(feats[k - 1], *f["fpn_inner%d" % k]).add_(top)
-            results.insert(0, F.conv2d(last, *f["fpn_layer%d" % k], padding=1))
-        return tuple(results)
+        return tuple(o.permute(1, 0, 2, 3) for o in self.forward_channel_major(x))
 
     @torch.no_grad()
     def run_backbone(self, frames):

@@ -122,8 +122,27 @@ class InferenceModel(nn.Module):
         pads = self._padded_feature_buffers(T, H, W, dev)
         Cn = m.backbone.out_channels
         for (buf, g), s in zip(pads, (32, 16, 8, 4)):
-            stack = torch.stack([fm[s] for fm in feature_maps], 0)                      # [T,C,h,w]  (layout 1)
-            hip.copy_to_volume(stack.contiguous(), 1, hip.padded_interior_view(buf, g, Cn, T, H // s, W // s))
+            stack = torch.stack([fm[s] for fm in feature_maps], 1)                      # [C,T,h,w]  (layout 0)
+            hip.copy_to_volume(stack.contiguous(), 0, hip.padded_interior_view(buf, g, Cn, T, H // s, W // s))
+        return self._run_heads(pads, T, H, W, dev)
+
+    @torch.no_grad()
+    def embed_frames(self, frames):
+        """Whole clip at once: frames float32 [T,3,H,W] on the device -> encoder writes its four FPN maps straight into
+        the decoders' zero-haloed inputs -> heads.  (No feature cache: used when clips do not share frames.)"""
+        hip.require_gpu()
+        m = self._model
+        T, _, H, W = frames.shape
+        dev = frames.device
+        pads = self._padded_feature_buffers(T, H, W, dev)
+        Cn = m.backbone.out_channels
+        vols = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads, (32, 16, 8, 4))}
+        m.backbone.run_backbone_into(frames, [vols[s] for s in (4, 8, 16, 32)])
+        return self._run_heads(pads, T, H, W, dev)
+
+    @torch.no_grad()
+    def _run_heads(self, pads, T, H, W, dev):
+        m = self._model
         feats = ([b for b, _ in pads], (T, H // 4, W // 4))
         eh = m.embedding_head
         eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
@@ -183,9 +202,9 @@ class InferenceModel(nn.Module):
         for i, sub in enumerate(subseq_idxes):
             need = sorted(set(t for t in sub if t not in cache))
             if need:
-                feats = m.backbone.run_backbone(frames[need])                           # one batch for all new frames
+                feats = m.backbone.forward_channel_major(frames[need])                  # one batch for all new frames
                 for j, t in enumerate(need):
-                    cache[t] = {s: feats[s][j] for s in (4, 8, 16, 32)}
+                    cache[t] = {s: f[:, j] for s, f in zip((4, 8, 16, 32), feats)}
             emb, bw, seed = self.embed_clip([cache[t] for t in sub], len(sub), H, W)
             uniq = sorted(set(sub))
             if len(uniq) != len(sub):                                                   # dict semantics of :137-138: last slot wins

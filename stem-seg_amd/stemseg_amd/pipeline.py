@@ -28,11 +28,7 @@ class ClipPipeline(object):
     @torch.no_grad()
     def embed(self, frames):
         """frames: float32 [T,3,H,W] on the device (pre-processed, H and W multiples of 32)."""
-        m = self.model
-        T, _, H, W = frames.shape
-        feats = m._model.backbone.run_backbone(frames)
-        maps = [{s: feats[s][t] for s in (4, 8, 16, 32)} for t in range(T)]
-        return m.embed_clip(maps, T, H, W)
+        return self.model.embed_frames(frames.contiguous())
 
     @torch.no_grad()
     def cluster(self, emb, bw, seed, label_start=1):

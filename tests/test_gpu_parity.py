@@ -90,6 +90,89 @@ def test_conv3d_k1(hip, cfg, shape):
     assert report("conv3d_k1 cfg%d %s" % (cfg, shape), out.cpu().numpy(), ref.numpy()) <= 2e-4
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 2, 9, 37), (64, 64, 3, 17, 40), (256, 256, 2, 6, 27), (128, 128, 8, 30, 54)])
+def test_conv2d_3x3_fused_epilogue(hip, shape):
+    """(1,3,3) conv over every t-plane (= the encoder's frames) with bias + ReLU fused, zero-haloed 2-D input."""
+    Cin, Cout, T, H, W = shape
+    x = _rand((Cin, T, H, W), 21)
+    w = _rand((Cout, Cin, 3, 3), 22, 1.0 / np.sqrt(Cin * 9))
+    b = _rand((Cout,), 23)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).permute(1, 0, 2, 3), torch.from_numpy(w), torch.from_numpy(b), padding=1)).permute(1, 0, 2, 3).numpy()
+    pitch = (W + 2 + 3) // 4 * 4
+    buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
+    buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
+    vin = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel())
+    scratch = torch.empty(16 * Cout * T * H * W, device="cuda")
+    for sk in (None, scratch):
+        out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        hip.conv3d(vin, hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(out), (1, 3, 3), 0, sk, dict(relu=1))
+        assert report("conv2d 3x3+relu %s splitk=%s" % (shape, sk is not None), out.cpu().numpy(), ref) <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(64, 256, 2, 9, 37), (256, 64, 3, 17, 40), (1024, 256, 2, 6, 27), (64, 64, 1, 5, 8)])
+def test_conv1x1_flat_decode_residual_relu(hip, shape):
+    """1x1 conv on the flat [C][V] view: (a) + residual + ReLU, dense out; (b) decoded into a zero-haloed 2-D layout."""
+    Cin, Cout, T, H, W = shape
+    V = T * H * W
+    x = _rand((Cin, V), 24)
+    w = _rand((Cout, Cin, 1, 1), 25, 1.0 / np.sqrt(Cin))
+    b = _rand((Cout,), 26)
+    r = _rand((Cout, V), 27)
+    z = torch.from_numpy(w.reshape(Cout, Cin)) @ torch.from_numpy(x) + torch.from_numpy(b)[:, None]
+    xd, rd, wd, bd = dev(x), dev(r), hip.pack_conv_weight(dev(w)), dev(b)
+    scratch = torch.empty(16 * Cout * V, device="cuda")
+    for sk in (None, scratch):
+        out = torch.full((Cout, V), float("nan"), device="cuda")
+        hip.conv3d(hip.flat_volume(xd), wd, bd, hip.flat_volume(out), 1, 0, sk, dict(relu=1, residual=rd, res_strides=(V, 0, 0)))
+        assert report("conv1x1+res+relu %s splitk=%s" % (shape, sk is not None), out.cpu().numpy(), F.relu(z + torch.from_numpy(r)).numpy()) <= 2e-4
+        pitch = (W + 2 + 3) // 4 * 4
+        buf = torch.zeros(Cout, T, H + 2, pitch, device="cuda")
+        vout = hip.Volume(buf.data_ptr() + 4 * (pitch + 1), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cout, T, H, W, buf.numel() - pitch - 1)
+        hip.conv3d(hip.flat_volume(xd), wd, bd, vout, 1, 0, sk, dict(relu=1, decode=(H, W)))
+        got = buf[:, :, 1:H + 1, 1:W + 1].cpu().numpy()
+        assert report("conv1x1 decode->haloed %s splitk=%s" % (shape, sk is not None), got, F.relu(z).reshape(Cout, T, H, W).numpy()) <= 2e-4
+        halo = buf.clone()
+        halo[:, :, 1:H + 1, 1:W + 1] = 0
+        assert float(halo.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
+def test_encoder_vs_golden(hip, golden, btype):
+    """HIP encoder (stem, bottlenecks with fused epilogues, FPN) vs the reference's outputs (golden) and the oracle."""
+    from stemseg_amd.modeling.backbone import ResNetFPN
+    g = golden("encoder")
+    tag = btype.replace("-", "")
+    H, W, seed, stride = g[tag + "__meta"].tolist()
+    bb = ResNetFPN(btype).eval()
+    sd = {k: torch.from_numpy(np.asarray(synth.synth_param("backbone." + k, v.shape, seed))).reshape(v.shape) for k, v in bb.state_dict().items()}
+    bb.load_state_dict(sd)
+    bb = bb.cuda()
+    x = synth.synth_frames(2, H, W, seed=seed).astype(np.float32)
+    x = torch.from_numpy(x).permute(0, 3, 1, 2) - torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    feats = bb.run_backbone(x.cuda())
+    for s in (4, 8, 16, 32):
+        ref = g["%s_s%d" % (tag, s)]
+        assert list(feats[s].shape) == g["%s_s%d__shape" % (tag, s)].tolist()
+        got = feats[s].contiguous().cpu().numpy().reshape(-1)[::stride]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert report("encoder %s 1/%d (rel to max %.3g)" % (btype, s, scale), got / scale, ref / scale) <= 1e-4
+
+
+def test_encoder_batch_of_8_odd_size_vs_oracle(hip):
+    """T = 8 frames, 96 x 160 (w32 = 5: ragged 32-column tiles everywhere), R-50, vs the CPU oracle."""
+    from stemseg_amd.modeling.backbone import ResNetFPN
+    bb = ResNetFPN("R-50-FPN").eval()
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in bb.state_dict().items()], 51, prefix="backbone.")
+    bb.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(bb.state_dict()[k].shape) for k, v in sd.items()})
+    x = torch.from_numpy(synth.synth_frames(8, 96, 160, seed=51).astype(np.float32)).permute(0, 3, 1, 2) - \
+        torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    ref = oenc.resnet_fpn(x, {"backbone." + k: v for k, v in sd.items()}, "R-50-FPN")
+    feats = bb.cuda().run_backbone(x.cuda())
+    for s in (4, 8, 16, 32):
+        scale = max(1.0, float(ref[s].abs().max()))
+        assert report("encoder T=8 96x160 1/%d" % s, feats[s].cpu().numpy() / scale, ref[s].numpy() / scale) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ GN / pool / upsample / heads
 @pytest.mark.parametrize("shape", [(256, 8, 4, 7), (128, 8, 30, 54), (64, 3, 5, 5)])
 def test_groupnorm_stats(hip, shape):

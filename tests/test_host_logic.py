@@ -161,9 +161,33 @@ def test_decoder_fails_loudly_without_gpu():
         s(feats)
 
 
+def folded_forward_torch(f, blocks, x):
+    """Test-only torch evaluation of ResNetFPN.folded_state() (conv + folded bias; no BN anywhere)."""
+    import torch.nn.functional as F
+    x = F.max_pool2d(F.relu(F.conv2d(x, *f["stem"], stride=2, padding=3)), 3, 2, 1)
+    feats, i = [], 0
+    for li, n in enumerate(blocks, 1):
+        for bi in range(n):
+            stride = 2 if (bi == 0 and li > 1) else 1
+            out = F.relu(F.conv2d(x, *f["b%d.conv1" % i], stride=stride))
+            out = F.relu(F.conv2d(out, *f["b%d.conv2" % i], padding=1))
+            out = F.conv2d(out, *f["b%d.conv3" % i])
+            idt = F.conv2d(x, *f["b%d.down" % i], stride=stride) if ("b%d.down" % i) in f else x
+            x = F.relu(out + idt)
+            i += 1
+        feats.append(x)
+    last = F.conv2d(feats[3], *f["fpn_inner4"])
+    res = {32: F.conv2d(last, *f["fpn_layer4"], padding=1)}
+    for k, s in ((3, 16), (2, 8), (1, 4)):
+        last = F.conv2d(feats[k - 1], *f["fpn_inner%d" % k]) + F.interpolate(last, scale_factor=2, mode="bilinear", align_corners=False)
+        res[s] = F.conv2d(last, *f["fpn_layer%d" % k], padding=1)
+    return res
+
+
 @pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
-def test_backbone_module_vs_golden(golden, btype):
-    """Own encoder module (FrozenBN folded, batched) with the reference's key names vs reference outputs."""
+def test_backbone_state_dict_and_bn_folding_vs_golden(golden, btype):
+    """Reference key names load, and the FrozenBN-folded weights the HIP encoder consumes reproduce the reference
+    encoder's outputs (evaluated here with plain torch convs -- the product's forward is HIP-only)."""
     from stemseg_amd.modeling.backbone import ResNetFPN
     g = golden("encoder")
     tag = btype.replace("-", "")
@@ -176,11 +200,14 @@ def test_backbone_module_vs_golden(golden, btype):
     bb.load_state_dict(sd)
     x = synth.synth_frames(2, H, W, seed=seed).astype(np.float32)
     x = torch.from_numpy(x).permute(0, 3, 1, 2) - torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
-    feats = bb.run_backbone(x)
+    feats = folded_forward_torch(bb.folded_state(), bb.stage_blocks, x)
     for s in (4, 8, 16, 32):
         ref = g["%s_s%d" % (tag, s)]
         got = feats[s].contiguous().numpy().reshape(-1)[::stride]
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (btype, s)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no MI355X visible"):
+            bb(x)
 
 
 # ------------------------------------------------------------------------------------------------ chainer host logic
