@@ -43,10 +43,12 @@ struct ConvKParams {
     const float* res;
     int64_t res_cs, res_ts, res_ys;
     int dec_H, dec_W;
+    int vec_epi;                 // 16-B epilogue through an LDS transpose (dense, aligned outputs only)
 };
 
-template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_>
+template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false>
 struct ConvCfg {
+    static constexpr bool PIPE = PIPE_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
     static constexpr int NTHREADS = 64 * WM * WN;
@@ -109,27 +111,37 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
 
-    const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
-    const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
-    for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
-        __syncthreads();   // everyone is done reading the previous chunk
-        // ---- stage the input halo tile --------------------------------------------------------
+    // ---- staging helpers ------------------------------------------------------------------------------
+    constexpr int XQ = C::XP / 4;
+    constexpr int NQ = C::CK * C::KT * C::RH * XQ;            // 16-B pieces of the input halo tile
+    constexpr int MQ = C::MT / 4;
+    constexpr int NWQ = C::CK * C::TAPS * MQ;                 // 16-B pieces of the weight slab
+    constexpr int IN_PT = (NQ + C::NTHREADS - 1) / C::NTHREADS, W_PT = (NWQ + C::NTHREADS - 1) / C::NTHREADS;
+    auto fetch_in = [&](int c0, int q) -> float4 {            // piece q of the input tile for chunk c0 (vec4 layout)
+        const int xq = q % XQ;
+        int rr = q / XQ;
+        const int r = rr % C::RH;
+        rr /= C::RH;
+        const int dt = rr % C::KT;
+        const int c = rr / C::KT;
+        const int yy = min(y0 + r, p.in_H - 1);
+        const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xq * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + c < p.Cin && tile_base + rel + 4 <= p.in_limit) v = *reinterpret_cast<const float4*>(in_tile + rel);
+        return v;
+    };
+    auto fetch_w = [&](int c0, int q) -> float4 {             // rows (sub, tap, c4) x MT output channels
+        const int mq = q % MQ;
+        const int row = q / MQ;                               // = (sub*TAPS + tap)*4 + c4
+        const int ch = c0 + (row / (C::TAPS * 4)) * 4 + (row & 3);
+        const float* wsrc = p.wpk + (int64_t)(c0 / 4) * (C::TAPS * 4) * p.Cout + co0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < p.Cin && co0 + mq * 4 < p.Cout) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * p.Cout + mq * 4);
+        return v;
+    };
+    auto stage_direct = [&](int c0) {                         // global -> LDS, no overlap (scalar fallback for odd strides)
         if (p.vec4) {
-            constexpr int XQ = C::XP / 4;
-            constexpr int NQ = C::CK * C::KT * C::RH * XQ;
-            for (int q = tid; q < NQ; q += C::NTHREADS) {
-                const int xq = q % XQ;
-                int rr = q / XQ;
-                const int r = rr % C::RH;
-                rr /= C::RH;
-                const int dt = rr % C::KT;
-                const int c = rr / C::KT;
-                const int yy = min(y0 + r, p.in_H - 1);
-                const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + c < p.Cin && tile_base + rel + 4 <= p.in_limit) v = *reinterpret_cast<const float4*>(in_tile + rel);
-                *reinterpret_cast<float4*>(in_lds + ((c * C::KT + dt) * C::RH + r) * C::XP + xq * 4) = v;
-            }
+            for (int q = tid; q < NQ; q += C::NTHREADS) *reinterpret_cast<float4*>(in_lds + q * 4) = fetch_in(c0, q);
         } else {
             constexpr int NE = C::CK * C::KT * C::RH * C::XP;
             for (int q = tid; q < NE; q += C::NTHREADS) {
@@ -143,25 +155,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
                 const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xx;
                 float v = 0.f;
                 if (c0 + c < p.Cin && tile_base + rel < p.in_limit) v = in_tile[rel];
-                in_lds[((c * C::KT + dt) * C::RH + r) * C::XP + xx] = v;
+                in_lds[q] = v;
             }
         }
-        // ---- stage the weight slab: rows (sub, tap, c4) x MT output channels -------------------
-        {
-            constexpr int MQ = C::MT / 4;
-            constexpr int NWQ = C::CK * C::TAPS * MQ;
-            const float* wsrc = p.wpk + (int64_t)(c0 / 4) * (C::TAPS * 4) * p.Cout + co0;
-            for (int q = tid; q < NWQ; q += C::NTHREADS) {
-                const int mq = q % MQ;
-                const int row = q / MQ;                       // = (sub*TAPS + tap)*4 + c4
-                const int ch = c0 + (row / (C::TAPS * 4)) * 4 + (row & 3);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ch < p.Cin && co0 + mq * 4 < p.Cout) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * p.Cout + mq * 4);
-                *reinterpret_cast<float4*>(w_lds + row * C::MT + mq * 4) = v;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA stream: every tap is a shifted LDS read ---------------------------------------
+        for (int q = tid; q < NWQ; q += C::NTHREADS) *reinterpret_cast<float4*>(w_lds + q * 4) = fetch_w(c0, q);
+    };
+    // ---- MFMA stream over one staged chunk: every tap is a shifted LDS read ------------------------------
+    auto compute = [&]() {
 #pragma unroll
         for (int sub = 0; sub < C::CK / 4; ++sub) {
 #pragma unroll
@@ -190,10 +190,94 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
                 }
             }
         }
+    };
+
+    const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
+    const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
+    if (C::PIPE && p.vec4) {
+        // software pipeline: the next chunk's global loads are issued into registers BEFORE the MFMA stream of the
+        // current chunk and written to LDS after it, so HBM/L2 latency hides under the matrix pipe.
+        float4 rin[IN_PT], rw[W_PT];
+        auto fetch_regs = [&](int c0) {
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ) rin[k] = fetch_in(c0, q); }
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NWQ) rw[k] = fetch_w(c0, q); }
+        };
+        auto regs_to_lds = [&]() {
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ) *reinterpret_cast<float4*>(in_lds + q * 4) = rin[k]; }
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NWQ) *reinterpret_cast<float4*>(w_lds + q * 4) = rw[k]; }
+        };
+        if (c_begin < c_end) {
+            fetch_regs(c_begin);
+            regs_to_lds();
+        }
+        __syncthreads();
+        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
+            const bool more = c0 + C::CK < c_end;
+            if (more) fetch_regs(c0 + C::CK);
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the MFMA stream
+            compute();
+            __syncthreads();                        // everyone is done reading this chunk
+            if (more) {
+                regs_to_lds();
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
+            __syncthreads();   // everyone is done reading the previous chunk
+            stage_direct(c0);
+            __syncthreads();
+            compute();
+        }
     }
 
     // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel) ----
     const int co_base = co0 + wm * (C::MI * 32);
+    if (p.vec_epi) {
+        // 16-B stores: each wave transposes its 32x32 accumulator tiles through LDS so that a lane owns 4 consecutive
+        // voxels of one channel (the MFMA layout gives it 16 channels of ONE voxel -> 4-B stores, 4x the instructions)
+        __syncthreads();                                       // all waves are done with the staged tiles
+        constexpr int TP = 36;                                 // padded row pitch (floats), keeps float4 reads aligned
+        float* tl = smem + wave * (32 * TP);
+        static_assert(4 * 32 * 36 <= C::LDS_FLOATS, "epilogue transpose buffer must fit the staging LDS");
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) {
+            const int s = wn * C::NI + ni;
+            const int y = y0 + s / C::COLS;
+            const int xs = x0 + (s % C::COLS) * 32;            // first voxel of this 32-wide segment
+#pragma unroll
+            for (int mi = 0; mi < C::MI; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tl[((r & 3) + 8 * (r >> 2) + 4 * half) * TP + l31] = acc[mi][ni][r];
+                // no barrier needed: the tile buffer is private to this wave (wave-synchronous LDS traffic)
+                __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the ds_writes above have landed
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (lane >> 3) + 8 * j, c4 = (lane & 7) * 4;
+                    const int co = co_base + mi * 32 + row;
+                    const int x = xs + c4;
+                    if (y < p.H && x < p.W && co < p.Cout) {    // W % 4 == 0 is guaranteed by the launcher for this path
+                        float4 v = *reinterpret_cast<const float4*>(tl + row * TP + c4);
+                        const float bv = p.bias ? p.bias[co] : 0.f;
+                        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                        const int64_t off = (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+                        if (p.res) {
+                            const float4 rv = *reinterpret_cast<const float4*>(p.res + (int64_t)co * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        *reinterpret_cast<float4*>(p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)co * p.out_cs + off) = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);            // reads done before the next tile overwrites the buffer
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
@@ -275,14 +359,14 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
 using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1>;   // 128 co x (4 rows x 32 cols)
 using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1>; // 128 co x (2 rows x 32 cols)
-using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8>;  // 128 co x 256 voxels
-using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4>; // 128 co x 128 voxels
-using K1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8>;  //  64 co x 256 voxels
+using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, true>;  // 128 co x 256 voxels
+using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, true>; // 128 co x 128 voxels
+using K1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, true>;  //  64 co x 256 voxels
 // 2-D convolutions of the encoder: the frames of a clip are the T axis, KT = 1
-using K2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
-using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1>;   // 128 co x (4 rows x 32 cols)
-using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1>; // 128 co x (2 rows x 32 cols)
-using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1>;   //  64 co x (8 rows x 32 cols)
+using K2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, true>;   // 128 co x (8 rows x 32 cols)
+using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
+using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
+using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true>;   //  64 co x (8 rows x 32 cols)
 
 template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats) {
@@ -306,6 +390,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         p.out = scratch; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.dec_H = p.dec_W = 0;
         p.out_cs = (int64_t)p.T * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
         p.out_split_stride = slab;
+        p.vec_epi = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0);
     } else p.out_split_stride = 0;
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT), (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
@@ -350,6 +435,11 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.res = epi ? epi->res : nullptr;
     p.res_cs = epi ? epi->res_cs : 0; p.res_ts = epi ? epi->res_ts : 0; p.res_ys = epi ? epi->res_ys : 0;
     p.dec_H = flat ? epi->dec_H : 0; p.dec_W = flat ? epi->dec_W : 0;
+    auto al16 = [](const void* ptr, int64_t cs, int64_t ts, int64_t ys, int T, int H) {
+        return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && (cs % 4 == 0) && (T == 1 || ts % 4 == 0) && (H == 1 || ys % 4 == 0);
+    };
+    p.vec_epi = (!flat && p.W % 4 == 0 && al16(p.out, p.out_cs, p.out_ts, p.out_ys, p.T, p.H) &&
+                 (!p.res || al16(p.res, p.res_cs, p.res_ts, p.res_ys, p.T, p.H))) ? 1 : 0;
     p.tiles_x = p.tiles_y = 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(in.ptr) % 16 == 0) && (in.c_stride % 4 == 0) &&
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
@@ -370,9 +460,10 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     if (k2) {
         if (p.Cout <= 64) return launch_cfg<K2M64>(p, s, scratch, scratch_floats);
         int cfg = tile_cfg;
-        if (cfg <= 0 || cfg > 3) {
-            if (num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= 512) cfg = 1;
-            else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
+        if (cfg <= 0 || cfg > 3) {   // biggest tile (best weight reuse) that split-K can still spread over the chip
+            const int64_t need = scratch ? 96 : 384;
+            if (num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= need) cfg = 1;
+            else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= need) cfg = 2;
             else cfg = 3;
         }
         if (cfg == 1) return launch_cfg<K2Big>(p, s, scratch, scratch_floats);
@@ -381,7 +472,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     }
     if (p.Cout <= 64) return launch_cfg<K1M64>(p, s, scratch, scratch_floats);
     int cfg = tile_cfg;
-    if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) ? 1 : 2;
+    if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
     if (cfg == 1) return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
     return launch_cfg<K1Small>(p, s, scratch, scratch_floats);
 }

@@ -170,7 +170,7 @@ struct EncoderPlan {
     int T, H, W, nblk[4], total_blocks;
     int h[4], w[4];            // 4x, 8x, 16x, 32x
     int64_t V[4];
-    int64_t S0, X1, A, B, Cst[4], M1, M2, DS, XS, L[4], SK, SKfloats, total;
+    int64_t S0, X1, A, B, Cst[4], M1[4], M2, DS, XS, L[4], SK, SKfloats, total;
 };
 
 static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
@@ -194,12 +194,11 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     p.X1 = take(64 * p.V[0]);
     p.A = take(256 * p.V[0]);
     p.B = take(256 * p.V[0]);
-    int64_t m1 = 0;
     for (int i = 0; i < 4; ++i) {
         p.Cst[i] = take((int64_t)(256 << i) * p.V[i]);
-        m1 = std::max(m1, Padded2D(64 << i, p.T, p.h[i], p.w[i]).total);
+        // one zero-haloed buffer PER STAGE: the halo stays zero only while a buffer keeps one geometry
+        p.M1[i] = take(Padded2D(64 << i, p.T, p.h[i], p.w[i]).total);
     }
-    p.M1 = take(m1);
     p.M2 = take(64 * p.V[0]);
     p.DS = take(256 * p.V[0]);
     p.XS = take(256 * p.V[1]);
@@ -284,12 +283,12 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             float* y = (b == p.nblk[st] - 1) ? ws + p.Cst[st] : ((b & 1) ? ws + p.B : ws + p.A);
             ConvEpilogue e1;                    // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
             e1.relu = 1; e1.dec_H = h; e1.dec_W = w;
-            rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1, mid, T, h, w), 1, 1, 1, 0, s,
+            rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1[st], mid, T, h, w), 1, 1, 1, 0, s,
                                ws + p.SK, p.SKfloats, &e1);
             if (rc) return rc;
             ConvEpilogue e2;                    // conv2 (3x3) + bn2 + relu -> dense
             e2.relu = 1;
-            rc = launch_conv3d(halo2d_view(ws + p.M1, mid, T, h, w), wts->conv2_w[bi], wts->conv2_b[bi], dense_volume(ws + p.M2, mid, T, h, w), 1, 3, 3, 0, s,
+            rc = launch_conv3d(halo2d_view(ws + p.M1[st], mid, T, h, w), wts->conv2_w[bi], wts->conv2_b[bi], dense_volume(ws + p.M2, mid, T, h, w), 1, 3, 3, 0, s,
                                ws + p.SK, p.SKfloats, &e2);
             if (rc) return rc;
             const float* idt = xin;
