@@ -8,7 +8,7 @@ import sys
 c = sqlite3.connect(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = c.execute("select name, start, end, grid_x, grid_y, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
-big = [r for r in rows if "conv_igemm" in r[0] and "<3, 3, 3, 4, 4, 2, 1, 4, 1>" in r[0]]
+big = [r for r in rows if "conv_igemm" in r[0] and "<3, 3, 3, 4, 4, 2, 1, 4, 1" in r[0]]
 assert len(big) >= 2 * (n + 1), "not enough steps in the trace"
 t0, t1 = big[-2 * n - 1][2], big[-1][2]
 agg = {}
