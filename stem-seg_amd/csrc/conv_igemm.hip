@@ -357,8 +357,8 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 // tile shapes --------------------------------------------------------------------------------------
 //                       KT KH KW  CK  MI NI WM WN COLS
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
-using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1>;   // 128 co x (4 rows x 32 cols)
-using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1>; // 128 co x (2 rows x 32 cols)
+using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
+using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
 using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, true>;  // 128 co x 256 voxels
 using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, true>; // 128 co x 128 voxels
 using K1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, true>;  //  64 co x 256 voxels
