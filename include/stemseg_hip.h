@@ -154,6 +154,10 @@ typedef struct StemsegDecoderDesc {
                                     on the library's internal stream set (k-1) % 4 beside the 4x branch (fork / join by
                                     events on the caller's stream; the call is still stream-ordered for the caller).
                                     Decoders that may overlap (embedding + seediness) should use different sets.     */
+    int32_t detached;            /* with concurrency >= 1: ALL work (also the 4x branch and the heads) runs on the internal
+                                    streams and the call returns without joining; the caller must enqueue
+                                    stemseg_hip_decoder_join(concurrency, stream) before it consumes `out` or re-uses the
+                                    inputs / workspace.  Lets a twin decoder be enqueued in between (both fill the chip). */
 } StemsegDecoderDesc;
 
 typedef struct StemsegDecoderWeights {
@@ -177,6 +181,9 @@ int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc, void* wor
 int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* weights,
                                 const float* const feats[4], float* out,
                                 void* workspace, size_t ws_bytes, void* stream);
+
+/* make `stream` wait for a detached decoder_forward issued with the same concurrency set */
+int stemseg_hip_decoder_join(int32_t concurrency, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 2-D encoder: ResNet-50/101 + FPN over the T frames of a clip (backbone/resnet.py:105-113, fpn.py:47-69,

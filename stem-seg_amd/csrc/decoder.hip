@@ -123,8 +123,8 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
 constexpr int STREAM_SETS = 4;
 struct BranchStreams {
     bool ok = false;
-    hipStream_t s[3];
-    hipEvent_t start, done[3];
+    hipStream_t s[4];            // 32x, 16x, 8x branches + (detached mode) the 4x branch / tail
+    hipEvent_t start, done[4];
 };
 static BranchStreams g_streams[16][STREAM_SETS];   // [device][set]
 static std::mutex g_streams_mu;
@@ -135,7 +135,7 @@ static BranchStreams* get_streams(int set) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
     BranchStreams& b = g_streams[dev][((set % STREAM_SETS) + STREAM_SETS) % STREAM_SETS];
     if (!b.ok) {
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             if (hipStreamCreateWithFlags(&b.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
             if (hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         }
@@ -263,6 +263,10 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     // the fuse convolutions.  concurrency == 0 keeps everything on the caller's stream.
     BranchStreams* bs = desc->concurrency ? get_streams(desc->concurrency - 1) : nullptr;
     hipStream_t s32 = bs ? bs->s[0] : s, s16 = bs ? bs->s[1] : s, s8 = bs ? bs->s[2] : s;
+    // detached: even the 4x branch and the tail run on an internal stream; the caller joins later with
+    // stemseg_hip_decoder_join, after it has enqueued other work (the twin decoder) on its own stream
+    const bool detached = bs && desc->detached;
+    hipStream_t sm = detached ? bs->s[3] : s;
 
     // 0. inputs into the zero-haloed layout (skipped when the caller already provides it)
     float* pin[4];
@@ -276,7 +280,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     }
     if (bs) {
         SS_HIP(hipEventRecord(bs->start, s));
-        for (int i = 0; i < 3; ++i) SS_HIP(hipStreamWaitEvent(bs->s[i], bs->start, 0));
+        for (int i = 0; i < (detached ? 4 : 3); ++i) SS_HIP(hipStreamWaitEvent(bs->s[i], bs->start, 0));
     }
     // 1. block_32x on s32: three conv/GN/ReLU(/pool) stages (embedding_decoder.py:20-35), then upsample into cat16[0:c32]
     rc = conv_gn(padded_halo_view(pin[0], p.cin, T, p.h[0], p.w[0]), wts->conv_w[0], wts->conv_b[0], wts->gn_w[0], wts->gn_b[0], p.c32, T,
@@ -319,14 +323,31 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, s);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm);
     if (rc) return rc;
-    if (bs) SS_HIP(hipStreamWaitEvent(s, bs->done[2], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, s);
+    if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
+    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm);
     if (rc) return rc;
     // 5. heads (:131-143)
     HeadSpec hs;
     hs.n_out = desc->n_out;
     for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
-    return launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, s);
+    rc = launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm);
+    if (rc) return rc;
+    if (detached) SS_HIP(hipEventRecord(bs->done[3], sm));
+    else if (bs) {
+        // join every branch stream DIRECTLY into the caller's stream as well (stream capture only recognises direct joins
+        // into the origin stream; the transitive 32x -> 16x -> 8x -> caller chain above is not enough for hipGraph capture)
+        SS_HIP(hipStreamWaitEvent(s, bs->done[0], 0));
+        SS_HIP(hipStreamWaitEvent(s, bs->done[1], 0));
+    }
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_decoder_join(int32_t concurrency, void* stream) {
+    SS_CHECK_ARG(concurrency >= 1, "decoder_join: concurrency set must be >= 1");
+    BranchStreams* bs = get_streams(concurrency - 1);
+    SS_CHECK_ARG(bs, "decoder_join: no stream set");
+    for (int i = 0; i < 4; ++i) SS_HIP(hipStreamWaitEvent(as_stream(stream), bs->done[i], 0));
+    return STEMSEG_OK;
 }

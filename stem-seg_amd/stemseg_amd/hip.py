@@ -28,7 +28,7 @@ class DecoderDesc(C.Structure):
                 ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
                 ("pool", C.c_int32 * 3), ("t_scale", C.c_int32 * 3), ("n_out", C.c_int32),
                 ("act", C.c_int32 * (2 * MAX_EMB_DIMS)), ("grid_axis", C.c_int32 * (2 * MAX_EMB_DIMS)),
-                ("input_layout", C.c_int32), ("concurrency", C.c_int32)]
+                ("input_layout", C.c_int32), ("concurrency", C.c_int32), ("detached", C.c_int32)]
 
 
 class DecoderWeights(C.Structure):
@@ -93,6 +93,7 @@ SIGNATURES = {
     "stemseg_hip_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDesc)]),
     "stemseg_hip_decoder_init_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_forward": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(_P), _P, _P, C.c_size_t, _P]),
+    "stemseg_hip_decoder_join": (C.c_int, [_I32, _P]),
     "stemseg_hip_seediness_accumulate": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "stemseg_hip_fg_mask": (C.c_int, [_P, _F, _F, _P, _I64, _P]),
     "stemseg_hip_fg_gather": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P]),

@@ -62,6 +62,7 @@ class SqueezeExpandTrunk(nn.Module):
         self._workspaces = {}     # (T, H4, W4, layout) -> (tensor, desc)
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
+        self.detached = False     # True: the call does not join; ``join()`` must follow (twin-decoder overlap)
 
     # ---- to be provided by the concrete decoder ---------------------------------------------------
     def _head_spec(self):
@@ -108,6 +109,10 @@ class SqueezeExpandTrunk(nn.Module):
     def _grid(self, c, T, H4, W4, dev):
         return None, None, None
 
+    def join(self):
+        """Make the current stream wait for a detached forward of this decoder."""
+        hip.check(hip.lib().stemseg_hip_decoder_join(int(self.concurrency), hip.stream()))
+
     @torch.no_grad()
     def run_hip(self, feats, input_layout=None, act_override=None):
         """feats: 4 device tensors (32x,16x,8x,4x) for ONE sample: dense [C,T,h,w] (layout 0), dense [T,C,h,w]
@@ -131,6 +136,7 @@ class SqueezeExpandTrunk(nn.Module):
             d.act[o], d.grid_axis[o] = act[o], c["axes"][o]
         d.input_layout = layout
         d.concurrency = int(self.concurrency)
+        d.detached = int(bool(self.detached) and self.concurrency >= 1)
         key = (T, H4, W4, layout, dev.index)
         ws = self._workspaces.get(key)
         if ws is None:

@@ -149,31 +149,30 @@ class InferenceModel(nn.Module):
         seed = None
         eh.concurrency = 1 if self.overlap_decoders else 0
         if eh.seediness_channels == 0 and not self.overlap_decoders:
-            m.seediness_head.concurrency = 0
+            m.seediness_head.concurrency, m.seediness_head.detached = 0, False
             seed = m.seediness_head.forward_single(feats, 2)
             if self.resize_scale != 1.0:
                 seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
             main = None
         elif eh.seediness_channels == 0:
-            # the seediness decoder shares nothing with the embedding decoder but its (read-only) inputs: run it on a
-            # side stream (its own branch-stream set) so the two decoders fill the chip together
+            # the seediness decoder shares nothing with the embedding decoder but its (read-only) inputs: enqueue it
+            # detached on the library's second stream set, enqueue the embedding decoder, then join -- the two decoders
+            # (2 big + 12 small convolutions) fill the chip together
             assert m.seediness_head is not None
-            main = torch.cuda.current_stream()
-            side = self._side_stream(dev)
-            side.wait_stream(main)
-            m.seediness_head.concurrency = 2
-            with torch.cuda.stream(side):
-                seed = m.seediness_head.forward_single(feats, 2)
-                if self.resize_scale != 1.0:                                            # inference_model.py:156 quirk
-                    seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+            sh = m.seediness_head
+            sh.concurrency, sh.detached = 2, True
+            seed = sh.forward_single(feats, 2)
+            main = sh
         out = eh.forward_single(feats, 2)
         E, Ev = eh.embedding_size, eh.variance_channels
         emb, bw = out[:E], out[E:E + Ev]
         if seed is None:
             seed = out[E + Ev:]
         elif main is not None:
-            main.wait_stream(side)
-            seed.record_stream(main)
+            main.join()
+            main.detached = False
+            if self.resize_scale != 1.0:                                                # inference_model.py:156 quirk
+                seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return emb, bw, seed
 
     def _side_stream(self, dev):
