@@ -144,6 +144,9 @@ def main():
     graph, static_in, static_out = None, None, None
     if not args.no_graph:
         try:
+            # inside the captured graph every launch sits on ONE stream: measured, the fork/join branch streams give no
+            # throughput here (each conv already fills the chip) and HIP's capture rejects the multi-stream fork/join
+            pipe.model.overlap_decoders = False
             static_in = clips[0].clone()
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream())
@@ -159,6 +162,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             print("[bench] hipGraph capture failed (%r); falling back to eager launches" % (e,), file=sys.stderr)
             graph = None
+            pipe.model.overlap_decoders = True
             torch.cuda.synchronize()
 
     def step_graph(i):
