@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,7 +147,7 @@ def main():
         try:
             # inside the captured graph every launch sits on ONE stream: measured, the fork/join branch streams give no
             # throughput here (each conv already fills the chip) and HIP's capture rejects the multi-stream fork/join
-            pipe.model.overlap_decoders = False
+            pipe.model.overlap_decoders = bool(args.graph_overlap)
             static_in = clips[0].clone()
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream())
@@ -160,6 +161,8 @@ def main():
             graph = g
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
             print("[bench] hipGraph capture failed (%r); falling back to eager launches" % (e,), file=sys.stderr)
             graph = None
             pipe.model.overlap_decoders = True

@@ -62,9 +62,14 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
         return torch.cat(ws, 0), torch.cat([b.float() for b in bs], 0), act, axes
 
     def _grid(self, c, T, H4, W4, dev):
-        key = (T, H4, W4, dev.index, float(self.time_scale))
+        # the time_scale buffer lives on the device: read it back once per value, not per call (a per-call .item() is a
+        # host sync and is illegal inside hipGraph capture)
+        sig = (self.time_scale.data_ptr(), self.time_scale._version)
+        if c.get("ts_sig") != sig:
+            c["ts_sig"], c["ts"] = sig, float(self.time_scale)
+        key = (T, H4, W4, dev.index, c["ts"])
         if key not in c["grids"]:
-            c["grids"][key] = tuple(g.contiguous() for g in grid_vectors(H4, W4, T, float(self.time_scale), device=dev))
+            c["grids"][key] = tuple(g.contiguous() for g in grid_vectors(H4, W4, T, c["ts"], device=dev))
         return c["grids"][key]
 
     def _acts(self):
