@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_MFMA_BF16_TFLOPS = 2500.0    # same guide: bf16 MFMA, dense (the 2:1-sparse 5 PF figure is not used)
 T, H, W = 8, 480, 864             # BASELINE config 1: DAVIS-shape 480p (480x854 padded to a multiple of 32)
 BACKBONE = "R-101-FPN"
 
@@ -104,6 +105,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="MFMA mode of every convolution: exact fp32 (default) or the 3-term bf16 split (fp32 accumulate)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -124,6 +127,7 @@ def main():
     from stemseg_amd import hip
     hip.require_gpu()
     pipe, sd = build_pipeline(device)
+    pipe.model.set_precision(args.precision)
     clips = [make_clip(1000 + rank * 97 + i, device) for i in range(2)]
 
     def step(i):
@@ -205,6 +209,7 @@ def main():
     if rank == 0:
         clips_total = args.steps * world
         # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes), measured inside the timed region
+        peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / 3.0
         k3 = [prof[t] for t in (8, 4, 2) if t in prof]
         ms = sum(p[0] for p in k3)
         fl = sum(p[1] for p in k3)
@@ -213,13 +218,15 @@ def main():
         res = {
             "metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(clips_total / dt, 4), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 operands as bf16x3 split (3 bf16 MFMAs per product, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + "
                                    "seediness decoders, fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE,
                        "clips_per_step": 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, fp32 MFMA 32x32x2)", "achieved": round(ach, 2),
-                         "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
+                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": None, "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "how": "hipEvent pairs around every 3x3x3 conv launch over %d serialized steps after the timed "
                                 "region (in the timed region the two decoders and their branches overlap on separate streams)" % n_roof,

@@ -94,7 +94,15 @@ typedef struct StemsegConvEpilogue {
     int64_t      res_c_stride, res_t_stride, res_y_stride;
     int32_t      decode_H, decode_W; /* > 0: the 1x1x1 conv runs on a flat [C][V] input (in->T = in->H = 1, in->W = V) and
                                         voxel v is stored at (t,y,x) = (v/(H*W), (v/W)%H, v%W) of `out` (e.g. dense -> haloed) */
+    int32_t      precision;        /* STEMSEG_PRECISION_F32 (exact fp32 MFMA) or STEMSEG_PRECISION_BF16X3: every fp32 operand is
+                                      split hi + lo into bf16 and a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores
+                                      with fp32 accumulation (~2^-17 relative per product, 5.3x the fp32-MFMA rate); packed_w
+                                      must then come from stemseg_hip_pack_conv_weight_bf16x3 */
 } StemsegConvEpilogue;
+#define STEMSEG_PRECISION_F32    0
+#define STEMSEG_PRECISION_BF16X3 1
+int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t Cin, int32_t taps);
+int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
 /* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).
  * epilogue may be NULL (plain conv + bias). */
 int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
@@ -158,6 +166,8 @@ typedef struct StemsegDecoderDesc {
                                     streams and the call returns without joining; the caller must enqueue
                                     stemseg_hip_decoder_join(concurrency, stream) before it consumes `out` or re-uses the
                                     inputs / workspace.  Lets a twin decoder be enqueued in between (both fill the chip). */
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | STEMSEG_PRECISION_BF16X3 for every convolution of the decoder
+                                    (weights in StemsegDecoderWeights must be packed for the same mode)                    */
 } StemsegDecoderDesc;
 
 typedef struct StemsegDecoderWeights {
@@ -196,6 +206,7 @@ typedef struct StemsegEncoderDesc {
     int32_t blocks[4];           /* bottleneck blocks per stage: R-50 {3,4,6,3}, R-101 {3,4,23,3}       */
     int32_t T, H, W;             /* frames per call and padded frame size (multiples of 32)              */
     int32_t out_channels;        /* 256                                                                  */
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | STEMSEG_PRECISION_BF16X3 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
 } StemsegEncoderDesc;
 
 typedef struct StemsegEncoderWeights {

@@ -80,6 +80,7 @@ struct ConvEpilogue {            // fused into the conv epilogue (or the split-K
     const float* res = nullptr;  // residual, addressed with (res_cs, res_ts, res_ys) at the output's (c, t, y, x)
     int64_t res_cs = 0, res_ts = 0, res_ys = 0;
     int dec_H = 0, dec_W = 0;    // > 0: 1x1x1 conv launched on a flat [C][V] input; voxel v -> (v / (H*W), (v / W) % H, v % W)
+    int precision = 0;           // 0: exact fp32 MFMA; 1: bf16x3 split (weights must be packed with ..._bf16x3)
 };
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0,

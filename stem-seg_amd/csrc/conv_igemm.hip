@@ -46,9 +46,13 @@ struct ConvKParams {
     int vec_epi;                 // 16-B epilogue through an LDS transpose (dense, aligned outputs only)
 };
 
-template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false>
+// bf16x3 ("3xBF16") mode: every fp32 operand x is split as x = hi + lo (+ residual <= 2^-18 |x|) with hi, lo bf16, and
+// a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate):
+// ~2^-17 relative error per product -- the same order as fp32 accumulation round-off over K = 6912 -- at 16/3 = 5.3x the
+// fp32-MFMA rate.  k-groups of 16: lane half h carries CPH channels x TPG taps (CPH * TPG = 8).
+template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false>
 struct ConvCfg {
-    static constexpr bool PIPE = PIPE_;
+    static constexpr bool PIPE = PIPE_, BF = BF_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
     static constexpr int NTHREADS = 64 * WM * WN;
@@ -59,8 +63,15 @@ struct ConvCfg {
     static constexpr int XP = ((COLS * 32 + KW - 1) + 3) / 4 * 4;
     static constexpr int IN_CH_STRIDE = KT * RH * XP;
     static constexpr int IN_FLOATS = CK * IN_CH_STRIDE;
-    static constexpr int W_FLOATS = CK * TAPS * MT;
+    // bf16x3 grouping: taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
+    static constexpr int TPG = TAPS >= 27 ? 4 : (TAPS >= 9 ? 2 : 1);
+    static constexpr int CPH = 8 / TPG;
+    static constexpr int NTG = (TAPS + TPG - 1) / TPG;                  // tap groups
+    static constexpr int NCG = BF ? CK / (2 * CPH) : 1;                 // channel groups per chunk
+    static constexpr int G = NTG * NCG;                                 // 16-wide k-groups per chunk
+    static constexpr int W_FLOATS = BF ? 2 * G * 2 * MT * 4 : CK * TAPS * MT;   // bf16x3: [hi|lo][G][half][MT] x 16 B
     static constexpr int LDS_FLOATS = IN_FLOATS + W_FLOATS;
+    static_assert(!BF || CK % (2 * CPH) == 0, "bf16x3: chunk must hold whole k-groups");
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
     static_assert(CK % 4 == 0, "channel chunk is a multiple of the packed sub-chunk (4)");
     static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
@@ -108,6 +119,12 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         b_ptr[ni] = in_lds + half * C::IN_CH_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
     }
 
+    const float* b_ptr_bf[C::NI];      // bf16x3: lane half h owns channels [h*CPH, (h+1)*CPH) of every k-group
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) {
+        const int s = wn * C::NI + ni;
+        b_ptr_bf[ni] = in_lds + half * (C::CPH * C::IN_CH_STRIDE) + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+    }
     const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
 
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     constexpr int XQ = C::XP / 4;
     constexpr int NQ = C::CK * C::KT * C::RH * XQ;            // 16-B pieces of the input halo tile
     constexpr int MQ = C::MT / 4;
-    constexpr int NWQ = C::CK * C::TAPS * MQ;                 // 16-B pieces of the weight slab
+    constexpr int NWQ = C::BF ? 2 * C::G * 2 * C::MT : C::CK * C::TAPS * MQ;   // 16-B pieces of the weight slab
     constexpr int IN_PT = (NQ + C::NTHREADS - 1) / C::NTHREADS, W_PT = (NWQ + C::NTHREADS - 1) / C::NTHREADS;
     auto fetch_in = [&](int c0, int q) -> float4 {            // piece q of the input tile for chunk c0 (vec4 layout)
         const int xq = q % XQ;
@@ -131,6 +148,15 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         return v;
     };
     auto fetch_w = [&](int c0, int q) -> float4 {             // rows (sub, tap, c4) x MT output channels
+        if constexpr (C::BF) {                                // piece q = ((hl*G + grp)*2 + half)*MT + co : 8 bf16 of one channel
+            const int col = q % C::MT, r = q / C::MT;
+            const int hl = r / (2 * C::G), gh = r - hl * (2 * C::G);
+            const float4* wsrc = reinterpret_cast<const float4*>(p.wpk) +
+                                 ((int64_t)((c0 / C::CK) * 2 + hl) * (2 * C::G) + gh) * p.Cout + co0 + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 < p.Cin && co0 + col < p.Cout) v = *wsrc;
+            return v;
+        }
         const int mq = q % MQ;
         const int row = q / MQ;                               // = (sub*TAPS + tap)*4 + c4
         const int ch = c0 + (row / (C::TAPS * 4)) * 4 + (row & 3);
@@ -162,6 +188,45 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     };
     // ---- MFMA stream over one staged chunk: every tap is a shifted LDS read ------------------------------
     auto compute = [&]() {
+        if constexpr (C::BF) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
+            constexpr int HL_BYTES = C::G * 2 * C::MT * 16;   // offset of the lo planes
+#pragma unroll
+            for (int grp = 0; grp < C::G; ++grp) {
+                const int cg = grp / C::NTG, tg = grp % C::NTG;
+                bf16x8 ah[C::MI], al[C::MI], bh[C::NI], bl[C::NI];
+#pragma unroll
+                for (int mi = 0; mi < C::MI; ++mi) {
+                    ah[mi] = *reinterpret_cast<const bf16x8*>(a_base + ((grp * 2) * C::MT + mi * 32) * 16);
+                    al[mi] = *reinterpret_cast<const bf16x8*>(a_base + HL_BYTES + ((grp * 2) * C::MT + mi * 32) * 16);
+                }
+#pragma unroll
+                for (int ni = 0; ni < C::NI; ++ni) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int tapi = j / C::CPH, chl = j % C::CPH;
+                        int tap = tg * C::TPG + tapi;
+                        tap = tap < C::TAPS ? tap : C::TAPS - 1;       // padded taps: any valid address (their weights are zero)
+                        const int dt = tap / (C::KH * C::KW), dy = (tap / C::KW) % C::KH, dx = tap % C::KW;
+                        const int off = (cg * 2 * C::CPH + chl) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
+                        const float x = b_ptr_bf[ni][off];
+                        const __bf16 hi = (__bf16)x;
+                        bh[ni][j] = hi;
+                        bl[ni][j] = (__bf16)(x - (float)hi);
+                    }
+                }
+#pragma unroll
+                for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < C::NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int sub = 0; sub < C::CK / 4; ++sub) {
 #pragma unroll
@@ -354,6 +419,41 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// bf16x3 packing: [Cout][Cin][taps] fp32 -> per chunk [hi|lo][G][half][Cout][8 bf16]; element j of (grp, half) is
+// channel cg*2*CPH + half*CPH + j % CPH of the chunk, tap tg*TPG + j / CPH (zero beyond the last tap / channel)
+__global__ void pack_conv_weight_bf16x3_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int Cin, int taps,
+                                                int CK, int TPG) {
+    const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
+    const int nchunks = (Cin + CK - 1) / CK;
+    const int64_t n = (int64_t)nchunks * 2 * G * 2 * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t r = i / Cout;
+        const int h = (int)(r & 1);
+        r >>= 1;
+        const int grp = (int)(r % G);
+        r /= G;
+        const int hl = (int)(r & 1);
+        const int chunk = (int)(r >> 1);
+        const int cg = grp / NTG, tg = grp % NTG;
+        unsigned short v[8];
+        for (int j = 0; j < 8; ++j) {
+            const int tapi = j / CPH, chl = j % CPH;
+            const int tap = tg * TPG + tapi, ci = chunk * CK + cg * 2 * CPH + h * CPH + chl;
+            float x = 0.f;
+            if (tap < taps && ci < Cin) x = w[((int64_t)co * Cin + ci) * taps + tap];
+            const __bf16 hi = (__bf16)x;
+            const __bf16 lo = (__bf16)(x - (float)hi);
+            const __bf16 pick = hl ? lo : hi;
+            v[j] = *reinterpret_cast<const unsigned short*>(&pick);
+        }
+        uint4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+        packed[i] = o;
+    }
+}
+
 // tile shapes --------------------------------------------------------------------------------------
 //                       KT KH KW  CK  MI NI WM WN COLS
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
@@ -367,6 +467,18 @@ using K2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, true>;   // 128 co x (8 rows x 
 using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
 using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
 using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true>;   //  64 co x (8 rows x 32 cols)
+
+// bf16x3 twins of the tile shapes (register prefetch only where the wider fragments still fit 256 VGPRs)
+using X3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, true>;
+using X3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true, true>;
+using X3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true, true>;
+using X1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, true>;
+using X1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, true, true>;
+using X1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, true, true>;
+using X2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, false, true>;
+using X2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true, true>;
+using X2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true, true>;
+using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 
 template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats) {
@@ -414,6 +526,7 @@ static int64_t num_workgroups(int Cout, int T, int H, int W) {
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats, const ConvEpilogue* epi) {
     SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
+    const bool bf = epi && epi->precision == 1;
     const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1), k2 = (kt == 1 && kh == 3 && kw == 3);
     SS_CHECK_ARG(k3 || k1 || k2, "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3 or 1x1x1)", kt, kh, kw);
     const bool flat = epi && epi->dec_W > 0;
@@ -453,12 +566,17 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K3Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
             else cfg = 3;
         }
+        if (bf) {
+            if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);
+            if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
+            return launch_cfg<X3Small>(p, s, scratch, scratch_floats);
+        }
         if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
         if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats);
         return launch_cfg<K3Small>(p, s, scratch, scratch_floats);
     }
     if (k2) {
-        if (p.Cout <= 64) return launch_cfg<K2M64>(p, s, scratch, scratch_floats);
+        if (p.Cout <= 64) return bf ? launch_cfg<X2M64>(p, s, scratch, scratch_floats) : launch_cfg<K2M64>(p, s, scratch, scratch_floats);
         int cfg = tile_cfg;
         if (cfg <= 0 || cfg > 3) {   // biggest tile (best weight reuse) that split-K can still spread over the chip
             const int64_t need = scratch ? 96 : 384;
@@ -466,13 +584,22 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= need) cfg = 2;
             else cfg = 3;
         }
+        if (bf) {
+            if (cfg == 1) return launch_cfg<X2Big>(p, s, scratch, scratch_floats);
+            if (cfg == 2) return launch_cfg<X2Med>(p, s, scratch, scratch_floats);
+            return launch_cfg<X2Small>(p, s, scratch, scratch_floats);
+        }
         if (cfg == 1) return launch_cfg<K2Big>(p, s, scratch, scratch_floats);
         if (cfg == 2) return launch_cfg<K2Med>(p, s, scratch, scratch_floats);
         return launch_cfg<K2Small>(p, s, scratch, scratch_floats);
     }
-    if (p.Cout <= 64) return launch_cfg<K1M64>(p, s, scratch, scratch_floats);
+    if (p.Cout <= 64) return bf ? launch_cfg<X1M64>(p, s, scratch, scratch_floats) : launch_cfg<K1M64>(p, s, scratch, scratch_floats);
     int cfg = tile_cfg;
     if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
+    if (bf) {
+        if (cfg == 1) return launch_cfg<X1Big>(p, s, scratch, scratch_floats);
+        return launch_cfg<X1Small>(p, s, scratch, scratch_floats);
+    }
     if (cfg == 1) return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
     return launch_cfg<K1Small>(p, s, scratch, scratch_floats);
 }
@@ -490,6 +617,26 @@ extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32
     return STEMSEG_OK;
 }
 
+extern "C" int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(w && packed, "pack_conv_weight_bf16x3: null pointer");
+    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_bf16x3: taps must be 27, 9 or 1");
+    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
+    SS_CHECK_ARG(Cin % CK == 0 && Cout % 32 == 0, "pack_conv_weight_bf16x3: Cin %% %d, Cout %% 32 (got %d, %d)", CK, Cin, Cout);
+    const int64_t n = stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps) / 16;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(pack_conv_weight_bf16x3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
+                       taps, CK, TPG);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t Cin, int32_t taps) {
+    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
+    const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH);
+    return (int64_t)((Cin + CK - 1) / CK) * 2 * (NTG * NCG) * 2 * Cout * 16;
+}
+
 extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
                                   int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
                                   int64_t splitk_scratch_floats, const StemsegConvEpilogue* epilogue, void* stream) {
@@ -499,6 +646,7 @@ extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w
     if (epilogue) {
         e.relu = epilogue->relu; e.res = epilogue->residual; e.res_cs = epilogue->res_c_stride; e.res_ts = epilogue->res_t_stride;
         e.res_ys = epilogue->res_y_stride; e.dec_H = epilogue->decode_H; e.dec_W = epilogue->decode_W;
+        e.precision = epilogue->precision;
     }
     return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream), splitk_scratch, splitk_scratch_floats,
                          epilogue ? &e : nullptr);

@@ -157,9 +157,11 @@ static inline StemsegVolume flat_volume(float* base, int C, int64_t V) {
 
 static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b, const float* gw, const float* gb, int Cout, int T, int H,
                    int W, int pool, const StemsegVolume& dst, float* D, float* stats, double* scratch, int G, float eps, hipStream_t s,
-                   float* splitk = nullptr, int64_t splitk_floats = 0) {
+                   float* splitk, int64_t splitk_floats, int precision) {
     StemsegVolume d = dense_volume(D, Cout, T, H, W);
-    int rc = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats);
+    ConvEpilogue e;
+    e.precision = precision;
+    int rc = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e);
     if (rc) return rc;
     rc = launch_gn_stats(D, Cout, (int64_t)T * H * W, G, eps, stats, scratch, s);
     if (rc) return rc;
@@ -251,6 +253,9 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
 
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
+    SS_CHECK_ARG(desc->precision == 0 || desc->precision == 1, "decoder: precision must be 0 (f32) or 1 (bf16x3)");
+    ConvEpilogue fuse_epi;
+    fuse_epi.precision = desc->precision;
     const float eps = desc->gn_eps;
     const int G = p.G, T = p.T;
     float* D[4]; float* stats[4]; double* scratch[4];
@@ -284,13 +289,13 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     }
     // 1. block_32x on s32: three conv/GN/ReLU(/pool) stages (embedding_decoder.py:20-35), then upsample into cat16[0:c32]
     rc = conv_gn(padded_halo_view(pin[0], p.cin, T, p.h[0], p.w[0]), wts->conv_w[0], wts->conv_b[0], wts->gn_w[0], wts->gn_b[0], p.c32, T,
-                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0]);
+                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), wts->conv_w[1], wts->conv_b[1], wts->gn_w[1], wts->gn_b[1], p.c32,
-                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0]);
+                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), wts->conv_w[2], wts->conv_b[2], wts->gn_w[2], wts->gn_b[2], p.c32,
-                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0]);
+                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2,
                          slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s32);
@@ -298,14 +303,14 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[0], s32));
     // 2. block_16x on s16 into cat16[c32:], join 32x, 1x1x1 fuse, upsample into cat8[0:c16]  (:112-117)
     rc = conv_gn(padded_halo_view(pin[1], p.cin, T, p.h[1], p.w[1]), wts->conv_w[3], wts->conv_b[3], wts->gn_w[3], wts->gn_b[3], p.c16, T,
-                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1]);
+                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), wts->conv_w[4], wts->conv_b[4], wts->gn_w[4], wts->gn_b[4], p.c16,
-                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1]);
+                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision);
     if (rc) return rc;
     const int64_t V16 = (int64_t)p.T16 * p.h[1] * p.w[1], V8 = (int64_t)p.T8 * p.h[2] * p.w[2], V4 = (int64_t)T * p.h[3] * p.w[3];
     if (bs) SS_HIP(hipStreamWaitEvent(s16, bs->done[0], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16);
+    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16, nullptr, 0, &fuse_epi);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
                          slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16);
@@ -313,20 +318,20 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[1], s16));
     // 3. block_8x on s8 into cat8[c16:], join 16x, fuse, upsample into cat4[0:c8]  (:119-123)
     rc = conv_gn(padded_halo_view(pin[2], p.cin, T, p.h[2], p.w[2]), wts->conv_w[5], wts->conv_b[5], wts->gn_w[5], wts->gn_b[5], p.c8, T, p.h[2],
-                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2]);
+                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(s8, bs->done[1], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8);
+    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, nullptr, 0, &fuse_epi);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8);
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, nullptr, 0, desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm);
+    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);
     if (rc) return rc;
     // 5. heads (:131-143)
     HeadSpec hs;

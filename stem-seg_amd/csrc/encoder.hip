@@ -250,6 +250,8 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         SS_CHECK_ARG(wts->fpn_inner_w[i] && wts->fpn_inner_b[i] && wts->fpn_layer_w[i] && wts->fpn_layer_b[i], "encoder_forward: null FPN weights %d", i);
     }
     SS_CHECK_ARG(desc->out_channels == 256, "encoder: out_channels must be 256");
+    SS_CHECK_ARG(desc->precision == 0 || desc->precision == 1, "encoder: precision must be 0 (f32) or 1 (bf16x3)");
+    const int prec = desc->precision;
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
     const int T = p.T;
@@ -282,24 +284,26 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             }
             float* y = (b == p.nblk[st] - 1) ? ws + p.Cst[st] : ((b & 1) ? ws + p.B : ws + p.A);
             ConvEpilogue e1;                    // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
-            e1.relu = 1; e1.dec_H = h; e1.dec_W = w;
+            e1.relu = 1; e1.dec_H = h; e1.dec_W = w; e1.precision = prec;
             rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1[st], mid, T, h, w), 1, 1, 1, 0, s,
                                ws + p.SK, p.SKfloats, &e1);
             if (rc) return rc;
             ConvEpilogue e2;                    // conv2 (3x3) + bn2 + relu -> dense
-            e2.relu = 1;
+            e2.relu = 1; e2.precision = prec;
             rc = launch_conv3d(halo2d_view(ws + p.M1[st], mid, T, h, w), wts->conv2_w[bi], wts->conv2_b[bi], dense_volume(ws + p.M2, mid, T, h, w), 1, 3, 3, 0, s,
                                ws + p.SK, p.SKfloats, &e2);
             if (rc) return rc;
             const float* idt = xin;
+            ConvEpilogue ed;
+            ed.precision = prec;
             if (first) {                        // projection shortcut: 1x1 (stride folded into xin) + bn
                 rc = launch_conv3d(flat_view(xin, cin, V), wts->down_w[bi], wts->down_b[bi], flat_view(ws + p.DS, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats,
-                                   nullptr);
+                                   &ed);
                 if (rc) return rc;
                 idt = ws + p.DS;
             }
             ConvEpilogue e3;                    // conv3 + bn3 + identity + relu
-            e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0;
+            e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0; e3.precision = prec;
             rc = launch_conv3d(flat_view(ws + p.M2, mid, V), wts->conv3_w[bi], wts->conv3_b[bi], flat_view(y, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats, &e3);
             if (rc) return rc;
             x = y;
@@ -309,8 +313,8 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
     // FPN (fpn.py:47-69), coarsest level first
     for (int k = 3; k >= 0; --k) {
         const int h = p.h[k], w = p.w[k];
-        ConvEpilogue e;
-        e.dec_H = h; e.dec_W = w;
+        ConvEpilogue e, el;
+        e.dec_H = h; e.dec_W = w; e.precision = prec; el.precision = prec;
         rc = launch_conv3d(flat_view(ws + p.Cst[k], 256 << k, p.V[k]), wts->fpn_inner_w[k], wts->fpn_inner_b[k], interior2d_view(ws + p.L[k], 256, T, h, w), 1, 1, 1, 0, s,
                            ws + p.SK, p.SKfloats, &e);
         if (rc) return rc;
@@ -320,7 +324,7 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
                                (const float*)(ws + p.L[k + 1] + gc.interior), (int64_t)256 * T, h, w, gf.ts, gf.pitch, gc.ts, gc.pitch);
             SS_LAUNCH_CHECK();
         }
-        rc = launch_conv3d(halo2d_view(ws + p.L[k], 256, T, h, w), wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, nullptr);
+        rc = launch_conv3d(halo2d_view(ws + p.L[k], 256, T, h, w), wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &el);
         if (rc) return rc;
     }
     return STEMSEG_OK;

@@ -28,7 +28,7 @@ class DecoderDesc(C.Structure):
                 ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
                 ("pool", C.c_int32 * 3), ("t_scale", C.c_int32 * 3), ("n_out", C.c_int32),
                 ("act", C.c_int32 * (2 * MAX_EMB_DIMS)), ("grid_axis", C.c_int32 * (2 * MAX_EMB_DIMS)),
-                ("input_layout", C.c_int32), ("concurrency", C.c_int32), ("detached", C.c_int32)]
+                ("input_layout", C.c_int32), ("concurrency", C.c_int32), ("detached", C.c_int32), ("precision", C.c_int32)]
 
 
 class DecoderWeights(C.Structure):
@@ -42,12 +42,12 @@ MAX_ENCODER_BLOCKS = 40
 
 class ConvEpilogue(C.Structure):
     _fields_ = [("relu", C.c_int32), ("residual", C.c_void_p), ("res_c_stride", C.c_int64), ("res_t_stride", C.c_int64),
-                ("res_y_stride", C.c_int64), ("decode_H", C.c_int32), ("decode_W", C.c_int32)]
+                ("res_y_stride", C.c_int64), ("decode_H", C.c_int32), ("decode_W", C.c_int32), ("precision", C.c_int32)]
 
 
 class EncoderDesc(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("blocks", C.c_int32 * 4), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("out_channels", C.c_int32)]
+                ("out_channels", C.c_int32), ("precision", C.c_int32)]
 
 
 _BLK = C.c_void_p * MAX_ENCODER_BLOCKS
@@ -81,6 +81,8 @@ SIGNATURES = {
     "stemseg_hip_profile_read": (C.c_int, [C.POINTER(C.c_double), _I32]),
     "stemseg_hip_padded_geometry": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64)]),
     "stemseg_hip_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "stemseg_hip_packed_weight_bytes_bf16x3": (C.c_int64, [_I32, _I32, _I32]),
+    "stemseg_hip_pack_conv_weight_bf16x3": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
     "stemseg_hip_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "stemseg_hip_encoder_init_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, _P]),
@@ -212,6 +214,23 @@ def pack_conv_weight(w):
     return out
 
 
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+
+def pack_conv_weight_any(w, precision="f32"):
+    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA) or 'bf16x3' (3-term bf16 split, fp32 accumulate)."""
+    if precision == "f32":
+        return pack_conv_weight(w)
+    assert precision == "bf16x3", precision
+    w = w.contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    nbytes = lib().stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps)
+    out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)      # opaque 16-B-aligned blob
+    check(lib().stemseg_hip_pack_conv_weight_bf16x3(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, stream()))
+    return out
+
+
 def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None, epilogue=None):
     """k: int (k x k x k) or a (kt, kh, kw) tuple; epilogue: dict(relu=, residual=tensor, res_strides=(c,t,y), decode=(H,W))."""
     n = 0 if splitk_scratch is None else splitk_scratch.numel()
@@ -225,6 +244,7 @@ def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None, epilog
             e.residual = r.data_ptr()
             e.res_c_stride, e.res_t_stride, e.res_y_stride = epilogue["res_strides"]
         e.decode_H, e.decode_W = epilogue.get("decode", (0, 0))
+        e.precision = PRECISIONS[epilogue.get("precision", "f32")]
     check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), kt, kh, kw, tile_cfg,
                                    ptr(splitk_scratch), n, C.byref(e) if e is not None else None, stream()))
 

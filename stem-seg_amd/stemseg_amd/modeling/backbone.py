@@ -101,6 +101,7 @@ class ResNetFPN(nn.Module):
         self.fpn = _FPN(out_channels)
         self.out_channels, self.is_3d = out_channels, False
         self._packed, self._sig, self._ws = None, None, {}
+        self.precision = "f32"    # "f32" | "bf16x3" (see stemseg_hip.h)
 
     # ---- FrozenBN folding: w' = w * scale[:, None, None, None], b' = shift (exact: eps == 0) -------------------
     def _signature(self):
@@ -134,7 +135,7 @@ class ResNetFPN(nn.Module):
         return f
 
     def _pack(self):
-        sig = self._signature()
+        sig = (self._signature(), self.precision)
         if self._sig == sig:
             return self._packed
         hip.require_gpu()
@@ -149,7 +150,7 @@ class ResNetFPN(nn.Module):
 
         def packed(name):
             wt, b = f[name]
-            pw, pb = hip.pack_conv_weight(dev(wt)), dev(b)
+            pw, pb = hip.pack_conv_weight_any(dev(wt), self.precision), dev(b)
             keep.append(pw)
             return pw.data_ptr(), pb.data_ptr()
         sw, sb = f["stem"]
@@ -173,6 +174,7 @@ class ResNetFPN(nn.Module):
         for i, n in enumerate(self.stage_blocks):
             d.blocks[i] = n
         d.T, d.H, d.W, d.out_channels = T, H, W, self.out_channels
+        d.precision = hip.PRECISIONS[self.precision]
         return d
 
     @torch.no_grad()

@@ -63,6 +63,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
         self.detached = False     # True: the call does not join; ``join()`` must follow (twin-decoder overlap)
+        self.precision = "f32"    # "f32": exact fp32 MFMA | "bf16x3": 3-term bf16 split MFMA with fp32 accumulation
 
     # ---- to be provided by the concrete decoder ---------------------------------------------------
     def _head_spec(self):
@@ -74,18 +75,18 @@ class SqueezeExpandTrunk(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _packed(self):
-        sig = self._param_signature()
+        sig = (self._param_signature(), self.precision)
         c = self._cache
         if c.get("sig") != sig:
             dev = next(self.parameters()).device
             conv_w, conv_b, gn_w, gn_b = [], [], [], []
             for blk, idx in _BLOCK_CONVS:
                 conv, gn = getattr(self, blk)[idx], getattr(self, blk)[idx + 1]
-                conv_w.append(hip.pack_conv_weight(conv.weight.detach().float()))
+                conv_w.append(hip.pack_conv_weight_any(conv.weight.detach().float(), self.precision))
                 conv_b.append(conv.bias.detach().float().contiguous())
                 gn_w.append(gn.weight.detach().float().contiguous())
                 gn_b.append(gn.bias.detach().float().contiguous())
-            fuse = [hip.pack_conv_weight(m.weight.detach().float()) for m in (self.conv_16, self.conv_8, self.conv_4)]
+            fuse = [hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8, self.conv_4)]
             hw, hb, act, axes = self._head_spec()
             c.clear()
             c.update(sig=sig, conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, fuse=fuse,
@@ -137,6 +138,7 @@ class SqueezeExpandTrunk(nn.Module):
         d.input_layout = layout
         d.concurrency = int(self.concurrency)
         d.detached = int(bool(self.detached) and self.concurrency >= 1)
+        d.precision = hip.PRECISIONS[self.precision]
         key = (T, H4, W4, layout, dev.index)
         ws = self._workspaces.get(key)
         if ws is None:

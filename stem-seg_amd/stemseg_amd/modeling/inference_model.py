@@ -103,6 +103,14 @@ class InferenceModel(nn.Module):
 
     has_semseg_head = property(lambda self: False)
 
+    def set_precision(self, precision):
+        """'f32' (exact fp32 MFMA, default) or 'bf16x3' (3-term bf16 split on the bf16 matrix cores, fp32 accumulate)."""
+        assert precision in hip.PRECISIONS, precision
+        m = self._model
+        for mod in (m.backbone, m.embedding_head, m.seediness_head):
+            if mod is not None:
+                mod.precision = precision
+
     # ---- one clip ----------------------------------------------------------------------------------
     def _padded_feature_buffers(self, T, H, W, dev):
         """Four zero-haloed buffers [256][T+2][h+2][pitch], allocated once per shape (halos stay zero)."""

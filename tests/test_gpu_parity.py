@@ -90,6 +90,43 @@ def test_conv3d_k1(hip, cfg, shape):
     assert report("conv3d_k1 cfg%d %s" % (cfg, shape), out.cpu().numpy(), ref.numpy()) <= 2e-4
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["k3", "k2", "k1"])
+def test_conv_bf16x3_split_mfma(hip, kind, cfg):
+    """bf16x3 mode (x = hi + lo in bf16; a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores, fp32 accumulate):
+    every kernel class and tile shape vs the fp32 torch reference, same tolerance as the exact-fp32 kernels."""
+    rs = 31 + cfg
+    if kind == "k1":
+        if cfg == 3:
+            pytest.skip("1x1 has two tile shapes")
+        Cin, Cout, V = 256, 128, 4 * 30 * 54
+        x = _rand((Cin, V), rs)
+        w = _rand((Cout, Cin, 1, 1, 1), rs + 1, 1.0 / np.sqrt(Cin))
+        b = _rand((Cout,), rs + 2)
+        ref = (torch.from_numpy(w.reshape(Cout, Cin)) @ torch.from_numpy(x) + torch.from_numpy(b)[:, None]).numpy()
+        out = torch.full((Cout, V), float("nan"), device="cuda")
+        hip.conv3d(hip.flat_volume(dev(x)), hip.pack_conv_weight_any(dev(w), "bf16x3"), dev(b), hip.flat_volume(out), 1, cfg, None, dict(precision="bf16x3"))
+    else:
+        Cin, Cout, T, H, W = (64, 128, 3, 9, 40) if kind == "k3" else (64, 128, 2, 17, 70)
+        x = _rand((Cin, T, H, W), rs)
+        kt = 3 if kind == "k3" else 1
+        w = _rand((Cout, Cin, kt, 3, 3), rs + 1, 1.0 / np.sqrt(Cin * 9 * kt))
+        b = _rand((Cout,), rs + 2)
+        ref = F.conv3d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), padding=(kt // 2, 1, 1))[0].numpy()
+        if kind == "k3":
+            buf, g = hip.alloc_padded(Cin, T, H, W)
+            hip.copy_to_volume(dev(x), 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
+            vin = hip.padded_halo_view(buf, g, Cin, T, H, W)
+        else:
+            pitch = (W + 2 + 3) // 4 * 4
+            buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
+            buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
+            vin = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel())
+        out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        hip.conv3d(vin, hip.pack_conv_weight_any(dev(w), "bf16x3"), dev(b), hip.dense_volume(out), (kt, 3, 3), cfg, None, dict(precision="bf16x3"))
+    assert report("conv %s bf16x3 cfg%d" % (kind, cfg), out.cpu().numpy(), ref) <= 2e-4
+
+
 @pytest.mark.parametrize("shape", [(8, 64, 2, 9, 37), (64, 64, 3, 17, 40), (256, 256, 2, 6, 27), (128, 128, 8, 30, 54)])
 def test_conv2d_3x3_fused_epilogue(hip, shape):
     """(1,3,3) conv over every t-plane (= the encoder's frames) with bias + ReLU fused, zero-haloed 2-D input."""
@@ -158,10 +195,12 @@ def test_encoder_vs_golden(hip, golden, btype):
         assert report("encoder %s 1/%d (rel to max %.3g)" % (btype, s, scale), got / scale, ref / scale) <= 1e-4
 
 
-def test_encoder_batch_of_8_odd_size_vs_oracle(hip):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_encoder_batch_of_8_odd_size_vs_oracle(hip, precision):
     """T = 8 frames, 96 x 160 (w32 = 5: ragged 32-column tiles everywhere), R-50, vs the CPU oracle."""
     from stemseg_amd.modeling.backbone import ResNetFPN
     bb = ResNetFPN("R-50-FPN").eval()
+    bb.precision = precision
     sd = synth.synth_state_dict([(k, v.shape) for k, v in bb.state_dict().items()], 51, prefix="backbone.")
     bb.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(bb.state_dict()[k].shape) for k, v in sd.items()})
     x = torch.from_numpy(synth.synth_frames(8, 96, 160, seed=51).astype(np.float32)).permute(0, 3, 1, 2) - \
@@ -170,7 +209,7 @@ def test_encoder_batch_of_8_odd_size_vs_oracle(hip):
     feats = bb.cuda().run_backbone(x.cuda())
     for s in (4, 8, 16, 32):
         scale = max(1.0, float(ref[s].abs().max()))
-        assert report("encoder T=8 96x160 1/%d" % s, feats[s].cpu().numpy() / scale, ref[s].numpy() / scale) <= 1e-4
+        assert report("encoder T=8 96x160 1/%d %s" % (s, precision), feats[s].cpu().numpy() / scale, ref[s].numpy() / scale) <= 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ GN / pool / upsample / heads
@@ -295,16 +334,18 @@ def test_seediness_decoder_vs_golden(hip, golden, T):
     assert np.array_equal(a, b), "decoder is not run-to-run deterministic"
 
 
-def test_decoder_full_size_480x864_vs_oracle(hip):
-    """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle."""
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_decoder_full_size_480x864_vs_oracle(hip, precision):
+    """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle, both MFMA modes."""
     T, h32, w32 = 8, 15, 27
     head = _emb_head("xyff", 4, True, False, T, 41)
+    head.precision = precision
     sd = synth.synth_state_dict(odec.decoder_param_shapes("embedding_head.", mode="xyff", embedding_size=4), 41)
     feats = synth.synth_features(T, h32, w32, seed=41)
     ref = odec.embedding_decoder(feats, sd, "xyff", True).numpy()
     out = head([dev(f)[None] for f in feats])[0].cpu().numpy()
     assert out.shape == (6, 8, 120, 216)
-    assert report("decoder 480x864", out, ref) <= 1e-3
+    assert report("decoder 480x864 %s" % precision, out, ref) <= 1e-3
 
 
 # ------------------------------------------------------------------------------------------------ fg mask / gather
@@ -481,7 +522,8 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
-def test_clip_pipeline_end_to_end_vs_oracle(hip):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_clip_pipeline_end_to_end_vs_oracle(hip, precision):
     """One clip through ClipPipeline.step (the bench's unit of work) at a reduced size vs the oracle pipeline:
     float outputs <= 1e-3; labels identical wherever the oracle's own decision has margin."""
     from stemseg_amd import config
@@ -495,6 +537,7 @@ def test_clip_pipeline_end_to_end_vs_oracle(hip):
     sd["seediness_head.conv_out.weight"] = sd["seediness_head.conv_out.weight"] * 30      # spread seediness over (0, 1)
     model._model.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(model._model.state_dict()[k].shape) for k, v in sd.items()})
     pipe = ClipPipeline(model)
+    model.set_precision(precision)
     frames = torch.from_numpy(synth.synth_frames(8, 96, 160, seed=33).astype(np.float32)).permute(0, 3, 1, 2) - \
         torch.tensor(config.cfg.INPUT.IMAGE_MEAN)[None, :, None, None]
     out = pipe.step(frames.cuda())
