@@ -101,6 +101,9 @@ def cpu_baseline(sd, frames_cpu):
 
 
 def main():
+    if os.environ.get("STEMSEG_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["STEMSEG_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -108,7 +111,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="MFMA mode of every convolution: exact fp32 (default) or the 3-term bf16 split (fp32 accumulate)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a captured hipGraph of the step instead of launching eagerly (experimental: ~10 %% faster, but "
+                         "graph replay was seen to fault intermittently on this ROCm build, so it is opt-in)")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
 
@@ -148,7 +154,7 @@ def main():
     # streams, fg mask, gather, clustering rounds) and replayed per clip: the launch-bound tail of small kernels no
     # longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
     graph, static_in, static_out = None, None, None
-    if not args.no_graph:
+    if args.graph and not args.no_graph:
         try:
             # inside the captured graph every launch sits on ONE stream: measured, the fork/join branch streams give no
             # throughput here (each conv already fills the chip) and HIP's capture rejects the multi-stream fork/join
