@@ -100,6 +100,11 @@ def cpu_baseline(sd, frames_cpu):
                       % (BACKBONE, out["labels"].shape[0], len(out["meta"]["instance_labels"]))}
 
 
+def mark(msg):
+    if os.environ.get("STEMSEG_BENCH_WATCHDOG"):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def main():
     if os.environ.get("STEMSEG_BENCH_WATCHDOG"):       # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
@@ -122,11 +127,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True          # MIOpen find mode for the (still torch-op) encoder convs
@@ -143,13 +149,16 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     meta = None
+    if args.graph:
+        pipe.model.overlap_decoders = False      # the captured graph is single-stream; warm up in the same mode
     for i in range(max(args.warmup, 1)):
         meta = step(i)
     sync()
+    mark("warmup done")
     # The ~250 launches of a step are captured ONCE into a hipGraph (encoder, both decoders with their fork/join branch
     # streams, fg mask, gather, clustering rounds) and replayed per clip: the launch-bound tail of small kernels no
     # longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
@@ -171,6 +180,7 @@ def main():
                 static_out = pipe.step(static_in)
             graph = g
             torch.cuda.synchronize()
+            mark("capture done")
         except Exception as e:  # noqa: BLE001
             import traceback
             traceback.print_exc()
@@ -187,6 +197,7 @@ def main():
     run = step_graph if graph is not None else step
     for i in range(2):
         meta = run(i)
+        mark("pre-run %d done" % i)
     sync()
     hip.profile_enable(graph is None)
     t0 = time.perf_counter()
@@ -194,6 +205,7 @@ def main():
         meta = run(i)
     sync()
     dt = time.perf_counter() - t0
+    mark("timed region done")
     hip.profile_enable(True)
     prof_concurrent = hip.profile_read()
     # Roofline pass: under stream concurrency the per-launch elapsed times overlap and are not additive, so the dominant
@@ -208,7 +220,7 @@ def main():
     prof = hip.profile_read()
     hip.profile_enable(False)
     pipe.model.overlap_decoders = True
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -248,7 +260,7 @@ def main():
             except Exception as e:  # noqa: BLE001  (never lose the GPU number because the baseline leg failed)
                 res["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
