@@ -120,6 +120,7 @@ def main():
                     help="replay a captured hipGraph of the step instead of launching eagerly (experimental: ~10 %% faster, but "
                          "graph replay was seen to fault intermittently on this ROCm build, so it is opt-in)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
 
@@ -153,8 +154,9 @@ def main():
             dist.barrier()
 
     meta = None
-    if args.graph:
-        pipe.model.overlap_decoders = False      # the captured graph is single-stream; warm up in the same mode
+    overlap = not (args.graph or args.no_overlap)
+    if not overlap:
+        pipe.model.overlap_decoders = False      # (the captured graph is single-stream; warm up in the same mode)
     for i in range(max(args.warmup, 1)):
         meta = step(i)
     sync()
@@ -186,7 +188,7 @@ def main():
             traceback.print_exc()
             print("[bench] hipGraph capture failed (%r); falling back to eager launches" % (e,), file=sys.stderr)
             graph = None
-            pipe.model.overlap_decoders = True
+            pipe.model.overlap_decoders = overlap
             torch.cuda.synchronize()
 
     def step_graph(i):
@@ -219,7 +221,7 @@ def main():
         step(i)
     prof = hip.profile_read()
     hip.profile_enable(False)
-    pipe.model.overlap_decoders = True
+    pipe.model.overlap_decoders = overlap
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -154,7 +154,9 @@ typedef struct StemsegDecoderDesc {
     float   gn_eps;              /* 1e-5                                                                    */
     int32_t pool[3];             /* common.py:8-24 : is temporal pooling layer i active (T=8: 1,1,0)        */
     int32_t t_scale[3];          /* common.py:27-35: temporal up-sampling factors (T=8: 1,2,2)              */
-    int32_t n_out;               /* head output channels (emb + var + seed, or 1 for the seediness decoder)  */
+    int32_t n_out;               /* head output channels: 1..8 = fused heads kernel (emb + var + seed / seediness);
+                                    a multiple of 32 = plain linear head through the 1x1x1 MFMA conv (semseg logits,
+                                    semseg_decoder.py:116; weights->head_w is then a packed conv weight, act is ignored) */
     int32_t act[STEMSEG_MAX_EMB_DIMS * 2];        /* per output channel, see stemseg_hip_heads          */
     int32_t grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
     int32_t input_layout;        /* 0: [C][T][h][w] dense, 1: [T][C][h][w] dense, 2: already zero-haloed     */
@@ -291,6 +293,30 @@ int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t* labels_b,
 
 /* in-place relabel: labels[i] = map[labels[i] + 1] for labels[i] + 1 in [0, map_len) (online_chainer.py:219-229) */
 int stemseg_hip_relabel(int64_t* labels, int64_t n, const int64_t* map, int32_t map_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Semantic-segmentation side (datasets with MODEL.USE_SEMSEG_HEAD: youtube_vis.yaml, kitti_mots_*.yaml).
+ * ---------------------------------------------------------------------------------------------- */
+#define STEMSEG_MAX_CLIP_FRAMES 32
+#define STEMSEG_SEMSEG_NONE 0     /* foreground probability only                                   */
+#define STEMSEG_SEMSEG_LOGITS 1   /* multiclass: mean class logits, float [F][C-1][HW]            */
+#define STEMSEG_SEMSEG_PROBS 2    /* multiclass: softmax over the classes, float [F][C-1][HW]     */
+#define STEMSEG_SEMSEG_ARGMAX 3   /* multiclass: class index, int64 [F][HW]                       */
+
+/* inference_model.py:121-128: acc[frame_index[t]][c][:] += clip_logits[c][t][:] for the T slots of one clip.
+ * acc: [n_frames][C][HW], ZERO-initialised by the caller before the first clip (the reference starts each frame's sum from
+ * the float 0., :80); clip_logits: the semseg decoder's output [C][T][HW]; frame_index: HOST array of T frame numbers, -1 =
+ * skip the slot; the non-negative entries of one call must be distinct (a clip that repeats a frame, inference/main.py:37-39,
+ * is accumulated with one call per repetition so that the per-frame order of the fp32 adds stays slot order, :126-128). */
+int stemseg_hip_semseg_accumulate(float* acc, const float* clip_logits, int32_t C, int32_t T, int64_t HW,
+                                  const int32_t* frame_index, int32_t n_frames, void* stream);
+
+/* InferenceModel.get_semseg_masks (inference_model.py:197-231) on the accumulated sums: mean = acc / counts[f] (device
+ * float [F]); C > 2: fg = sigmoid(mean[C-1]), multiclass from mean[0..C-2] per output_type; C == 2: fg = softmax(mean)[1]
+ * and no multiclass output (the reference then fails on `[].cpu()`, :231 -- here the buffer is simply left untouched).
+ * fg: float [F][HW]. */
+int stemseg_hip_semseg_masks(const float* acc, const float* counts, int32_t F, int32_t C, int64_t HW, int32_t output_type,
+                             float* fg, void* multiclass, void* stream);
 
 #ifdef __cplusplus
 }

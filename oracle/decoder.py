@@ -119,8 +119,37 @@ def seediness_decoder(feats, sd, prefix="seediness_head."):
     return F.conv3d(x, _t(sd[prefix + "conv_out.weight"])).sigmoid()[0]
 
 
+@torch.no_grad()
+def semseg_decoder(feats, sd, prefix="semseg_head."):
+    """semseg_decoder.py:93-116 -> raw class logits [num_classes(+1), T, H/4, W/4].  NOTE the reference's forward takes
+    its list ordered 4x, 8x, 16x, 32x and reverses it (:93); ``feats`` here is ALREADY 32x, 16x, 8x, 4x (trunk order)."""
+    feats = [_t(f).float() for f in feats]
+    feats = [f[None] if f.dim() == 4 else f for f in feats]
+    x = trunk(feats, sd, prefix, feats[0].shape[2])
+    return F.conv3d(x, _t(sd[prefix + "conv_out.weight"]))[0]
+
+
+@torch.no_grad()
+def semseg_masks(mean_logits, output_type="probs"):
+    """inference_model.py:197-231 on per-frame MEAN logits [T, C, H, W]: C > 2 -> last channel is the fg logit
+    (sigmoid), the rest are class logits (logits | softmax | argmax); C == 2 -> fg = softmax[:, 1], no class map."""
+    x = _t(mean_logits).float()
+    if x.shape[1] > 2:
+        multi, fg = x.split((x.shape[1] - 1, 1), dim=1)
+        if output_type == "logits":
+            mc = multi
+        elif output_type == "probs":
+            mc = F.softmax(multi, dim=1)
+        elif output_type == "argmax":
+            mc = multi.argmax(dim=1)
+        else:
+            mc = None
+        return fg.squeeze(1).sigmoid(), mc
+    return F.softmax(x, dim=1)[:, 1], None
+
+
 def decoder_param_shapes(prefix, inter=(256, 256, 128, 128), cin=256, kind="embedding", mode="xyff",
-                         embedding_size=4, seediness_output=False):
+                         embedding_size=4, seediness_output=False, n_classes=1):
     """(key, shape) list in the reference's state-dict naming."""
     c32, c16, c8, c4 = inter
     out = []
@@ -148,6 +177,8 @@ def decoder_param_shapes(prefix, inter=(256, 256, 128, 128), cin=256, kind="embe
         if seediness_output:
             out.append((prefix + "conv_seediness.weight", (1, c4, 1, 1, 1)))
         out.append((prefix + "time_scale", ()))
+    elif kind == "semseg":
+        out.append((prefix + "conv_out.weight", (n_classes, c4, 1, 1, 1)))     # n_classes incl. the fg channel if any
     else:
         out.append((prefix + "conv_out.weight", (1, c4, 1, 1, 1)))
     return out

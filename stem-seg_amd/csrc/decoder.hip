@@ -73,7 +73,8 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     SS_CHECK_ARG(d->in_channels % 4 == 0 && d->in_channels > 0, "decoder: in_channels %% 4");
     for (int i = 0; i < 4; ++i) SS_CHECK_ARG(d->inter[i] > 0 && d->inter[i] % 32 == 0 && d->inter[i] % d->gn_groups == 0,
                                              "decoder: inter[%d]=%d must be a multiple of 32 and of gn_groups", i, d->inter[i]);
-    SS_CHECK_ARG(d->n_out >= 1 && d->n_out <= 8, "decoder: n_out=%d", d->n_out);
+    SS_CHECK_ARG((d->n_out >= 1 && d->n_out <= 8) || (d->n_out <= 256 && d->n_out % 32 == 0),
+                 "decoder: n_out=%d (1..8 through the fused heads kernel, or a multiple of 32 <= 256 through the 1x1x1 MFMA conv)", d->n_out);
     SS_CHECK_ARG(d->input_layout >= 0 && d->input_layout <= 2, "decoder: input_layout");
     p.cin = d->in_channels; p.c32 = d->inter[0]; p.c16 = d->inter[1]; p.c8 = d->inter[2]; p.c4 = d->inter[3];
     p.T = d->T; p.G = d->gn_groups;
@@ -334,11 +335,18 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);
     if (rc) return rc;
     // 5. heads (:131-143)
-    HeadSpec hs;
-    hs.n_out = desc->n_out;
-    for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
-    rc = launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm);
-    if (rc) return rc;
+    if (desc->n_out > 8) {
+        // wide linear head (semseg_decoder.py:116: conv_out, class logits, no activation): the 1x1x1 MFMA conv; head_w is
+        // then a PACKED conv weight with Cout = n_out (zero-padded to a multiple of 32 by the caller), head_b may be NULL
+        rc = launch_conv3d(flat_volume(ws + p.X4, p.c4, V4), wts->head_w, wts->head_b, flat_volume(out, desc->n_out, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);
+        if (rc) return rc;
+    } else {
+        HeadSpec hs;
+        hs.n_out = desc->n_out;
+        for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
+        rc = launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm);
+        if (rc) return rc;
+    }
     if (detached) SS_HIP(hipEventRecord(bs->done[3], sm));
     else if (bs) {
         // join every branch stream DIRECTLY into the caller's stream as well (stream capture only recognises direct joins

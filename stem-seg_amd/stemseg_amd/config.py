@@ -17,6 +17,8 @@ def _defaults():
             RESNETS=NS(BACKBONE_OUT_CHANNELS=256),
             EMBEDDINGS=NS(HEAD_TYPE="squeeze_expand_decoder", INTER_CHANNELS=[256, 256, 128, 128], SCALE=[32, 16, 8, 4],
                           EMBEDDING_SIZE=3, TANH_ACTIVATION=True, NORMALIZATION_LAYER="gn", GN_NUM_GROUPS=32, POOL_TYPE="avg"),
+            SEMSEG=NS(HEAD_TYPE="squeeze_expand_decoder", FEATURE_SCALE=[4, 8, 16, 32], INTER_CHANNELS=[256, 256, 128, 128],
+                      NORMALIZATION_LAYER="gn", GN_NUM_GROUPS=32, POOL_TYPE="avg", FOREGROUND_CHANNEL=True),
             SEEDINESS=NS(HEAD_TYPE="squeeze_expand_decoder", INTER_CHANNELS=[256, 256, 128, 128], FEATURE_SCALE=[32, 16, 8, 4],
                          NORMALIZATION_LAYER="gn", GN_NUM_GROUPS=32, POOL_TYPE="avg"),
         ),
@@ -36,6 +38,7 @@ def _apply(c, preset):
         c.INPUT.MIN_DIM, c.INPUT.MAX_DIM, c.INPUT.NUM_FRAMES, c.INPUT.NUM_CLASSES = 640, 1196, 8, 41
         c.MODEL.EMBEDDING_DIM_MODE, c.MODEL.USE_SEEDINESS_HEAD, c.MODEL.USE_SEMSEG_HEAD = "xyff", False, True
         c.MODEL.EMBEDDINGS.EMBEDDING_SIZE = 4
+        c.MODEL.SEMSEG.INTER_CHANNELS = [256, 256, 256, 256]
         c.TRAINING.LOSSES.EMBEDDING.FREE_DIM_STDS = [0.3, 0.3]
     elif preset == "kittimots":     # config/kitti_mots_2.yaml
         c.INPUT.MIN_DIM, c.INPUT.MAX_DIM, c.INPUT.NUM_FRAMES, c.INPUT.NUM_CLASSES = 736, 1792, 8, 3

@@ -103,7 +103,11 @@ SIGNATURES = {
     "stemseg_hip_cluster": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, C.POINTER(ClusterParams), _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "stemseg_hip_overlap_counts": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "stemseg_hip_relabel": (C.c_int, [_P, _I64, _P, _I32, _P]),
+    "stemseg_hip_semseg_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I64, C.POINTER(C.c_int32), _I32, _P]),
+    "stemseg_hip_semseg_masks": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _P, _P, _P]),
 }
+
+SEMSEG_OUTPUT_TYPES = {None: 0, "none": 0, "logits": 1, "probs": 2, "argmax": 3}
 
 _lib = None
 
@@ -368,3 +372,27 @@ def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):
 
 def relabel(labels, mapping):
     check(lib().stemseg_hip_relabel(ptr(labels, torch.int64), labels.numel(), ptr(mapping, torch.int64), mapping.numel(), stream()))
+
+
+def semseg_accumulate(acc, clip_logits, frame_index):
+    """acc [F,C,H,W] (zero-initialised) += clip_logits [C,T,H,W] at the clip's frames (host list of T distinct ints)."""
+    require_gpu()
+    Cn, T, H, W = clip_logits.shape
+    assert acc.is_contiguous() and clip_logits.is_contiguous() and tuple(acc.shape[1:]) == (Cn, H, W)
+    idx = (C.c_int32 * T)(*[int(t) for t in frame_index])
+    check(lib().stemseg_hip_semseg_accumulate(ptr(acc, torch.float32), ptr(clip_logits, torch.float32), Cn, T, H * W, idx, acc.shape[0], stream()))
+
+
+def semseg_masks(acc, counts, output_type="probs"):
+    """acc [F,C,H,W], counts float32 [F] (device) -> (fg [F,H,W] float32, multiclass | None); inference_model.py:197-231."""
+    require_gpu()
+    Fn, Cn, H, W = acc.shape
+    code = SEMSEG_OUTPUT_TYPES[output_type]
+    fg = torch.empty(Fn, H, W, dtype=torch.float32, device=acc.device)
+    mc = None
+    if Cn > 2 and code == 3:
+        mc = torch.empty(Fn, H, W, dtype=torch.int64, device=acc.device)
+    elif Cn > 2 and code in (1, 2):
+        mc = torch.empty(Fn, Cn - 1, H, W, dtype=torch.float32, device=acc.device)
+    check(lib().stemseg_hip_semseg_masks(ptr(acc, torch.float32), ptr(counts, torch.float32), Fn, Cn, H * W, code, ptr(fg), ptr(mc) if mc is not None else None, stream()))
+    return fg, mc

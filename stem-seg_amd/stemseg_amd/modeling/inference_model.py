@@ -25,6 +25,7 @@ from .backbone import BACKBONE_REGISTRY
 from .embedding_decoder import EMBEDDING_HEAD_REGISTRY
 from .embedding_utils import get_nb_free_dims  # noqa: F401  (re-export, as in the reference's import surface)
 from .seediness_decoder import SEEDINESS_HEAD_REGISTRY
+from .semseg_decoder import SEMSEG_HEAD_REGISTRY
 
 EmbeddingMapEntry = namedtuple("EmbeddingMapEntry", ["subseq_frames", "embeddings", "bandwidths", "seediness"])
 
@@ -65,7 +66,7 @@ def preprocess_frames(frames, device="cuda"):
 
 
 def build_model():
-    """backbone + heads from the global cfg (model_builder.py:247-369 minus losses / semseg head)."""
+    """backbone + heads from the global cfg (model_builder.py:247-369 minus the losses)."""
     m = nn.Module()
     m.backbone = BACKBONE_REGISTRY[cfg.MODEL.BACKBONE.TYPE](cfg)
     e = cfg.MODEL.EMBEDDINGS
@@ -81,6 +82,13 @@ def build_model():
         m.seediness_head = SEEDINESS_HEAD_REGISTRY[s.HEAD_TYPE](
             m.backbone.out_channels, s.INTER_CHANNELS, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(s.GN_NUM_GROUPS, c))
     m.semseg_head = None
+    if cfg.MODEL.USE_SEMSEG_HEAD:
+        g = cfg.MODEL.SEMSEG
+        assert g.NORMALIZATION_LAYER == "gn" and g.POOL_TYPE == "avg"
+        m.semseg_head = SEMSEG_HEAD_REGISTRY[g.HEAD_TYPE](
+            m.backbone.out_channels, cfg.INPUT.NUM_CLASSES, inter_channels=g.INTER_CHANNELS, feature_scales=g.FEATURE_SCALE,
+            foreground_channel=g.FOREGROUND_CHANNEL, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(g.GN_NUM_GROUPS, c))
+        m.semseg_feature_map_scale = list(g.FEATURE_SCALE)
     m.embedding_head_feature_map_scale = list(e.SCALE)
     return m
 
@@ -95,19 +103,20 @@ class InferenceModel(nn.Module):
             sd = torch.load(restore_path, map_location="cpu")['model']
             self._model.load_state_dict(sd, strict=False)
         self.resize_scale = resize_scale
+        self.semseg_output_type = semseg_output_type
         self.outputs_on_cpu = outputs_on_cpu
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
         self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
         self.eval()
 
-    has_semseg_head = property(lambda self: False)
+    has_semseg_head = property(lambda self: self._model.semseg_head is not None)
 
     def set_precision(self, precision):
         """'f32' (exact fp32 MFMA, default) or 'bf16x3' (3-term bf16 split on the bf16 matrix cores, fp32 accumulate)."""
         assert precision in hip.PRECISIONS, precision
         m = self._model
-        for mod in (m.backbone, m.embedding_head, m.seediness_head):
+        for mod in (m.backbone, m.embedding_head, m.seediness_head, m.semseg_head):
             if mod is not None:
                 mod.precision = precision
 
@@ -183,6 +192,40 @@ class InferenceModel(nn.Module):
                 seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return emb, bw, seed
 
+    @torch.no_grad()
+    def semseg_logits_clip(self, T, H, W, dev):
+        """Class logits [C, T, h4*r, w4*r] of the clip whose features sit in the zero-haloed buffers (inference_model.py:121-124)."""
+        sh = self._model.semseg_head
+        sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
+        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev)], (T, H // 4, W // 4)), 2)
+        if self.resize_scale != 1.0:
+            logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+        return logits.contiguous()
+
+    @staticmethod
+    def _accumulate_semseg(acc, counts, logits, sub):
+        """semseg_logits[t][0] += logits[i]; [1] += 1 for every slot i of the clip, duplicates included (:126-128): one
+        launch per 'occurrence rank' so that no launch adds twice into the same frame and per-frame order stays slot order."""
+        seen, rank = {}, []
+        for t in sub:
+            rank.append(seen.get(t, 0))
+            seen[t] = rank[-1] + 1
+            counts[t] += 1
+        for r in range(max(rank) + 1):
+            hip.semseg_accumulate(acc, logits, [t if k == r else -1 for t, k in zip(sub, rank)])
+
+    @torch.no_grad()
+    def get_semseg_masks(self, acc, counts):
+        """(fg_masks [F,h,w] float, multiclass_masks) from the accumulated logits (inference_model.py:197-231); with a
+        2-channel head the reference crashes on the empty multiclass list (:231) -- an empty list is returned instead."""
+        if acc is None:
+            return [], []
+        cnt = torch.as_tensor(counts, dtype=torch.float32).to(acc.device)
+        fg, mc = hip.semseg_masks(acc, cnt, self.semseg_output_type)
+        if self.outputs_on_cpu:
+            fg, mc = fg.cpu(), (mc.cpu() if mc is not None else None)
+        return fg, (mc if mc is not None else [])
+
     def _side_stream(self, dev):
         if getattr(self, "_side", None) is None:
             self._side = {}
@@ -206,6 +249,7 @@ class InferenceModel(nn.Module):
             for t in sub:
                 deps.setdefault(t, set()).add(i)
         maps = []
+        acc, counts = None, [0] * len(frames)
         for i, sub in enumerate(subseq_idxes):
             need = sorted(set(t for t in sub if t not in cache))
             if need:
@@ -213,6 +257,11 @@ class InferenceModel(nn.Module):
                 for j, t in enumerate(need):
                     cache[t] = {s: f[:, j] for s, f in zip((4, 8, 16, 32), feats)}
             emb, bw, seed = self.embed_clip([cache[t] for t in sub], len(sub), H, W)
+            if self.has_semseg_head:                                                    # same zero-haloed inputs, third decoder
+                logits = self.semseg_logits_clip(len(sub), H, W, emb.device)
+                if acc is None:
+                    acc = torch.zeros((len(frames), logits.shape[0]) + tuple(logits.shape[2:]), dtype=torch.float32, device=logits.device)
+                self._accumulate_semseg(acc, counts, logits, sub)
             uniq = sorted(set(sub))
             if len(uniq) != len(sub):                                                   # dict semantics of :137-138: last slot wins
                 sel = torch.as_tensor([max(j for j, v in enumerate(sub) if v == t) for t in uniq], device=emb.device)
@@ -225,4 +274,5 @@ class InferenceModel(nn.Module):
                 if not deps[t]:
                     cache.pop(t, None)
                     del deps[t]
-        return {"fg_masks": [], "multiclass_masks": [], "embeddings": maps}
+        fg_masks, multiclass_masks = self.get_semseg_masks(acc, counts)
+        return {"fg_masks": fg_masks, "multiclass_masks": multiclass_masks, "embeddings": maps}

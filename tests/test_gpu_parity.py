@@ -348,6 +348,116 @@ def test_decoder_full_size_480x864_vs_oracle(hip, precision):
     assert report("decoder 480x864 %s" % precision, out, ref) <= 1e-3
 
 
+# ------------------------------------------------------------------------------------------------ semseg head
+def _semseg_head(ncls, fg, ws, inter=(128, 128, 64, 64)):
+    from stemseg_amd.modeling.semseg_decoder import SqueezeExpandDecoder as Sem
+    m = Sem(256, ncls, list(inter), (4, 8, 16, 32), foreground_channel=bool(fg), NormType=_gn, num_frames=8)
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in m.state_dict().items()], ws, prefix="semseg_head.")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(m.state_dict()[k].shape) for k, v in sd.items()})
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("name", ["sem_bin", "sem_kitti", "sem_ytvis"])
+def test_semseg_decoder_vs_golden(hip, golden, name, precision):
+    """2 / 3+1 channels go through the fused heads kernel, 40+1 through the 1x1x1 MFMA conv (zero-padded to 64 rows)."""
+    g = golden("semseg")
+    ncls, fg, h32, w32, ws = g[name + "__meta"].tolist()
+    m = _semseg_head(ncls, fg, ws)
+    m.precision = precision
+    feats = synth.synth_features(8, h32, w32, seed=ws)
+    out = m([dev(f)[None] for f in feats[::-1]])[0].cpu().numpy()          # reference order: 4x, 8x, 16x, 32x
+    assert out.shape == tuple(g[name + "__shape"].tolist())
+    stride = 1 if g[name].ndim == 4 else 3
+    assert report("semseg %s %s" % (name, precision), out.reshape(-1)[::stride], g[name].reshape(-1)) <= 1e-3
+
+
+def test_semseg_accumulate_and_masks_vs_golden(hip, golden):
+    """accumulate (incl. a clip that repeats a frame) is bit-exact vs sequential numpy fp32 adds; the mask kernel on the
+    GOLDEN logits: fg / logits / probs <= 1e-6, argmax identical."""
+    g = golden("semseg")
+    rs = np.random.RandomState(5)
+    Cn, T, H, W, Fn = 5, 4, 6, 10, 6
+    clips = [(rs.randn(Cn, T, H, W).astype(np.float32), sub) for sub in ([0, 1, 2, 3], [2, 3, 4, 5], [5, 5, 5, 1])]
+    acc = torch.zeros(Fn, Cn, H, W, device="cuda")
+    ref, cnt = np.zeros((Fn, Cn, H, W), np.float32), [0] * Fn
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    for x, sub in clips:
+        InferenceModel._accumulate_semseg(acc, cnt, dev(x), sub)
+        for i, t in enumerate(sub):
+            ref[t] = ref[t] + x[:, i]
+    assert cnt == [1, 2, 2, 2, 1, 4] and np.array_equal(acc.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError):
+        hip.semseg_accumulate(acc, dev(clips[0][0]), [1, 1, 2, 3])          # duplicates in one launch are refused
+    for name, kinds in (("sem_kitti", ("logits", "probs", "argmax", None)), ("sem_ytvis", ("argmax",))):
+        ncls, fg, h32, w32, ws = g[name + "__meta"].tolist()
+        if name == "sem_kitti":
+            y = g[name]
+        else:                                                                # wide case: the golden keeps every 3rd logit only
+            sd = synth.synth_state_dict(odec.decoder_param_shapes("semseg_head.", kind="semseg", n_classes=ncls + fg, inter=(128, 128, 64, 64)), ws)
+            y = odec.semseg_decoder(synth.synth_features(8, h32, w32, seed=ws), sd).numpy()
+        T2 = y.shape[1]
+        mult = np.array([1 + t % 3 for t in range(T2)], np.float32)
+        sums = np.ascontiguousarray((y * mult[None, :, None, None]).transpose(1, 0, 2, 3))     # [F, C, h, w]
+        for kind in kinds:
+            fgm, mc = hip.semseg_masks(dev(sums), dev(mult), kind)
+            key = "%s_fg_%s" % (name, kind or "logits")
+            assert report("semseg fg %s %s" % (name, kind), fgm.cpu().numpy(), g[key]) <= 1e-6
+            if kind is None:
+                assert mc is None
+            elif kind == "argmax":
+                srt = np.sort((sums / mult[:, None, None, None])[:, :-1], 1)
+                safe = (srt[:, -1] - srt[:, -2]) > (0 if name == "sem_kitti" else 1e-4)
+                assert np.array_equal(mc.cpu().numpy()[safe], g["%s_mc_argmax" % name][safe]) and safe.mean() > 0.99
+            else:
+                assert report("semseg mc %s %s" % (name, kind), mc.cpu().numpy(), g["%s_mc_%s" % (name, kind)]) <= 1e-6
+    # 2-channel head: fg = softmax[:, 1]
+    x = rs.randn(3, 2, 5, 7).astype(np.float32)
+    fgm, mc = hip.semseg_masks(dev(x), dev(np.ones(3, np.float32)), "probs")
+    assert mc is None and report("semseg fg binary", fgm.cpu().numpy(), torch.softmax(torch.from_numpy(x), 1)[:, 1].numpy()) <= 1e-6
+
+
+def test_inference_model_with_semseg_head(hip):
+    """kitti-style model (xyt embeddings with in-head seediness + 3+1-channel semseg head) over overlapping clips incl. a
+    repeated-frame clip: per-clip outputs and the averaged semseg masks vs the oracle run on the same frames."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel, preprocess_frames
+    from oracle import encoder as oenc
+    config.load_preset("kittimots")
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 96, 128
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        model = InferenceModel(semseg_output_type="argmax")
+        sd = model._model.state_dict()
+        new = {k: synth.synth_param(k, v.shape, 23) for k, v in sd.items()}
+        model._model.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(sd[k].shape) for k, v in new.items()})
+        model = model.cuda()
+        assert model.has_semseg_head
+        frames = synth.synth_frames(10, 96, 128, seed=23)
+        subs = [list(range(0, 8)), list(range(2, 10)), [9, 9, 9, 9, 9, 9, 9, 3]]
+        res = model([f for f in frames], subs)
+        x, _ = preprocess_frames(frames)
+        new = {k: np.asarray(v).reshape(tuple(sd[k].shape)) for k, v in new.items()}
+        feats = {s: f.numpy() for s, f in oenc.resnet_fpn(x.cpu().numpy(), new, "R-50-FPN").items()}
+        acc, cnt = None, np.zeros(10)
+        for sub in subs:
+            f = [np.stack([feats[s][t] for t in sub], 1) for s in (32, 16, 8, 4)]
+            y = odec.semseg_decoder(f, new).numpy()
+            acc = np.zeros((10,) + y.shape[:1] + y.shape[2:], np.float32) if acc is None else acc
+            for i, t in enumerate(sub):
+                acc[t] += y[:, i]
+                cnt[t] += 1
+        mean = acc / cnt[:, None, None, None].astype(np.float32)
+        fg_ref, mc_ref = odec.semseg_masks(mean, "argmax")
+        assert report("semseg model fg", res["fg_masks"].cpu().numpy(), fg_ref.numpy()) <= 1e-3
+        srt = np.sort(mean[:, :-1], 1)
+        safe = (srt[:, -1] - srt[:, -2]) > 1e-3
+        assert np.array_equal(res["multiclass_masks"].cpu().numpy()[safe], mc_ref.numpy()[safe])
+        assert len(res["embeddings"]) == 3 and res["embeddings"][2].subseq_frames == [3, 9]
+    finally:
+        config.load_preset("defaults")
+
+
 # ------------------------------------------------------------------------------------------------ fg mask / gather
 def test_fg_mask_accumulate(hip):
     rs = np.random.RandomState(3)

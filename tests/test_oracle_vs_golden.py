@@ -41,6 +41,50 @@ def test_seediness_decoder(golden, T):
     assert np.abs(out - g["seediness"]).max() <= TOL
 
 
+SEMSEG_CASES = ["sem_bin", "sem_kitti", "sem_ytvis"]
+
+
+def semseg_case(g, name):
+    """-> (state dict, features in trunk order, reference logits flattened, stride of the stored samples, n channels)"""
+    ncls, fg, h32, w32, ws = g[name + "__meta"].tolist()
+    nch = ncls + fg
+    sd = _dec_sd("semseg_head.", ws, kind="semseg", n_classes=nch, inter=(128, 128, 64, 64))
+    feats = synth.synth_features(8, h32, w32, seed=ws)
+    shape = tuple(g[name + "__shape"].tolist())
+    stride = 1 if g[name].ndim == 4 else 3
+    return sd, feats, g[name].reshape(-1), stride, shape
+
+
+@pytest.mark.parametrize("name", SEMSEG_CASES)
+def test_semseg_decoder(golden, name):
+    g = golden("semseg")
+    sd, feats, ref, stride, shape = semseg_case(g, name)
+    out = odec.semseg_decoder(feats, sd).numpy()
+    assert out.shape == shape
+    assert np.abs(out.reshape(-1)[::stride] - ref).max() <= TOL
+
+
+def test_semseg_masks(golden):
+    """get_semseg_masks restated (inference_model.py:197-231) on the oracle's own logits, frame t averaged over 1 + t % 3 copies."""
+    g = golden("semseg")
+    assert int(g["sem_bin_masks_raise"]) == 1          # the reference itself fails for a 2-channel head
+    for name, kinds in (("sem_kitti", ("logits", "probs", "argmax")), ("sem_ytvis", ("argmax",))):
+        sd, feats, _, _, _ = semseg_case(g, name)
+        y = odec.semseg_decoder(feats, sd)              # [C, T, h, w]
+        mean = torch.stack([(y[:, t] * float(1 + t % 3)) / float(1 + t % 3) for t in range(y.shape[1])], 0)
+        for kind in kinds:
+            fg, mc = odec.semseg_masks(mean, kind)
+            assert np.abs(fg.numpy() - g["%s_fg_%s" % (name, kind)]).max() <= TOL
+            ref = g["%s_mc_%s" % (name, kind)]
+            if kind == "argmax":
+                # ties aside, class decisions must agree wherever the reference's top-2 margin exceeds the logit tolerance
+                srt = np.sort(mean[:, :-1].numpy(), 1)
+                safe = (srt[:, -1] - srt[:, -2]) > 1e-4
+                assert np.array_equal(mc.numpy()[safe], ref[safe]) and safe.mean() > 0.99
+            else:
+                assert np.abs(mc.numpy() - ref).max() <= TOL
+
+
 @pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
 def test_encoder(golden, btype):
     g = golden("encoder")

@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "encoder", "model_davis", "cluster", "chainer", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "encoder", "model_davis", "cluster", "chainer", "misc"]
 
 
 def _save(name, **arrays):
@@ -84,6 +84,51 @@ def gen_decoders(T):
         out["seediness"] = head(feats)[0].numpy()
         out["seediness__meta"] = np.array([0, 3, 4, 6, 0, 0], np.int64)
     _save("decoder_T%d" % T, **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_semseg():
+    """Semseg head (semseg_decoder.py:12-116) + InferenceModel.get_semseg_masks (inference_model.py:197-231)."""
+    import ref_shim
+    ref_shim.install(num_frames=8)
+    import torch
+    import torch.nn as nn
+    from stemseg.modeling.semseg_decoder import SEMSEG_HEAD_REGISTRY
+    from stemseg.modeling.inference_model import InferenceModel
+    Sem = SEMSEG_HEAD_REGISTRY["squeeze_expand_decoder"]
+    norm = partial(nn.GroupNorm, 32)
+    out = {}
+    with torch.no_grad():
+        # name, num_classes, fg channel, H32, W32, seed     (2: davis-style binary; 3+1: kitti; 40+1: ytvis -> wide head)
+        for name, ncls, fg, h32, w32, ws in (("sem_bin", 2, False, 3, 4, 31), ("sem_kitti", 3, True, 3, 3, 32),
+                                             ("sem_ytvis", 40, True, 3, 4, 33)):
+            head = Sem(256, ncls, [128, 128, 64, 64], (4, 8, 16, 32), foreground_channel=fg,
+                       PoolType=nn.AvgPool3d, NormType=norm).eval()
+            _load_synth_weights(head, ws, prefix="semseg_head.")
+            feats = [torch.from_numpy(f)[None] for f in synth.synth_features(8, h32, w32, seed=ws)]
+            y = head(feats[::-1])[0]                       # the head wants 4x..32x and reverses internally
+            out[name] = y.numpy() if ncls < 8 else y.numpy().reshape(-1)[::3].copy()       # wide head: every 3rd value
+            out[name + "__shape"] = np.array(y.shape, np.int64)
+            out[name + "__meta"] = np.array([ncls, int(fg), h32, w32, ws], np.int64)
+            # get_semseg_masks on "averaged" logits: frame t seen (1 + t % 3) times
+            T = y.shape[1]
+            acc = [[y[:, t][None] * float(1 + t % 3), 1 + t % 3] for t in range(T)]
+            for kind in (("logits", "probs", "argmax") if ncls < 8 else ("argmax",)):
+                stub = type("S", (), {})()
+                stub._model = type("M", (), {"semseg_head": head})()
+                stub.semseg_generation_on_gpu = False
+                stub.semseg_output_type = kind
+                try:
+                    fgm, mc = InferenceModel.get_semseg_masks(stub, acc)
+                except AttributeError:
+                    # reference quirk: with a 2-channel head multiclass_masks stays a list and `.cpu()` raises
+                    # (inference_model.py:231) -- recorded, not papered over
+                    out["%s_masks_raise" % name] = np.array(1, np.int64)
+                    continue
+                out["%s_fg_%s" % (name, kind)] = fgm.numpy()
+                if torch.is_tensor(mc):
+                    out["%s_mc_%s" % (name, kind)] = mc.numpy()
+    _save("semseg", **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -363,6 +408,8 @@ def main():
     g = args.group
     if g.startswith("dec_T"):
         gen_decoders(int(g[5:]))
+    elif g == "semseg":
+        gen_semseg()
     elif g == "encoder":
         gen_encoder()
     elif g == "model_davis":
