@@ -116,13 +116,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
                     help="MFMA mode of every convolution: exact fp32 (default) or the 3-term bf16 split (fp32 accumulate)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph of the step instead of launching eagerly (experimental: ~10 %% faster, but "
-                         "graph replay was seen to fault intermittently on this ROCm build, so it is opt-in)")
-    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly instead of replaying the captured hipGraph of the step (use under rocprofv3)")
+    ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)      # (the default; kept for old command lines)
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
+    args.graph = not args.no_graph
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,7 +136,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the (still torch-op) encoder convs
 
     from stemseg_amd import hip
     hip.require_gpu()
@@ -161,27 +160,13 @@ def main():
         meta = step(i)
     sync()
     mark("warmup done")
-    # The ~250 launches of a step are captured ONCE into a hipGraph (encoder, both decoders with their fork/join branch
-    # streams, fg mask, gather, clustering rounds) and replayed per clip: the launch-bound tail of small kernels no
-    # longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
-    graph, static_in, static_out = None, None, None
-    if args.graph and not args.no_graph:
+    # The ~330 launches of a step are captured ONCE into a hipGraph (ClipPipeline.capture: encoder, both decoders, fg
+    # mask, gather, clustering rounds, all on one stream) and replayed per clip: the launch-bound tail of small kernels
+    # no longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
+    graph = None
+    if args.graph:
         try:
-            # inside the captured graph every launch sits on ONE stream: measured, the fork/join branch streams give no
-            # throughput here (each conv already fills the chip) and HIP's capture rejects the multi-stream fork/join
-            pipe.model.overlap_decoders = bool(args.graph_overlap)
-            static_in = clips[0].clone()
-            side = torch.cuda.Stream(device=device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                pipe.step(static_in)                      # warm the capture stream's allocator pools
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_out = pipe.step(static_in)
-            graph = g
-            torch.cuda.synchronize()
+            graph = pipe.capture(clips[0], overlap=bool(args.graph_overlap))
             mark("capture done")
         except Exception as e:  # noqa: BLE001
             import traceback
@@ -192,9 +177,7 @@ def main():
             torch.cuda.synchronize()
 
     def step_graph(i):
-        static_in.copy_(clips[i % len(clips)], non_blocking=True)
-        graph.replay()
-        return hip.read_cluster_meta(static_out["meta"])
+        return hip.read_cluster_meta(graph.run(clips[i % len(clips)])["meta"])
 
     run = step_graph if graph is not None else step
     for i in range(2):

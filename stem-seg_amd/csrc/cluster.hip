@@ -135,6 +135,12 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_round_kernel(const Cluster
     const long long end = (beg + chunk < N) ? beg + chunk : N;
 
     float center[STEMSEG_MAX_EMB_DIMS], bwv[STEMSEG_MAX_EMB_DIMS];
+    if (round < 0 && blockIdx.x == 0) {
+        // zero the loop state and the output record here rather than with hipMemsetAsync: no block of THIS launch reads
+        // them, and memset nodes in a captured hipGraph were seen to land out of order with the short kernels around them
+        for (int k = threadIdx.x; k < (int)(sizeof(StemsegClusterMeta) / 4); k += CL_THREADS) reinterpret_cast<int*>(p.meta)[k] = 0;
+        for (int k = threadIdx.x; k < (int)(sizeof(ClusterState) / 4); k += CL_THREADS) reinterpret_cast<int*>(p.state)[k] = 0;
+    }
     if (round >= 0) {
         // block-uniform read of the termination flag (another block of this launch may set it meanwhile)
         if (threadIdx.x == 0) sh_done = p.state->done;
@@ -453,8 +459,10 @@ extern "C" int stemseg_hip_cluster(const float* emb, const float* bw, const floa
     SS_CHECK_ARG(params->max_instances >= 1 && params->max_instances <= STEMSEG_MAX_INSTANCES, "cluster: max_instances out of range");
     SS_CHECK_ARG(ws_bytes >= stemseg_hip_cluster_workspace_bytes(n_max), "cluster: workspace too small");
     hipStream_t s = as_stream(stream);
-    SS_HIP(hipMemsetAsync(meta_dev, 0, sizeof(StemsegClusterMeta), s));
-    if (n_max == 0) return STEMSEG_OK;   // clusterers.py:62-69
+    if (n_max == 0) {                    // clusterers.py:62-69: nothing to cluster, empty record
+        SS_HIP(hipMemsetAsync(meta_dev, 0, sizeof(StemsegClusterMeta), s));
+        return STEMSEG_OK;
+    }
     SS_CHECK_ARG(emb && (bw || Ev == 0) && seed && labels && workspace, "cluster: null pointer");
     ClusterKParams p;
     p.emb = emb; p.bw = bw; p.seed = seed; p.n_dev = reinterpret_cast<const long long*>(n_points_dev); p.n_max = n_max;
@@ -470,7 +478,7 @@ extern "C" int stemseg_hip_cluster(const float* emb, const float* bw, const floa
     p.state = reinterpret_cast<ClusterState*>(w);
     p.meta = meta_dev; p.labels = reinterpret_cast<long long*>(labels); p.masks = opt_masks; p.probs = opt_probs;
     p.nblk = grid_for(n_max, CL_THREADS * 4, CL_MAX_BLOCKS);
-    SS_HIP(hipMemsetAsync(p.state, 0, sizeof(ClusterState), s));
+    static_assert(sizeof(StemsegClusterMeta) % 4 == 0 && sizeof(ClusterState) % 4 == 0, "word-zeroed in the round -1 launch");
     for (int round = -1; round < params->max_instances; ++round) {
         hipLaunchKernelGGL(cluster_round_kernel, dim3(p.nblk), dim3(CL_THREADS), 0, s, p, round);
         SS_LAUNCH_CHECK();

@@ -353,10 +353,21 @@ def cluster(emb, bw, seed, params, label_start, n_points_dev=None, want_masks=Fa
     return labels, meta, masks, probs
 
 
+_meta_pinned = {}
+
+
 def read_cluster_meta(meta_dev):
-    """Device->host copy of the StemsegClusterMeta record (synchronises the stream)."""
-    host = meta_dev.cpu().numpy().tobytes()
-    return ClusterMeta.from_buffer_copy(host)
+    """Device->host copy of the StemsegClusterMeta record (synchronises the current stream).  The copy lands in a
+    persistent PINNED host buffer: a direct DMA, no pageable staging (``.cpu()`` on a tensor that lives in a hipGraph's
+    private pool was seen to fault the GPU after a few replays on ROCm 7.2)."""
+    n = meta_dev.numel()
+    key = (meta_dev.device.index, n)
+    buf = _meta_pinned.get(key)
+    if buf is None:
+        buf = _meta_pinned[key] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    buf.copy_(meta_dev, non_blocking=True)
+    torch.cuda.current_stream(meta_dev.device).synchronize()
+    return ClusterMeta.from_buffer_copy(buf.numpy().tobytes())
 
 
 def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):

@@ -348,6 +348,38 @@ def test_decoder_full_size_480x864_vs_oracle(hip, precision):
     assert report("decoder 480x864 %s" % precision, out, ref) <= 1e-3
 
 
+def test_graphed_step_equals_eager(hip):
+    """ClipPipeline.capture: the hipGraph replay of a step is bit-identical to eager launches, for the captured clip and
+    for other clips (different fg counts / instance counts), including the pinned read-back of the clustering record."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset("davis")
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        model = InferenceModel()
+        sd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 29))).reshape(v.shape) for k, v in sd.items()}
+        new["seediness_head.conv_out.weight"] = new["seediness_head.conv_out.weight"] * 40.0
+        model._model.load_state_dict(new)
+        pipe = ClipPipeline(model, seediness_thresh=0.5)
+        clips = [dev(synth.synth_frames(8, 96, 128, seed=s).astype(np.float32).transpose(0, 3, 1, 2) - 110.0) for s in (1, 2, 3)]
+        eager = []
+        for c in clips:
+            o = pipe.step(c)
+            eager.append((o["labels"].clone(), o["emb"].clone(), hip.read_cluster_meta(o["meta"])))
+        g = pipe.capture(clips[0])
+        for rep in range(3):
+            for c, (lab, emb, meta) in zip(clips, eager):
+                o = g.run(c)
+                m = hip.read_cluster_meta(o["meta"])
+                assert (m.K, m.n_points) == (meta.K, meta.n_points)
+                assert torch.equal(o["labels"], lab) and torch.equal(o["emb"], emb)
+        assert len(set(int(e[2].n_points) for e in eager)) > 1, "test clips should differ in fg count"
+    finally:
+        config.load_preset("defaults")
+
+
 # ------------------------------------------------------------------------------------------------ semseg head (SURVEY 8f #1)
 def _semseg_head(ncls, fg, ws, inter=(128, 128, 64, 64)):
     from stemseg_amd.modeling.semseg_decoder import SqueezeExpandDecoder as Sem

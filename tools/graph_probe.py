@@ -15,10 +15,14 @@ import bench  # noqa: E402
 
 stage = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+mode = sys.argv[3] if len(sys.argv) > 3 else "same"      # same | alt (alternate two clips through a static input) | altmeta
 dev = torch.device("cuda", 0)
 pipe, _ = bench.build_pipeline(dev)
 pipe.model.overlap_decoders = False
-clip = bench.make_clip(1, dev)
+SEED = int(os.environ.get("PROBE_SEED", "1"))
+clip = bench.make_clip(SEED, dev).clone()
+clip_b = bench.make_clip(SEED + 1, dev)
+clip_a = clip.clone()
 m = pipe.model
 ref = pipe.step(clip)
 torch.cuda.synchronize()
@@ -43,8 +47,13 @@ def cluster():
     return pipe.cluster(emb, bw, seed)["labels"]
 
 
+pipe_out = None
+
+
 def everything():
-    return pipe.step(clip)["labels"]
+    global pipe_out
+    pipe_out = pipe.step(clip)
+    return pipe_out["labels"]
 
 
 fn = {"encoder": encoder, "decoders": decoders, "cluster": cluster, "all": everything}[stage]
@@ -61,9 +70,23 @@ with torch.cuda.graph(g):
     out = fn()
 torch.cuda.synchronize()
 bad = 0
-for i in range(n):
-    g.replay()
+if mode == "same":
+    for i in range(n):
+        g.replay()
+        torch.cuda.synchronize()
+        if not torch.equal(out, want):
+            bad += 1
+else:
+    from stemseg_amd import hip
+    assert stage == "all"
+    res = []
+    for i in range(n):
+        clip.copy_(clip_b if i % 2 else clip_a, non_blocking=True)
+        g.replay()
+        if mode == "altmeta":
+            hip.read_cluster_meta(pipe_out["meta"])
+        res.append(out.clone())
     torch.cuda.synchronize()
-    if not torch.equal(out, want):
-        bad += 1
+    bad = sum(0 if torch.equal(r, res[i % 2]) else 1 for i, r in enumerate(res))
+    bad += 0 if torch.equal(res[0], want) else 100
 print("graph probe %-9s: %d replays, %d mismatching" % (stage, n, bad))
