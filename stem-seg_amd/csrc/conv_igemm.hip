@@ -386,21 +386,43 @@ struct SplitReduceParams {
     int64_t out_cs, out_ts, out_ys, res_cs, res_ts, res_ys, slab;
     int C, H, W, ksplit, relu;     // (H, W): how to split the flat voxel index into (t, y, x)
     int64_t V;
+    unsigned n_items;              // threads needed: C * V / (4 or 1)
 };
+// One thread per output float4 (VEC: W % 4 == 0 and 16-B aligned output / residual rows) or per output float; the index
+// is decomposed with 32-bit divisions once per thread.  Partial slabs are dense [C][T][H][W], so their reads are coalesced
+// 16-B loads in the VEC form.
+template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReduceParams p) {
-    const int64_t HW = (int64_t)p.H * p.W, total = p.V * p.C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i / p.V);
-        int64_t r = i - (int64_t)c * p.V;
-        const int t = (int)(r / HW);
-        r -= (int64_t)t * HW;
-        const int y = (int)(r / p.W), x = (int)(r - (int64_t)y * p.W);
+    constexpr int VW = VEC ? 4 : 1;
+    const unsigned wq = (unsigned)p.W / VW;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= p.n_items) return;
+    const unsigned row = idx / wq, x = (idx - row * wq) * VW;
+    const unsigned th = (unsigned)(p.V / p.W);                 // T * H rows per channel
+    const unsigned c = row / th, r2 = row - c * th;
+    const unsigned t = r2 / (unsigned)p.H, y = r2 - t * (unsigned)p.H;
+    const int64_t i = (int64_t)row * p.W + x;
+    const int64_t o = (int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+    if constexpr (VEC) {
+        float4 acc = *reinterpret_cast<const float4*>(p.partial + i);
+        for (int z = 1; z < p.ksplit; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(p.partial + (int64_t)z * p.slab + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (p.bias) { const float b = p.bias[c]; acc.x += b; acc.y += b; acc.z += b; acc.w += b; }
+        if (p.res) {
+            const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4*>(p.out + o) = acc;
+    } else {
         float acc = p.partial[i];
         for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
         if (p.bias) acc += p.bias[c];
         if (p.res) acc += p.res[(int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x];
         if (p.relu) acc = fmaxf(acc, 0.f);
-        p.out[(int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x] = acc;
+        p.out[o] = acc;
     }
 }
 
@@ -480,8 +502,12 @@ using X2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true, true>;
 using X2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true, true>;
 using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 
+// sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
+// MFMA peak)
+constexpr double CU_FLOPS_F32 = 0.46e12;
+
 template <class C>
-static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats) {
+static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0) {
     p.tiles_x = (int)ceil_div(p.W, C::COLS * 32);
     p.tiles_y = (int)ceil_div(p.H, C::ROWS);
     // split-K over the input-channel chunks when the layer alone cannot give every CU two workgroups
@@ -490,9 +516,12 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     const int64_t slab = (int64_t)p.Cout * p.T * p.H * p.W;
     int ksplit = 1;
     while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= 640 && slab * ksplit * 2 <= scratch_floats) ksplit *= 2;
+    if (force_ksplit > 0) ksplit = (scratch && (int64_t)force_ksplit * slab <= scratch_floats) ? std::min(force_ksplit, nchunks) : 1;
     p.chunks_per_split = (int)ceil_div(nchunks, ksplit);
     ksplit = (int)ceil_div(nchunks, p.chunks_per_split);
     SplitReduceParams rp;
+    // 16-B reduce: the true output (and residual) rows are aligned (vec_epi as computed by the caller) and W % 4 == 0
+    const bool rp_vec = p.vec_epi && p.dec_W == 0 && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) && (slab % 4 == 0);
     if (ksplit > 1) {
         rp.partial = scratch; rp.bias = p.bias; rp.res = p.res; rp.out = p.out;
         rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys; rp.res_cs = p.res_cs; rp.res_ts = p.res_ts; rp.res_ys = p.res_ys;
@@ -510,12 +539,61 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
     if (ksplit > 1) {
-        const int64_t total = slab;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, s, rp);
+        const int64_t items = slab / (rp_vec ? 4 : 1);
+        SS_CHECK_ARG(items < (1ll << 32) - 256, "conv3d: split-K output too large (%lld elements)", (long long)slab);
+        rp.n_items = (unsigned)items;
+        if (rp_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, s, rp);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, s, rp);
     }
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
+}
+
+// Tail balancing for launches of a few big workgroups per CU.  An MFMA-bound CU works through its workgroups at a fixed
+// rate, so a launch costs ceil(workgroups / 256) "units"; 840 workgroups (block_4x at 480p) cost 4 units for 3.28 units of
+// work.  Here the output rows are cut in two: the first nA row-tiles run whole (a multiple of 256 workgroups, or close),
+// the remaining rows run split-K by k with the deterministic slab reduce, which cuts their units into k-ths:
+// 504 + 3 x 336 workgroups cost 2 + 4/3 = 3.33 units.  The split is chosen by a cost model (units x time per unit +
+// slab traffic) and only taken when it beats the plain launch by > 3 %.  Sub-launches are ordinary launches on row
+// sub-volumes (pointer offsets), so results are bit-identical to the plain launch wherever k = 1 and equal to a plain
+// split-K launch elsewhere (fixed summation order).
+template <class C>
+static int launch_rows_balanced(const ConvKParams& p0, hipStream_t s, float* scratch, int64_t scratch_floats, double cu_flops) {
+    constexpr int NCU = 256;
+    const int tiles_x = (int)ceil_div(p0.W, C::COLS * 32), n = (int)ceil_div(p0.H, C::ROWS);
+    const int64_t c = (int64_t)tiles_x * p0.T * ceil_div(p0.Cout, C::MT);
+    const int nchunks = (int)ceil_div(p0.Cin, C::CK);
+    const double t_unit = 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * p0.Cin * C::TAPS / cu_flops;
+    const double t_plain = (double)ceil_div(n * c, NCU) * t_unit;
+    double best = t_plain;
+    int best_nA = n, best_k = 1;
+    static const int ks[] = {2, 3, 4, 6, 8};
+    for (int nA = 0; nA < n && scratch; ++nA) {
+        const int64_t rowsB = p0.H - (int64_t)nA * C::ROWS;
+        const int64_t slabB = (int64_t)p0.Cout * p0.T * rowsB * p0.W;
+        for (int k : ks) {
+            if (k > nchunks || k * slabB > scratch_floats) continue;
+            const double units = (double)ceil_div(nA * c, NCU) + (double)ceil_div((n - nA) * c * k, NCU) / k;
+            const double t = units * t_unit + 2.0 * k * slabB * 4.0 / 3.0e12 + 8e-6;
+            if (t < best) { best = t; best_nA = nA; best_k = k; }
+        }
+    }
+    if (best > 0.97 * t_plain) return launch_cfg<C>(p0, s, scratch, scratch_floats);
+    auto rows = [&](int r0, int r1) {
+        ConvKParams q = p0;
+        q.in += (int64_t)r0 * p0.in_ys; q.in_limit -= (int64_t)r0 * p0.in_ys; q.in_H = (r1 - r0) + C::KH - 1;
+        q.out += (int64_t)r0 * p0.out_ys;
+        if (q.res) q.res += (int64_t)r0 * p0.res_ys;
+        q.H = r1 - r0;
+        return q;
+    };
+    const int rA = best_nA * C::ROWS;
+    if (rA > 0) {
+        const int rc = launch_cfg<C>(rows(0, rA), s, nullptr, 0);
+        if (rc) return rc;
+    }
+    return launch_cfg<C>(rows(rA, p0.H), s, scratch, scratch_floats, best_k);
 }
 
 template <class C>
@@ -567,11 +645,11 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else cfg = 3;
         }
         if (bf) {
-            if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);
+            if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);   // (row balancing measured slower here)
             if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
             return launch_cfg<X3Small>(p, s, scratch, scratch_floats);
         }
-        if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
+        if (cfg == 1) return launch_rows_balanced<K3Big>(p, s, scratch, scratch_floats, CU_FLOPS_F32);
         if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats);
         return launch_cfg<K3Small>(p, s, scratch, scratch_floats);
     }

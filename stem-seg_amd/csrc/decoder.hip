@@ -95,11 +95,12 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     p.D[1] = take((int64_t)p.c16 * p.T * p.h[1] * p.w[1]);
     p.D[2] = take((int64_t)p.c8 * p.T * p.h[2] * p.w[2]);
     p.D[3] = take((int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
-    // split-K partial-sum scratch for the small-map branches (up to 16 / 4 / 2 slabs); the 4x branch never splits
+    // split-K partial-sum scratch: small-map branches up to 16 / 4 / 2 slabs; the 4x branch splits only the rows of its
+    // tail (launch_rows_balanced), 2 slabs' worth covers any (rows, k) the cost model picks
     p.Sfloats[0] = 16 * (int64_t)p.c32 * p.T * p.h[0] * p.w[0];
     p.Sfloats[1] = 4 * (int64_t)p.c16 * p.T * p.h[1] * p.w[1];
     p.Sfloats[2] = 2 * (int64_t)p.c8 * p.T * p.h[2] * p.w[2];
-    p.Sfloats[3] = 0;
+    p.Sfloats[3] = 2 * (int64_t)p.c4 * p.T * p.h[3] * p.w[3];
     for (int i = 0; i < 4; ++i) p.S[i] = p.Sfloats[i] ? take(p.Sfloats[i]) : 0;
     p.P32b = take(PaddedGeom(p.c32, p.Ta1, p.h[0], p.w[0]).total);
     p.P32c = take(PaddedGeom(p.c32, p.Ta2, p.h[0], p.w[0]).total);
@@ -329,7 +330,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, nullptr, 0, desc->precision);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);
