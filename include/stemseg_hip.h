@@ -318,6 +318,32 @@ int stemseg_hip_semseg_accumulate(float* acc, const float* clip_logits, int32_t 
 int stemseg_hip_semseg_masks(const float* acc, const float* counts, int32_t F, int32_t C, int64_t HW, int32_t output_type,
                              float* fg, void* multiclass, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pre-processing (inference_image_loader.py:23-43, data/common.py:12-30, structures/image_list.py:93-104), one launch:
+ * frames uint8 [T][H0][W0][3] (device) -> bilinear resize to (new_h, new_w), align_corners=False -> optional / 255 ->
+ * (x - mean[c]) / std[c] -> optional channel flip (RGB models) -> out float [T][3][pad_h][pad_w], zero right / bottom padding.
+ * mean / std are HOST arrays of 3 floats in the frames' channel order.
+ * ---------------------------------------------------------------------------------------------- */
+int stemseg_hip_preprocess_frames(const uint8_t* frames, int32_t T, int32_t H0, int32_t W0, int32_t new_h, int32_t new_w,
+                                  int32_t pad_h, int32_t pad_w, const float mean[3], const float std[3], int32_t unit_scale,
+                                  int32_t flip_channels, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mask materialisation for the writers (output_utils/davis.py:76-110; same chain in youtube_vis.py:118-155 and
+ * kitti_mots.py:89-130).  File formats stay on the host.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* davis.py:76-77: dense [H][W] uint8 := 0, then dense[ys[i]][xs[i]] = lut[labels[i] + 1] -- lut maps (track label + 1) to
+ * "index in instances_to_keep + 1" (1..255) or 0 for labels that are not kept (outliers, tracks beyond max_tracks). */
+int stemseg_hip_scatter_instance_index(const int64_t* ys, const int64_t* xs, const int64_t* labels, int64_t n, const int32_t* lut,
+                                       int32_t lut_len, uint8_t* dense, int32_t H, int32_t W, void* stream);
+
+/* davis.py:79-110 fused: one-hot planes of `dense` [h][w] -> bilinear x mask_scale (align_corners=False) -> crop to
+ * (crop_h, crop_w) = the resized network input without its zero padding -> bilinear resize to (out_h, out_w) -> > 0.5 ->
+ * out [out_h][out_w] uint8 = kept-instance index + 1 (0 = none).  mask_scale = 1 reproduces `upscaled_inputs`. */
+int stemseg_hip_resample_instance_masks(const uint8_t* dense, int32_t h, int32_t w, float mask_scale, int32_t crop_h, int32_t crop_w,
+                                        int32_t out_h, int32_t out_w, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

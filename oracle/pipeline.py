@@ -8,10 +8,32 @@ TEST INFRASTRUCTURE -- see oracle/__init__.py.
 """
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import decoder as odec
 from . import encoder as oenc
 from .clusterer import sequential_clustering
+
+
+@torch.no_grad()
+def preprocess_frames(frames_u8, min_dim, max_dim, mean=(102.9801, 115.9465, 122.7717), std=(1.0, 1.0, 1.0), unit_scale=False,
+                      flip_channels=False):
+    """uint8 [T,H0,W0,3] -> float32 [T,3,H,W] (inference_image_loader.py:23-43: per-frame F.interpolate bilinear to
+    compute_resize_params_2's size; data/common.py:12-30: (/255), (x - mean) / std, channel flip; image_list.py:93-104:
+    zero pad to multiples of 32)."""
+    import math
+    from .masks import compute_resize_params_2
+    x = torch.as_tensor(np.asarray(frames_u8)).permute(0, 3, 1, 2).float()
+    H0, W0 = x.shape[-2:]
+    nw, nh, _ = compute_resize_params_2((W0, H0), min_dim, max_dim)
+    x = torch.cat([F.interpolate(x[i:i + 1], (nh, nw), mode="bilinear", align_corners=False) for i in range(x.shape[0])], 0)
+    if unit_scale:
+        x = x / 255.
+    x = (x - torch.tensor(mean, dtype=torch.float32)[None, :, None, None]) / torch.tensor(std, dtype=torch.float32)[None, :, None, None]
+    if flip_channels:
+        x = x.flip(dims=[1])
+    H, W = int(math.ceil(nh / 32)) * 32, int(math.ceil(nw / 32)) * 32
+    return F.pad(x, (0, W - nw, 0, H - nh)), (nh, nw)
 
 
 def bandwidth_activation(var):

@@ -105,6 +105,9 @@ SIGNATURES = {
     "stemseg_hip_relabel": (C.c_int, [_P, _I64, _P, _I32, _P]),
     "stemseg_hip_semseg_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I64, C.POINTER(C.c_int32), _I32, _P]),
     "stemseg_hip_semseg_masks": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _P, _P, _P]),
+    "stemseg_hip_preprocess_frames": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float), _I32, _I32, _P, _P]),
+    "stemseg_hip_scatter_instance_index": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _P]),
+    "stemseg_hip_resample_instance_masks": (C.c_int, [_P, _I32, _I32, C.c_float, _I32, _I32, _I32, _I32, _P, _P]),
 }
 
 SEMSEG_OUTPUT_TYPES = {None: 0, "none": 0, "logits": 1, "probs": 2, "argmax": 3}
@@ -407,3 +410,36 @@ def semseg_masks(acc, counts, output_type="probs"):
         mc = torch.empty(Fn, Cn - 1, H, W, dtype=torch.float32, device=acc.device)
     check(lib().stemseg_hip_semseg_masks(ptr(acc, torch.float32), ptr(counts, torch.float32), Fn, Cn, H * W, code, ptr(fg), ptr(mc) if mc is not None else None, stream()))
     return fg, mc
+
+
+def scatter_instance_index(ys, xs, labels, lut, H, W):
+    """dense uint8 [H,W]: lut[label + 1] at the (ys, xs) of the frame's foreground points, 0 elsewhere (davis.py:76-77)."""
+    require_gpu()
+    dense = torch.empty(H, W, dtype=torch.uint8, device=lut.device)
+    n = labels.numel()
+    check(lib().stemseg_hip_scatter_instance_index(ptr(ys, torch.int64) if n else None, ptr(xs, torch.int64) if n else None,
+                                                   ptr(labels, torch.int64) if n else None, n, ptr(lut, torch.int32), lut.numel(),
+                                                   ptr(dense), H, W, stream()))
+    return dense
+
+
+def resample_instance_masks(dense, mask_scale, crop_hw, out_hw):
+    """dense uint8 [h,w] -> condensed uint8 [out_h,out_w] through x mask_scale, crop, resize, > 0.5 (davis.py:79-110)."""
+    require_gpu()
+    h, w = dense.shape
+    out = torch.empty(out_hw[0], out_hw[1], dtype=torch.uint8, device=dense.device)
+    check(lib().stemseg_hip_resample_instance_masks(ptr(dense, torch.uint8), h, w, float(mask_scale), int(crop_hw[0]), int(crop_hw[1]),
+                                                    int(out_hw[0]), int(out_hw[1]), ptr(out), stream()))
+    return out
+
+
+def preprocess_frames(frames_u8, new_hw, pad_hw, mean, std, unit_scale=False, flip_channels=False):
+    """uint8 [T,H0,W0,3] (device) -> float32 [T,3,pad_h,pad_w]: resize, normalise, pad in one launch."""
+    require_gpu()
+    T, H0, W0, ch = frames_u8.shape
+    assert ch == 3
+    out = torch.empty(T, 3, pad_hw[0], pad_hw[1], dtype=torch.float32, device=frames_u8.device)
+    m, s = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    check(lib().stemseg_hip_preprocess_frames(ptr(frames_u8, torch.uint8), T, H0, W0, int(new_hw[0]), int(new_hw[1]), int(pad_hw[0]), int(pad_hw[1]),
+                                              m, s, int(bool(unit_scale)), int(bool(flip_channels)), ptr(out), stream()))
+    return out

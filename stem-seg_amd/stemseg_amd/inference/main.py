@@ -79,7 +79,12 @@ class TrackGenerator(object):
         n = len(frames)
         subseq_idxes, _ = get_subsequence_frames(n, cfg.INPUT.NUM_FRAMES, self.dataset_name, self.frame_overlap)
         out = self.model(frames, subseq_idxes)
-        return out["embeddings"], self.get_fg_masks_from_seediness(out), out["multiclass_masks"]
+        fg_masks = out["fg_masks"]
+        if torch.is_tensor(fg_masks):            # semseg head present: its foreground probability > 0.5 (main.py:142-144)
+            fg_masks = torch.stack([hip.fg_mask(p.contiguous(), 1.0, 0.5) for p in fg_masks.cuda()], 0)
+        else:                                    # otherwise the seediness map, averaged over clips, > threshold (:145-147)
+            fg_masks = self.get_fg_masks_from_seediness(out)
+        return out["embeddings"], fg_masks, out["multiclass_masks"]
 
     def do_clustering(self, all_embeddings, fg_masks):
         dicts = [{"frames": f, "embeddings": e, "bandwidths": b, "seediness": s} for (f, e, b, s) in all_embeddings]

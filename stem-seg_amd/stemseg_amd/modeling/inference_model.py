@@ -17,7 +17,6 @@ from collections import namedtuple
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import hip
 from ..config import cfg
@@ -47,22 +46,19 @@ def pad_to_multiple_of_32(h, w):
 
 @torch.no_grad()
 def preprocess_frames(frames, device="cuda"):
-    """uint8 BGR frames [T,H0,W0,3] (numpy or tensor) -> float32 [T,3,H,W]: bilinear resize to cfg MIN/MAX_DIM,
-    mean-subtract (no /255, std 1), zero-pad right/bottom to multiples of 32."""
-    x = torch.as_tensor(np.asarray(frames)) if not torch.is_tensor(frames) else frames
-    x = x.to(device).permute(0, 3, 1, 2).float()
-    H0, W0 = x.shape[-2:]
+    """uint8 BGR frames [T,H0,W0,3] (numpy or tensor) -> (float32 [T,3,H,W] on the device, (new_h, new_w)): bilinear resize
+    to cfg MIN/MAX_DIM, mean-subtract (no /255, std 1 with the reference's configs), zero-pad right/bottom to multiples of
+    32 -- one HIP launch (inference_image_loader.py:23-43, data/common.py:12-30, image_list.py:93-104)."""
+    hip.require_gpu()
+    x = torch.as_tensor(np.ascontiguousarray(frames)) if not torch.is_tensor(frames) else frames
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[-1] == 3, "frames: uint8 [T, H, W, 3]"
+    x = x.to(device).contiguous()
+    H0, W0 = x.shape[1:3]
     nw, nh, _ = compute_resize_params_2((W0, H0), cfg.INPUT.MIN_DIM, cfg.INPUT.MAX_DIM)
-    x = F.interpolate(x, (nh, nw), mode="bilinear", align_corners=False)
-    mean = torch.tensor(cfg.INPUT.IMAGE_MEAN, dtype=torch.float32, device=x.device)[None, :, None, None]
-    std = torch.tensor(cfg.INPUT.IMAGE_STD, dtype=torch.float32, device=x.device)[None, :, None, None]
-    if cfg.INPUT.NORMALIZE_TO_UNIT_SCALE:
-        x = x / 255.
-    x = (x - mean) / std
-    if not cfg.INPUT.BGR_INPUT:
-        x = x.flip(dims=[1])
     H, W = pad_to_multiple_of_32(nh, nw)
-    return F.pad(x, (0, W - nw, 0, H - nh)), (nh, nw)
+    out = hip.preprocess_frames(x, (nh, nw), (H, W), cfg.INPUT.IMAGE_MEAN, cfg.INPUT.IMAGE_STD,
+                                cfg.INPUT.NORMALIZE_TO_UNIT_SCALE, not cfg.INPUT.BGR_INPUT)
+    return out, (nh, nw)
 
 
 def build_model():

@@ -490,6 +490,94 @@ def test_inference_model_with_semseg_head(hip):
         config.load_preset("defaults")
 
 
+# ------------------------------------------------------------------------------------------------ pre-processing (8f #4)
+def test_preprocess_frames_vs_golden_and_oracle(hip, golden):
+    from oracle import pipeline as opipe
+    from stemseg_amd import config
+    from stemseg_amd.modeling import inference_model as im
+    g = golden("misc")
+    try:
+        config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 64, 96
+        out, hw = im.preprocess_frames(g["preproc__in"][None])
+        assert tuple(out.shape[1:]) == g["preproc__out"].shape
+        assert report("preprocess (golden, 50x70 -> 64x96)", out[0].cpu().numpy(), g["preproc__out"]) <= 1e-4
+        # 720p -> DAVIS 480p network input (down-scaling), 360p -> YT-VIS (up-scaling), unit scale + RGB flip variant
+        for (h0, w0), (mn, mx), unit, flip in (((720, 1280), (480, 854), False, False), ((360, 640), (640, 1196), False, False),
+                                              ((100, 75), (96, 160), True, True)):
+            config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = mn, mx
+            config.cfg.INPUT.NORMALIZE_TO_UNIT_SCALE, config.cfg.INPUT.BGR_INPUT = unit, not flip
+            config.cfg.INPUT.IMAGE_STD = [0.229, 0.224, 0.225] if unit else [1.0, 1.0, 1.0]
+            config.cfg.INPUT.IMAGE_MEAN = [0.485, 0.456, 0.406] if unit else [102.9801, 115.9465, 122.7717]
+            fr = synth.synth_frames(3, h0, w0, seed=h0)
+            out, hw = im.preprocess_frames(fr)
+            ref, hw_ref = opipe.preprocess_frames(fr, mn, mx, config.cfg.INPUT.IMAGE_MEAN, config.cfg.INPUT.IMAGE_STD, unit, flip)
+            assert hw == hw_ref and tuple(out.shape) == tuple(ref.shape)
+            assert report("preprocess %dx%d -> %s" % (h0, w0, tuple(ref.shape[-2:])), out.cpu().numpy(), ref.numpy()) <= 1e-4
+    finally:
+        config.load_preset("defaults")
+
+
+# ------------------------------------------------------------------------------------------------ mask materialisation (8f #3)
+def test_mask_materialisation_vs_golden(hip, golden):
+    """MaskMaterializer vs the PNGs written by the reference's DavisOutputGenerator: identical except (at most) pixels whose
+    soft value sits within 1e-6 of the 0.5 threshold."""
+    from oracle import masks as omask
+    from stemseg_amd import config
+    from stemseg_amd.inference.output_utils import MaskMaterializer, instances_to_keep
+    g = golden("masks")
+    try:
+        for name in g["__names"].tolist():
+            h, w, ih, iw, mn, mx, nf, max_tracks = g[name + "__dims"].tolist()
+            config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = mn, mx
+            maps = g[name + "__maps"]
+            life = dict(zip(g[name + "__lifetime_keys"].tolist(), g[name + "__lifetime_vals"].tolist()))
+            idxes, labels = [], []
+            for t in range(nf):
+                ys, xs = np.nonzero(maps[t])
+                idxes.append((dev(ys), dev(xs)))
+                labels.append(dev(maps[t][ys, xs]))
+            keep, out = MaskMaterializer(-1).process_sequence((ih, iw), idxes, labels, life, (h, w), 4.0, max_tracks)
+            assert keep == g[name + "__keep"].tolist() == instances_to_keep(life, -1, max_tracks)
+            out, ref = out.cpu().numpy(), g[name + "__condensed"]
+            bad = out != ref
+            for t in np.unique(np.nonzero(bad)[0]).tolist():
+                soft = omask.soft_masks(maps[t], keep, (ih, iw), mn, mx).numpy()
+                assert (np.abs(soft - 0.5).min(0)[bad[t]] < 1e-6).all(), "mask mismatch away from the threshold (%s frame %d)" % (name, t)
+            print("[parity] masks %-6s %d frames %dx%d -> %dx%d: %d / %d pixels differ (threshold ties)" % (name, nf, h, w, ih, iw, bad.sum(), bad.size))
+            assert bad.mean() < 1e-3
+    finally:
+        config.load_preset("defaults")
+
+
+def test_mask_materialisation_full_size_vs_oracle(hip):
+    """DAVIS 480p: 120x216 label maps -> 480x854 masks (identity resize after the crop) and a 720p original (up-scaling)."""
+    from oracle import masks as omask
+    from stemseg_amd import config
+    from stemseg_amd.inference.output_utils import MaskMaterializer
+    rs = np.random.RandomState(11)
+    try:
+        for (ih, iw), (mn, mx) in (((480, 854), (480, 854)), ((720, 1280), (480, 854))):
+            config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = mn, mx
+            maps = np.zeros((2, 120, 216), np.int64)
+            for k in range(1, 13):
+                y, x, hh, ww = rs.randint(0, 100), rs.randint(0, 190), rs.randint(4, 30), rs.randint(4, 40)
+                maps[:, y:y + hh, x:x + ww] = k
+            maps[1] = np.roll(maps[1], 3, axis=1)
+            life = {k: int(rs.randint(0, 5)) for k in range(1, 13)}
+            idxes = [(dev(np.nonzero(m)[0]), dev(np.nonzero(m)[1])) for m in maps]
+            labels = [dev(m[np.nonzero(m)]) for m in maps]
+            keep, out = MaskMaterializer(-1).process_sequence((ih, iw), idxes, labels, life, (120, 216), 4.0, 10)
+            ref = omask.condensed_masks(maps, keep, (ih, iw), mn, mx).numpy()
+            bad = out.cpu().numpy() != ref
+            print("[parity] masks full size -> %dx%d: %d / %d pixels differ" % (ih, iw, bad.sum(), bad.size))
+            for t in np.unique(np.nonzero(bad)[0]).tolist():
+                soft = omask.soft_masks(maps[t], keep, (ih, iw), mn, mx).numpy()
+                assert (np.abs(soft - 0.5).min(0)[bad[t]] < 1e-6).all()
+            assert bad.mean() < 1e-3
+    finally:
+        config.load_preset("defaults")
+
+
 # ------------------------------------------------------------------------------------------------ fg mask / gather
 def test_fg_mask_accumulate(hip):
     rs = np.random.RandomState(3)

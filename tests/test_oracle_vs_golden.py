@@ -85,6 +85,20 @@ def test_semseg_masks(golden):
                 assert np.abs(mc.numpy() - ref).max() <= TOL
 
 
+def test_mask_materialisation(golden):
+    """oracle/masks.py vs the PNGs written by the reference's DavisOutputGenerator (tools/make_goldens.py::gen_masks)."""
+    from oracle import masks as omask
+    g = golden("masks")
+    for name in g["__names"].tolist():
+        h, w, ih, iw, mn, mx, nf, max_tracks = g[name + "__dims"].tolist()
+        life = dict(zip(g[name + "__lifetime_keys"].tolist(), g[name + "__lifetime_vals"].tolist()))
+        keep = omask.instances_to_keep(life, -1, max_tracks)
+        assert keep == g[name + "__keep"].tolist()
+        out = omask.condensed_masks(g[name + "__maps"], keep, (ih, iw), mn, mx).numpy()
+        assert np.array_equal(out, g[name + "__condensed"]), name
+        assert out.max() == len(keep)
+
+
 @pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
 def test_encoder(golden, btype):
     g = golden("encoder")

@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "encoder", "model_davis", "cluster", "chainer", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "encoder", "model_davis", "cluster", "chainer", "misc"]
 
 
 def _save(name, **arrays):
@@ -129,6 +129,74 @@ def gen_semseg():
                 if torch.is_tensor(mc):
                     out["%s_mc_%s" % (name, kind)] = mc.numpy()
     _save("semseg", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def _label_frames(n_frames, h, w, seed):
+    """Per-frame label maps at mask resolution: moving rectangles / a disc with ids 1..5, an outlier id -1, 0 = background."""
+    rng = np.random.RandomState(seed)
+    maps = np.zeros((n_frames, h, w), np.int64)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for t in range(n_frames):
+        maps[t, 2:9, 1 + t:8 + t] = 1
+        maps[t, 10 + (t % 3):18, 3:12] = 2
+        if t >= 2:
+            maps[t][(yy - 12) ** 2 + (xx - (w - 8 - t)) ** 2 <= 20] = 3
+        if t < 4:
+            maps[t, h - 5:h - 1, w - 7:w - 1] = 4            # reaches into the zero-padded border of the network input
+        maps[t, 0:2, w - 3:w] = 5
+        maps[t][(rng.uniform(size=(h, w)) < 0.02) & (maps[t] > 0)] = -1       # scattered outliers inside instances
+    return maps
+
+
+def gen_masks():
+    """DavisOutputGenerator.process_sequence (output_utils/davis.py:38-116): label scatter -> one-hot -> bilinear x4 -> crop the
+    zero padding -> bilinear resize to the image size -> > 0.5 -> condensed uint8 map; read back from the PNGs it writes."""
+    import shutil
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    from PIL import Image
+    from stemseg.inference.output_utils.davis import DavisOutputGenerator
+    tmp = os.path.join(ROOT, ".tmp_goldens")
+    out = {}
+    names = []
+    #        name       mask h, w   image h, w   MIN  MAX   frames max_tracks
+    cases = [("up",      24, 32,     70, 100,     90,  128,  6,     10),     # resized 90x128 inside the padded 96x128
+             ("ident",   24, 32,     96, 128,     96,  128,  4,     10),     # image already at network size
+             ("down",    16, 24,     200, 311,    60,  96,   5,     3),      # shrink + max_tracks truncation
+             ]
+    try:
+        for name, h, w, ih, iw, mn, mx, nf, max_tracks in cases:
+            cfg.INPUT.update_param("MIN_DIM", mn)
+            cfg.INPUT.update_param("MAX_DIM", mx)
+            maps = _label_frames(nf, h, w, seed=h + nf)
+            idxes, labels = [], []
+            counts, life = {}, {}
+            for t in range(nf):
+                ys, xs = np.nonzero(maps[t])
+                idxes.append((torch.from_numpy(ys), torch.from_numpy(xs)))
+                labels.append(torch.from_numpy(maps[t][ys, xs]))
+                for i in np.unique(maps[t][ys, xs]).tolist():
+                    counts[i] = counts.get(i, 0) + int((maps[t] == i).sum())
+                    lo, hi = life.get(i, (10000, -1))
+                    life[i] = (min(lo, t), max(hi, t))
+            lifetimes = {k: v[1] - v[0] for k, v in life.items()}
+            seq = type("Seq", (), {"image_dims": (ih, iw), "id": name})()
+            gen = DavisOutputGenerator(tmp, -1, False)
+            keep, _ = gen.process_sequence(seq, idxes, labels, counts, lifetimes, None, (h, w), 4.0, max_tracks, device="cpu")
+            pngs = [np.array(Image.open(os.path.join(tmp, "results", name, "%05d.png" % t))) for t in range(nf)]
+            out[name + "__maps"] = maps
+            out[name + "__dims"] = np.array([h, w, ih, iw, mn, mx, nf, max_tracks], np.int64)
+            out[name + "__lifetime_keys"] = np.array(list(lifetimes.keys()), np.int64)
+            out[name + "__lifetime_vals"] = np.array(list(lifetimes.values()), np.int64)
+            out[name + "__keep"] = np.array(keep, np.int64)
+            out[name + "__condensed"] = np.stack(pngs, 0).astype(np.uint8)
+            names.append(name)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["__names"] = np.array(names)
+    _save("masks", **out)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -410,6 +478,8 @@ def main():
         gen_decoders(int(g[5:]))
     elif g == "semseg":
         gen_semseg()
+    elif g == "masks":
+        gen_masks()
     elif g == "encoder":
         gen_encoder()
     elif g == "model_davis":
