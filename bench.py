@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
-TRAFFIC_BLOCK4X_GB = 0.99         # measured offline with PMC counters (cannot be read from inside the process)
+TRAFFIC_BLOCK4X_GB = 1.17         # measured offline with PMC counters (cannot be read from inside the process)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # same guide: bf16 MFMA, dense (the 2:1-sparse 5 PF figure is not used)
 T, H, W = 8, 480, 864             # BASELINE config 1: DAVIS-shape 480p (480x854 padded to a multiple of 32)
 BACKBONE = "R-101-FPN"
@@ -232,11 +232,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": TRAFFIC_BLOCK4X_GB if args.precision == "f32" else None,
-                         "traffic_note": "GB per launch of the block_4x conv (algorithmic 0.322 GB), FETCH_SIZE x2 + WRITE_SIZE from separate "
-                                         "rocprofv3 --pmc passes, profiles/r01_pmc_conv3d_block4x.txt",
+                         "traffic_note": "GB per block_4x conv (its two row sub-launches + the split-K reduce; algorithmic 0.322 GB), FETCH_SIZE x2 + "
+                                         "WRITE_SIZE from separate rocprofv3 --pmc passes, profiles/r01_pmc_conv3d_block4x.txt",
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                         "how": "hipEvent pairs around every 3x3x3 conv launch over %d serialized steps after the timed "
-                                "region (in the timed region the two decoders and their branches overlap on separate streams)" % n_roof,
+                         "how": "hipEvent pairs around every 3x3x3 conv launch (incl. its split-K reduce) over %d eager steps after the "
+                                "timed region; a launch = one kernel launch of the conv (the block_4x conv issues two)" % n_roof,
                          "hip_graph_replay_in_timed_region": graph is not None},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -558,28 +558,39 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
 // slab traffic) and only taken when it beats the plain launch by > 3 %.  Sub-launches are ordinary launches on row
 // sub-volumes (pointer offsets), so results are bit-identical to the plain launch wherever k = 1 and equal to a plain
 // split-K launch elsewhere (fixed summation order).
+struct RowPlan { double cost; int nA, k; };
+
+// Cost of the best (whole rows, split-K rows) cut for tile shape C: rounds x time per round + slab traffic.  `occ`
+// workgroups share a CU (LDS-limited), so the chip has 256 * occ slots and one round of co-resident workgroups takes
+// occ x (flops per workgroup / sustained per-CU rate x eff); eff = relative MFMA efficiency of the tile shape
+// (measured with tools/conv_sweep.py: 4-row tiles reach 0.92 of the 8-row tile's rate).
 template <class C>
-static int launch_rows_balanced(const ConvKParams& p0, hipStream_t s, float* scratch, int64_t scratch_floats, double cu_flops) {
-    constexpr int NCU = 256;
+static RowPlan plan_rows(const ConvKParams& p0, bool have_scratch, int64_t scratch_floats, double cu_flops, int occ, double eff) {
+    const int64_t slots = 256 * occ;
     const int tiles_x = (int)ceil_div(p0.W, C::COLS * 32), n = (int)ceil_div(p0.H, C::ROWS);
     const int64_t c = (int64_t)tiles_x * p0.T * ceil_div(p0.Cout, C::MT);
     const int nchunks = (int)ceil_div(p0.Cin, C::CK);
-    const double t_unit = 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * p0.Cin * C::TAPS / cu_flops;
-    const double t_plain = (double)ceil_div(n * c, NCU) * t_unit;
-    double best = t_plain;
-    int best_nA = n, best_k = 1;
+    const double t_round = occ * 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * p0.Cin * C::TAPS / (cu_flops * eff);
+    RowPlan best{(double)ceil_div(n * c, slots) * t_round, n, 1};
+    const double t_plain = best.cost;
     static const int ks[] = {2, 3, 4, 6, 8};
-    for (int nA = 0; nA < n && scratch; ++nA) {
+    for (int nA = 0; nA < n && have_scratch; ++nA) {
         const int64_t rowsB = p0.H - (int64_t)nA * C::ROWS;
         const int64_t slabB = (int64_t)p0.Cout * p0.T * rowsB * p0.W;
         for (int k : ks) {
             if (k > nchunks || k * slabB > scratch_floats) continue;
-            const double units = (double)ceil_div(nA * c, NCU) + (double)ceil_div((n - nA) * c * k, NCU) / k;
-            const double t = units * t_unit + 2.0 * k * slabB * 4.0 / 3.0e12 + 8e-6;
-            if (t < best) { best = t; best_nA = nA; best_k = k; }
+            const double rounds = (double)ceil_div(nA * c, slots) + (double)ceil_div((n - nA) * c * k, slots) / k;
+            const double t = rounds * t_round + 2.0 * k * slabB * 4.0 / 3.0e12 + 8e-6;
+            if (t < best.cost) best = RowPlan{t, nA, k};
         }
     }
-    if (best > 0.97 * t_plain) return launch_cfg<C>(p0, s, scratch, scratch_floats);
+    if (best.cost > 0.97 * t_plain) best = RowPlan{t_plain, n, 1};      // not worth the extra launches
+    return best;
+}
+
+template <class C>
+static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int64_t scratch_floats, const RowPlan& plan) {
+    if (plan.k <= 1) return launch_cfg<C>(p0, s, scratch, scratch_floats);
     auto rows = [&](int r0, int r1) {
         ConvKParams q = p0;
         q.in += (int64_t)r0 * p0.in_ys; q.in_limit -= (int64_t)r0 * p0.in_ys; q.in_H = (r1 - r0) + C::KH - 1;
@@ -588,12 +599,21 @@ static int launch_rows_balanced(const ConvKParams& p0, hipStream_t s, float* scr
         q.H = r1 - r0;
         return q;
     };
-    const int rA = best_nA * C::ROWS;
+    const int rA = plan.nA * C::ROWS;
     if (rA > 0) {
         const int rc = launch_cfg<C>(rows(0, rA), s, nullptr, 0);
         if (rc) return rc;
     }
-    return launch_cfg<C>(rows(rA, p0.H), s, scratch, scratch_floats, best_k);
+    return launch_cfg<C>(rows(rA, p0.H), s, scratch, scratch_floats, plan.k);
+}
+
+// big launches (>= 512 workgroups of the 8-row tile): 8-row tile vs 4-row tile, each with its best row cut
+template <class Big, class Med>
+static int launch_planned(const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, int occ_big, int occ_med) {
+    const RowPlan a = plan_rows<Big>(p, scratch != nullptr, scratch_floats, CU_FLOPS_F32, occ_big, 1.0);
+    const RowPlan b = plan_rows<Med>(p, scratch != nullptr, scratch_floats, CU_FLOPS_F32, occ_med, 0.92);
+    if (b.cost < 0.97 * a.cost) return launch_rows<Med>(p, s, scratch, scratch_floats, b);
+    return launch_rows<Big>(p, s, scratch, scratch_floats, a);
 }
 
 template <class C>
@@ -649,7 +669,8 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
             return launch_cfg<X3Small>(p, s, scratch, scratch_floats);
         }
-        if (cfg == 1) return launch_rows_balanced<K3Big>(p, s, scratch, scratch_floats, CU_FLOPS_F32);
+        if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<K3Big, K3Med>(p, s, scratch, scratch_floats, 2, 2);
+        if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
         if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats);
         return launch_cfg<K3Small>(p, s, scratch, scratch_floats);
     }
@@ -667,13 +688,20 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             if (cfg == 2) return launch_cfg<X2Med>(p, s, scratch, scratch_floats);
             return launch_cfg<X2Small>(p, s, scratch, scratch_floats);
         }
+        if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= 512)
+            return launch_planned<K2Big, K2Med>(p, s, scratch, scratch_floats, 3, 3);
         if (cfg == 1) return launch_cfg<K2Big>(p, s, scratch, scratch_floats);
         if (cfg == 2) return launch_cfg<K2Med>(p, s, scratch, scratch_floats);
         return launch_cfg<K2Small>(p, s, scratch, scratch_floats);
     }
     if (p.Cout <= 64) return bf ? launch_cfg<X1M64>(p, s, scratch, scratch_floats) : launch_cfg<K1M64>(p, s, scratch, scratch_floats);
     int cfg = tile_cfg;
-    if (cfg <= 0 || cfg > 2) cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
+    if (cfg <= 0 || cfg > 2) {
+        cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
+        // expansion convs with a short K (<= 8 channel chunks) are bound by their output / residual traffic: the 128-voxel
+        // tile keeps twice as many workgroups in flight (measured, tools/conv_sweep.py: 64->256 +res 233 -> 167 us)
+        if (!bf && p.Cin <= 256 && p.Cout >= 4 * p.Cin) cfg = 2;
+    }
     if (bf) {
         if (cfg == 1) return launch_cfg<X1Big>(p, s, scratch, scratch_floats);
         return launch_cfg<X1Small>(p, s, scratch, scratch_floats);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Steady-state per-step kernel breakdown from a rocprofv3 rocpd trace of bench.py: uses the last `n` steps, a step
-being delimited by every 2nd launch of the big 3x3x3 conv tile (block_4x of the two decoders).
+being delimited by the encoder's stem kernel (one launch per clip).
 Usage: tools/prof_steady.py results.db [n_steps]"""
 import sqlite3
 import sys
@@ -8,9 +8,9 @@ import sys
 c = sqlite3.connect(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = c.execute("select name, start, end, grid_x, grid_y, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
-big = [r for r in rows if "conv_igemm" in r[0] and "<3, 3, 3, 4, 4, 2, 1, 4, 1" in r[0]]
-assert len(big) >= 2 * (n + 1), "not enough steps in the trace"
-t0, t1 = big[-2 * n - 1][2], big[-1][2]
+stem = [r for r in rows if "stem_conv7x7" in r[0]]
+assert len(stem) >= n + 1, "not enough steps in the trace"
+t0, t1 = stem[-n - 1][1], stem[-1][1]
 agg = {}
 for name, s, e, gx, gy, wx, lds, vg in rows:
     if s < t0 or e > t1:
