@@ -219,6 +219,11 @@ def main():
         fl = sum(p[1] for p in k3)
         launches = sum(p[2] for p in k3)
         ach = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        def cls(tags):
+            sel = [prof[t] for t in tags if t in prof]
+            m, f = sum(q[0] for q in sel) / n_roof, sum(q[1] for q in sel) / n_roof
+            return {"ms_per_step": round(m, 3), "gflop_per_step": round(f / 1e9, 1), "tflops": round(f / m / 1e9, 1) if m > 0 else None}
+        breakdown = {"conv3x3x3": cls((8, 4, 2)), "conv1x3x3": cls((28, 24, 22)), "conv1x1x1": cls((18, 14, 16, 12))}
         res = {
             "metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(clips_total / dt, 4), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -237,7 +242,8 @@ def main():
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "how": "hipEvent pairs around every 3x3x3 conv launch (incl. its split-K reduce) over %d eager steps after the "
                                 "timed region; a launch = one kernel launch of the conv (the block_4x conv issues two)" % n_roof,
-                         "hip_graph_replay_in_timed_region": graph is not None},
+                         "hip_graph_replay_in_timed_region": graph is not None,
+                         "conv_classes_eager": breakdown},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
