@@ -73,7 +73,9 @@ class GraphedStep(object):
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: calls made meanwhile by OTHER threads (e.g. the RCCL watchdog's event queries when a process
+            # group is alive) must not invalidate this thread's capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = pipe.step(self.static_in)
             torch.cuda.synchronize(dev)
         finally:
