@@ -76,6 +76,40 @@ def test_conv3d_k3(hip, cfg, shape):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("kind", ["k3", "k2"])
+def test_conv_kitti_shape_planner_and_tiling_stress(hip, kind):
+    """BASELINE config 4 (KITTI-MOTS, max_dim 1948 -> padded 608x1952): the 4x map is 152 x 488 -- 19 row tiles x 16 column
+    tiles x T, thousands of workgroups, so the launch planner's row cut (whole rows + split-K rows) is what runs.  Compared
+    with torch's CPU convolution (channel counts reduced to keep the CPU side in seconds), NaN-poisoned output / scratch,
+    twice for determinism."""
+    T, H, W = 8, 152, 488
+    Cin, Cout = (32, 128) if kind == "k3" else (64, 128)
+    x = _rand((Cin, T, H, W), 5)
+    if kind == "k3":
+        w = _rand((Cout, Cin, 3, 3, 3), 6, 1.0 / np.sqrt(Cin * 27))
+        b = _rand((Cout,), 7)
+        ref = F.conv3d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), padding=1)[0].numpy()
+        buf, g = hip.alloc_padded(Cin, T, H, W)
+        hip.copy_to_volume(dev(x), 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
+        vin, k = hip.padded_halo_view(buf, g, Cin, T, H, W), 3
+    else:
+        w = _rand((Cout, Cin, 1, 3, 3), 6, 1.0 / np.sqrt(Cin * 9))
+        b = _rand((Cout,), 7)
+        ref = F.conv2d(torch.from_numpy(x).permute(1, 0, 2, 3), torch.from_numpy(w[:, :, 0]), torch.from_numpy(b), padding=1).permute(1, 0, 2, 3).numpy()
+        pitch = hip.padded_geometry(Cin, 1, H, W)["pitch"]
+        buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
+        buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
+        vin, k = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel()), (1, 3, 3)
+    scratch = torch.full((2 * Cout * T * H * W,), float("nan"), device="cuda")
+    outs = []
+    for _ in range(2):
+        o = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        hip.conv3d(vin, hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(o), k, 0, scratch)
+        outs.append(o.cpu().numpy())
+    assert report("conv %s KITTI 4x shape (planner)" % kind, outs[0], ref) <= 2e-4
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(64, 128, 1000), (384, 128, 4 * 60 * 108), (512, 256, 1001), (8, 32, 5)])
 def test_conv3d_k1(hip, cfg, shape):
@@ -671,6 +705,21 @@ def test_cluster_full_size_vs_oracle(hip, K):
     assert np.array_equal(l1, l2)
     bad = np.flatnonzero(l1 != ref)
     assert bad.size == 0, "K=%d N=%d: %d mismatches" % (K, e.shape[0], bad.size)
+
+
+def test_cluster_ytvis_full_resolution_1M_points(hip):
+    """BASELINE config 2 (YouTube-VIS 360p -> padded 384x640, --resize_embeddings): the head outputs are up-sampled x4 and
+    clustered at full resolution: ~1e6 foreground points in one clip (5x the DAVIS case).  Labels exact vs the oracle, deterministic."""
+    emb, bw, sd, fg = synth.synth_cluster_case(8, 384, 640, 12, seed=77, bg_fraction=0.12)
+    e, b, s, _ = opipe.gather_fg(emb, bw, sd, fg)
+    assert e.shape[0] > 900_000
+    ref, ref_meta = sequential_clustering(e, b, s, label_start=1, free_dim_stds=[0.3, 0.3])
+    params = np.array([0.8, 20, 1, 2, 0.3, 0.3])
+    l1, m1 = _hip_cluster(e, b, s[:, None], params, want=False)
+    l2, _ = _hip_cluster(e, b, s[:, None], params, want=False)
+    assert m1["instance_labels"] == ref_meta["instance_labels"] and len(m1["instance_labels"]) >= 12
+    assert np.array_equal(l1, l2)
+    assert np.array_equal(l1, ref), "%d mismatches of %d" % ((l1 != ref).sum(), l1.size)
 
 
 def test_overlap_counts_and_relabel(hip):
