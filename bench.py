@@ -5,10 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one synthetic clip (T=8 frames, padded 480x864, ResNet-101-FPN, DAVIS heads: embedding decoder +
-separate seediness decoder) through encoder -> 3-D decoders -> fused heads -> fg mask -> fg gather -> sequential
-clustering -> read-back of the clustering record (K, instance list), with the input frames already resident in
-HBM.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
+One "step" = a batch of --clips-per-step (default 4) synthetic clips (each T=8 frames, padded 480x864, ResNet-101-FPN,
+DAVIS heads: embedding decoder + separate seediness decoder): ONE encoder pass over all their frames (the encoder is
+per-frame), then per clip 3-D decoders -> fused heads -> fg mask -> fg gather -> sequential clustering -> read-back of the
+clustering record (K, instance list), with the input frames already resident in HBM.  value = clips / s.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
 are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the step (use under rocprofv3)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)      # (the default; kept for old command lines)
+    ap.add_argument("--clips-per-step", type=int, default=4,
+                    help="clips that share one encoder pass per step (frames are independent in the encoder; stacking clips fills "
+                         "its small-map launches); decoders, fg gather and clustering run per clip.  1 = one clip per step")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -141,11 +144,14 @@ def main():
     hip.require_gpu()
     pipe, sd = build_pipeline(device)
     pipe.model.set_precision(args.precision)
-    clips = [make_clip(1000 + rank * 97 + i, device) for i in range(2)]
+    NC = max(1, args.clips_per_step)
+    clips = [torch.cat([make_clip(1000 + rank * 97 + i * NC + c, device) for c in range(NC)], 0) for i in range(2)]
+
+    def read_back(outs):                               # the consumer's read-back (K, centres): one small D2H per clip
+        return [hip.read_cluster_meta(o["meta"]) for o in outs][-1]
 
     def step(i):
-        out = pipe.step(clips[i % len(clips)])
-        return hip.read_cluster_meta(out["meta"])     # the consumer's read-back (K, centres): one small D2H per clip
+        return read_back(pipe.step_batch(clips[i % len(clips)], NC))
 
     def sync():
         torch.cuda.synchronize()
@@ -166,7 +172,7 @@ def main():
     graph = None
     if args.graph:
         try:
-            graph = pipe.capture(clips[0], overlap=bool(args.graph_overlap))
+            graph = pipe.capture(clips[0], overlap=bool(args.graph_overlap), n_clips=NC)
             mark("capture done")
         except Exception as e:  # noqa: BLE001
             import traceback
@@ -177,7 +183,7 @@ def main():
             torch.cuda.synchronize()
 
     def step_graph(i):
-        return hip.read_cluster_meta(graph.run(clips[i % len(clips)])["meta"])
+        return read_back(graph.run(clips[i % len(clips)]))
 
     run = step_graph if graph is not None else step
     for i in range(2):
@@ -211,7 +217,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        clips_total = args.steps * world
+        clips_total = args.steps * world * NC
         # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes), measured inside the timed region
         peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / 3.0
         k3 = [prof[t] for t in (8, 4, 2) if t in prof]
@@ -221,8 +227,8 @@ def main():
         ach = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
         def cls(tags):
             sel = [prof[t] for t in tags if t in prof]
-            m, f = sum(q[0] for q in sel) / n_roof, sum(q[1] for q in sel) / n_roof
-            return {"ms_per_step": round(m, 3), "gflop_per_step": round(f / 1e9, 1), "tflops": round(f / m / 1e9, 1) if m > 0 else None}
+            m, f = sum(q[0] for q in sel) / (n_roof * NC), sum(q[1] for q in sel) / (n_roof * NC)
+            return {"ms_per_clip": round(m, 3), "gflop_per_clip": round(f / 1e9, 1), "tflops": round(f / m / 1e9, 1) if m > 0 else None}
         breakdown = {"conv3x3x3": cls((8, 4, 2)), "conv1x3x3": cls((28, 24, 22)), "conv1x1x1": cls((18, 14, 16, 12))}
         res = {
             "metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(clips_total / dt, 4), "unit": "clips/s",
@@ -232,7 +238,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + "
                                    "seediness decoders, fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE,
-                       "clips_per_step": 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
+                       "clips_per_step": NC, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -247,7 +253,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items()}, clips[0].cpu())
+                res["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items()}, clips[0][:T].cpu())
             except Exception as e:  # noqa: BLE001  (never lose the GPU number because the baseline leg failed)
                 res["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(res))

@@ -209,6 +209,9 @@ typedef struct StemsegEncoderDesc {
     int32_t T, H, W;             /* frames per call and padded frame size (multiples of 32)              */
     int32_t out_channels;        /* 256                                                                  */
     int32_t precision;           /* STEMSEG_PRECISION_F32 | STEMSEG_PRECISION_BF16X3 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
+    int32_t n_clips;             /* >= 1: the T frames are n_clips consecutive clips of T / n_clips frames; each clip's four maps
+                                    go to their own output volumes (frames are independent in the encoder, so several clips
+                                    share one pass: layer3 / layer4 launches grow from 0.4 to n_clips x 0.4 waves of the chip) */
 } StemsegEncoderDesc;
 
 typedef struct StemsegEncoderWeights {
@@ -225,10 +228,11 @@ typedef struct StemsegEncoderWeights {
 
 size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* desc);
 int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
-/* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[0..3]: the four FPN maps (4x, 8x, 16x, 32x) as volumes
- * [256][T][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed inputs (then no copy is needed). */
+/* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[4 * c + k], c < n_clips, k = 0..3: the four FPN maps (4x, 8x, 16x,
+ * 32x) of clip c as volumes [256][T / n_clips][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed
+ * inputs (then no copy is needed). */
 int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEncoderWeights* weights, const float* frames,
-                                const StemsegVolume out[4], void* workspace, size_t ws_bytes, void* stream);
+                                const StemsegVolume* out, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Clustering side.

@@ -177,6 +177,7 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     SS_CHECK_ARG(d, "encoder: null descriptor");
     SS_CHECK_ARG(d->struct_bytes == (int32_t)sizeof(StemsegEncoderDesc), "encoder: descriptor size mismatch (%d vs %d): ABI skew",
                  d->struct_bytes, (int)sizeof(StemsegEncoderDesc));
+    SS_CHECK_ARG(d->n_clips >= 1 && d->T % d->n_clips == 0, "encoder: T=%d is not n_clips=%d whole clips", d->T, d->n_clips);
     SS_CHECK_ARG(d->T >= 1 && d->H >= 32 && d->W >= 32 && d->H % 32 == 0 && d->W % 32 == 0, "encoder: T=%d H=%d W=%d (H, W multiples of 32)", d->T, d->H, d->W);
     p.T = d->T; p.H = d->H; p.W = d->W;
     p.total_blocks = 0;
@@ -234,7 +235,7 @@ extern "C" int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc
 }
 
 extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEncoderWeights* wts, const float* frames,
-                                           const StemsegVolume out[4], void* workspace, size_t ws_bytes, void* stream) {
+                                           const StemsegVolume* out, void* workspace, size_t ws_bytes, void* stream) {
     EncoderPlan p;
     int rc = make_encoder_plan(desc, p);
     if (rc) return rc;
@@ -245,8 +246,11 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
     }
     SS_CHECK_ARG(wts->stem_w && wts->stem_b, "encoder_forward: null stem weights");
     for (int i = 0; i < 4; ++i) {
-        SS_CHECK_ARG(out[i].ptr && out[i].C == desc->out_channels && out[i].T == p.T && out[i].H == p.h[i] && out[i].W == p.w[i],
-                     "encoder_forward: output volume %d must be [%d][%d][%d][%d]", i, desc->out_channels, p.T, p.h[i], p.w[i]);
+        for (int c = 0; c < desc->n_clips; ++c) {
+            const StemsegVolume& o = out[4 * c + i];
+            SS_CHECK_ARG(o.ptr && o.C == desc->out_channels && o.T == p.T / desc->n_clips && o.H == p.h[i] && o.W == p.w[i],
+                         "encoder_forward: output volume %d of clip %d must be [%d][%d][%d][%d]", i, c, desc->out_channels, p.T / desc->n_clips, p.h[i], p.w[i]);
+        }
         SS_CHECK_ARG(wts->fpn_inner_w[i] && wts->fpn_inner_b[i] && wts->fpn_layer_w[i] && wts->fpn_layer_b[i], "encoder_forward: null FPN weights %d", i);
     }
     SS_CHECK_ARG(desc->out_channels == 256, "encoder: out_channels must be 256");
@@ -324,8 +328,16 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
                                (const float*)(ws + p.L[k + 1] + gc.interior), (int64_t)256 * T, h, w, gf.ts, gf.pitch, gc.ts, gc.pitch);
             SS_LAUNCH_CHECK();
         }
-        rc = launch_conv3d(halo2d_view(ws + p.L[k], 256, T, h, w), wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &el);
-        if (rc) return rc;
+        // the output conv runs once per clip: each clip's map goes to its own (usually zero-haloed) consumer volume
+        const int Tc = T / desc->n_clips;
+        for (int c = 0; c < desc->n_clips; ++c) {
+            StemsegVolume in = halo2d_view(ws + p.L[k], 256, T, h, w);
+            in.ptr += (int64_t)c * Tc * in.t_stride;
+            in.limit -= (int64_t)c * Tc * in.t_stride;
+            in.T = Tc;
+            rc = launch_conv3d(in, wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[4 * c + k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &el);
+            if (rc) return rc;
+        }
     }
     return STEMSEG_OK;
 }

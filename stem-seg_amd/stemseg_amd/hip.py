@@ -47,7 +47,7 @@ class ConvEpilogue(C.Structure):
 
 class EncoderDesc(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("blocks", C.c_int32 * 4), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("out_channels", C.c_int32), ("precision", C.c_int32)]
+                ("out_channels", C.c_int32), ("precision", C.c_int32), ("n_clips", C.c_int32)]
 
 
 _BLK = C.c_void_p * MAX_ENCODER_BLOCKS
@@ -86,7 +86,7 @@ SIGNATURES = {
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
     "stemseg_hip_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "stemseg_hip_encoder_init_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, _P]),
-    "stemseg_hip_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), _P, C.POINTER(Volume * 4), _P, C.c_size_t, _P]),
+    "stemseg_hip_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), _P, C.POINTER(Volume), _P, C.c_size_t, _P]),
     "stemseg_hip_groupnorm_stats": (C.c_int, [_P, _I32, _I64, _I32, _F, _P, _P, _P]),
     "stemseg_hip_gn_relu_pool": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, C.POINTER(Volume), _P]),
     "stemseg_hip_upsample_trilinear": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(Volume), _P]),

@@ -168,24 +168,27 @@ class ResNetFPN(nn.Module):
         self._packed, self._sig = (w, keep), sig
         return self._packed
 
-    def _desc(self, T, H, W):
+    def _desc(self, T, H, W, n_clips=1):
         d = hip.EncoderDesc()
         d.struct_bytes = C.sizeof(hip.EncoderDesc)
         for i, n in enumerate(self.stage_blocks):
             d.blocks[i] = n
         d.T, d.H, d.W, d.out_channels = T, H, W, self.out_channels
         d.precision = hip.PRECISIONS[self.precision]
+        d.n_clips = n_clips
         return d
 
     @torch.no_grad()
     def run_backbone_into(self, frames, out_volumes):
         """frames: float32 [T,3,H,W] on the device; out_volumes: 4 ``hip.Volume`` (4x, 8x, 16x, 32x), each
-        [256][T][H/s][W/s] -- e.g. the interiors of the decoders' zero-haloed inputs."""
+        [256][T][H/s][W/s] -- e.g. the interiors of the decoders' zero-haloed inputs.  With 4 * n volumes the T frames are n
+        consecutive clips of T / n frames sharing one encoder pass; volumes 4c .. 4c+3 receive clip c."""
         hip.require_gpu()
         frames = frames.contiguous().float()
         T, _, H, W = frames.shape
         w, _keep = self._pack()
-        d = self._desc(T, H, W)
+        assert len(out_volumes) % 4 == 0 and T % (len(out_volumes) // 4) == 0
+        d = self._desc(T, H, W, len(out_volumes) // 4)
         key = (T, H, W, frames.device.index)
         ws = self._ws.get(key)
         if ws is None:
@@ -195,8 +198,8 @@ class ResNetFPN(nn.Module):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=frames.device)
             hip.check(hip.lib().stemseg_hip_encoder_init_workspace(C.byref(d), hip.ptr(ws), nbytes, hip.stream()))
             self._ws[key] = ws
-        vols = (hip.Volume * 4)(*out_volumes)
-        hip.check(hip.lib().stemseg_hip_encoder_forward(C.byref(d), C.byref(w), hip.ptr(frames), C.byref(vols), hip.ptr(ws), ws.numel(), hip.stream()))
+        vols = (hip.Volume * len(out_volumes))(*out_volumes)
+        hip.check(hip.lib().stemseg_hip_encoder_forward(C.byref(d), C.byref(w), hip.ptr(frames), vols, hip.ptr(ws), ws.numel(), hip.stream()))
 
     @torch.no_grad()
     def forward_channel_major(self, frames):

@@ -117,9 +117,10 @@ class InferenceModel(nn.Module):
                 mod.precision = precision
 
     # ---- one clip ----------------------------------------------------------------------------------
-    def _padded_feature_buffers(self, T, H, W, dev):
-        """Four zero-haloed buffers [256][T+2][h+2][pitch], allocated once per shape (halos stay zero)."""
-        key = (T, H, W, dev.index)
+    def _padded_feature_buffers(self, T, H, W, dev, slot=0):
+        """Four zero-haloed buffers [256][T+2][h+2][pitch], allocated once per shape (halos stay zero); ``slot`` selects one
+        of several independent sets (one per clip when clips share an encoder pass)."""
+        key = (T, H, W, dev.index, slot)
         if key not in self._pads:
             Cn = self._model.backbone.out_channels
             self._pads[key] = [hip.alloc_padded(Cn, T, H // s, W // s, dev) for s in (32, 16, 8, 4)]
@@ -152,6 +153,24 @@ class InferenceModel(nn.Module):
         vols = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads, (32, 16, 8, 4))}
         m.backbone.run_backbone_into(frames, [vols[s] for s in (4, 8, 16, 32)])
         return self._run_heads(pads, T, H, W, dev)
+
+    @torch.no_grad()
+    def embed_frames_batch(self, frames, n_clips):
+        """``n_clips`` clips in one encoder pass: frames float32 [n_clips * T, 3, H, W] -> list of (emb, bw, seed) per clip.
+        The encoder treats frames independently, so stacking clips only makes its small-map launches (layer3, layer4: 0.4
+        waves of the chip per clip) fuller; the decoders and everything after run per clip."""
+        hip.require_gpu()
+        m = self._model
+        NT, _, H, W = frames.shape
+        assert NT % n_clips == 0
+        T, dev, Cn = NT // n_clips, frames.device, m.backbone.out_channels
+        pads = [self._padded_feature_buffers(T, H, W, dev, slot=c) for c in range(n_clips)]
+        vols = []
+        for c in range(n_clips):
+            v = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads[c], (32, 16, 8, 4))}
+            vols += [v[s] for s in (4, 8, 16, 32)]
+        m.backbone.run_backbone_into(frames, vols)
+        return [self._run_heads(pads[c], T, H, W, dev) for c in range(n_clips)]
 
     @torch.no_grad()
     def _run_heads(self, pads, T, H, W, dev):

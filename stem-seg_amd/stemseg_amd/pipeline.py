@@ -50,17 +50,29 @@ class ClipPipeline(object):
 
 
     @torch.no_grad()
-    def capture(self, example_frames, overlap=False):
+    def step_batch(self, frames, n_clips):
+        """``n_clips`` clips stacked along the frame axis ([n_clips * T, 3, H, W]): one encoder pass, then decoders + fg mask +
+        gather + clustering per clip.  Returns a list of ``step``-style dicts."""
+        outs = []
+        for emb, bw, seed in self.model.embed_frames_batch(frames.contiguous(), n_clips):
+            out = self.cluster(emb, bw, seed)
+            out.update(emb=emb, bw=bw, seed=seed)
+            outs.append(out)
+        return outs
+
+    @torch.no_grad()
+    def capture(self, example_frames, overlap=False, n_clips=None):
         """Capture ``step`` for clips of ``example_frames``' shape into ONE hipGraph (~330 kernel nodes on a single stream:
         measured, the decoders' fork/join branch streams buy nothing once every conv fills the chip, and single-stream
         capture is the robust form).  Returns a ``GraphedStep``; its outputs are static device tensors overwritten by
         every ``run``.  Requires that ``step`` has no host synchronisation -- which is how the path is built."""
-        return GraphedStep(self, example_frames, overlap)
+        return GraphedStep(self, example_frames, overlap, n_clips)
 
 
 class GraphedStep(object):
-    def __init__(self, pipe, example_frames, overlap=False):
+    def __init__(self, pipe, example_frames, overlap=False, n_clips=None):
         self.pipe = pipe
+        fn = pipe.step if n_clips is None else (lambda x: pipe.step_batch(x, n_clips))     # n_clips: ``run`` returns a list
         prev = pipe.model.overlap_decoders
         pipe.model.overlap_decoders = bool(overlap)       # True = capture the fork/join branch streams too (experimental)
         try:
@@ -69,14 +81,14 @@ class GraphedStep(object):
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                pipe.step(self.static_in)                 # allocates every cached workspace outside the capture
+                fn(self.static_in)                        # allocates every cached workspace outside the capture
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: calls made meanwhile by OTHER threads (e.g. the RCCL watchdog's event queries when a process
             # group is alive) must not invalidate this thread's capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.out = pipe.step(self.static_in)
+                self.out = fn(self.static_in)
             torch.cuda.synchronize(dev)
         finally:
             pipe.model.overlap_decoders = prev

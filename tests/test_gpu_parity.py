@@ -414,6 +414,45 @@ def test_graphed_step_equals_eager(hip):
         config.load_preset("defaults")
 
 
+def test_step_batch_shares_the_encoder_pass(hip):
+    """ClipPipeline.step_batch: 3 clips through ONE encoder call (n_clips = 3 in the encoder descriptor, each clip's FPN maps
+    written into its own zero-haloed buffers) == the clips one by one.  Split-K partitions depend on the launch size, so floats
+    may differ in the last bits (<= 1e-5); labels are compared where the single-clip decision has margin."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset("davis")
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        model = InferenceModel()
+        sd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 29))).reshape(v.shape) for k, v in sd.items()}
+        new["seediness_head.conv_out.weight"] = new["seediness_head.conv_out.weight"] * 40.0
+        model._model.load_state_dict(new)
+        pipe = ClipPipeline(model, seediness_thresh=0.5)
+        clips = [dev(synth.synth_frames(8, 96, 160, seed=s).astype(np.float32).transpose(0, 3, 1, 2) - 110.0) for s in (4, 5, 6)]
+        single = []
+        for c in clips:
+            o = pipe.step(c)
+            single.append({k: o[k].clone() for k in ("emb", "bw", "seed", "labels", "fg")})
+        outs = pipe.step_batch(torch.cat(clips, 0), 3)
+        assert len(outs) == 3
+        for i, (o, r) in enumerate(zip(outs, single)):
+            assert report("batch clip %d emb" % i, o["emb"].cpu().numpy(), r["emb"].cpu().numpy()) <= 1e-5
+            # (the x40 gain on the seediness logits of this test amplifies the last-bit differences of the trunk)
+            assert report("batch clip %d seed" % i, o["seed"].cpu().numpy(), r["seed"].cpu().numpy()) <= 5e-4
+            if torch.equal(o["fg"], r["fg"]):
+                same = (o["labels"] == r["labels"]).float().mean().item()
+                print("[parity] batch clip %d: %.4f of labels identical" % (i, same))
+                assert same > 0.999
+        g = pipe.capture(torch.cat(clips, 0), n_clips=3)
+        outs2 = g.run(torch.cat(clips, 0))
+        for o, r in zip(outs2, outs):
+            assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
+    finally:
+        config.load_preset("defaults")
+
+
 # ------------------------------------------------------------------------------------------------ semseg head (SURVEY 8f #1)
 def _semseg_head(ncls, fg, ws, inter=(128, 128, 64, 64)):
     from stemseg_amd.modeling.semseg_decoder import SqueezeExpandDecoder as Sem
