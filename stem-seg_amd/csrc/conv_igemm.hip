@@ -20,6 +20,7 @@
 // staging with the other's MFMA stream.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace stemseg {
 
@@ -50,9 +51,11 @@ struct ConvKParams {
 // a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate):
 // ~2^-17 relative error per product -- the same order as fp32 accumulation round-off over K = 6912 -- at 16/3 = 5.3x the
 // fp32-MFMA rate.  k-groups of 16: lane half h carries CPH channels x TPG taps (CPH * TPG = 8).
-template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false>
+// DB: double-buffered LDS with a 2-channel chunk -- the next chunk is prefetched into registers under the MFMA stream and
+// written to the OTHER buffer, so a chunk costs one barrier and no exposed load latency (big 3x3x3 tile, fp32 only).
+template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false, bool DB_ = false>
 struct ConvCfg {
-    static constexpr bool PIPE = PIPE_, BF = BF_;
+    static constexpr bool PIPE = PIPE_, BF = BF_, DB = DB_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
     static constexpr int NTHREADS = 64 * WM * WN;
@@ -70,10 +73,11 @@ struct ConvCfg {
     static constexpr int NCG = BF ? CK / (2 * CPH) : 1;                 // channel groups per chunk
     static constexpr int G = NTG * NCG;                                 // 16-wide k-groups per chunk
     static constexpr int W_FLOATS = BF ? 2 * G * 2 * MT * 4 : CK * TAPS * MT;   // bf16x3: [hi|lo][G][half][MT] x 16 B
-    static constexpr int LDS_FLOATS = IN_FLOATS + W_FLOATS;
+    static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+    static constexpr int LDS_FLOATS = BUF_FLOATS * (DB ? 2 : 1);
     static_assert(!BF || CK % (2 * CPH) == 0, "bf16x3: chunk must hold whole k-groups");
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
-    static_assert(CK % 4 == 0, "channel chunk is a multiple of the packed sub-chunk (4)");
+    static_assert(CK % 4 == 0 || (DB && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (DB)");
     static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
 };
 
@@ -158,6 +162,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
             return v;
         }
         const int mq = q % MQ;
+        if constexpr (C::CK == 2) {                           // one channel pair: LDS rows (tap, e) <- packed rows (tap, cp*2 + e)
+            const int row2 = q / MQ, tap = row2 >> 1, e = row2 & 1;
+            const float* wsrc2 = p.wpk + ((int64_t)(c0 / 4) * (C::TAPS * 4) + tap * 4 + ((c0 >> 1) & 1) * 2 + e) * p.Cout + co0;
+            float4 v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + e < p.Cin && co0 + mq * 4 < p.Cout) v2 = *reinterpret_cast<const float4*>(wsrc2 + mq * 4);
+            return v2;
+        }
         const int row = q / MQ;                               // = (sub*TAPS + tap)*4 + c4
         const int ch = c0 + (row / (C::TAPS * 4)) * 4 + (row & 3);
         const float* wsrc = p.wpk + (int64_t)(c0 / 4) * (C::TAPS * 4) * p.Cout + co0;
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         for (int q = tid; q < NWQ; q += C::NTHREADS) *reinterpret_cast<float4*>(w_lds + q * 4) = fetch_w(c0, q);
     };
     // ---- MFMA stream over one staged chunk: every tap is a shifted LDS read ------------------------------
-    auto compute = [&]() {
+    auto compute = [&](const int buf_off = 0) {
         if constexpr (C::BF) {
             typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
             const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
@@ -227,8 +238,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
             }
             return;
         }
+        constexpr int NSUB = C::CK >= 4 ? C::CK / 4 : 1, NCP = C::CK >= 4 ? 2 : 1, WROWS = C::CK >= 4 ? 4 : 2;
 #pragma unroll
-        for (int sub = 0; sub < C::CK / 4; ++sub) {
+        for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
             for (int dt = 0; dt < C::KT; ++dt) {
 #pragma unroll
@@ -236,15 +248,15 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 #pragma unroll
                     for (int dx = 0; dx < C::KW; ++dx) {
 #pragma unroll
-                        for (int cp = 0; cp < 2; ++cp) {
+                        for (int cp = 0; cp < NCP; ++cp) {
                             const int tap = (dt * C::KH + dy) * C::KW + dx;
-                            const int wrow = (sub * C::TAPS + tap) * 4 + cp * 2;
+                            const int wrow = (sub * C::TAPS + tap) * WROWS + cp * 2;
                             const int boff = (sub * 4 + cp * 2) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
                             float a[C::MI], b[C::NI];
 #pragma unroll
-                            for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[wrow * C::MT + mi * 32];
+                            for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[buf_off + wrow * C::MT + mi * 32];
 #pragma unroll
-                            for (int ni = 0; ni < C::NI; ++ni) b[ni] = b_ptr[ni][boff];
+                            for (int ni = 0; ni < C::NI; ++ni) b[ni] = b_ptr[ni][buf_off + boff];
 #pragma unroll
                             for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -259,7 +271,38 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 
     const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
     const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
-    if (C::PIPE && p.vec4) {
+    if constexpr (C::DB) {
+        // double-buffered LDS (launcher guarantees vec4): prefetch chunk i+1 into registers, run chunk i's MFMA stream from
+        // buffer i % 2, write the registers to the other buffer, ONE barrier per chunk
+        float4 rin[IN_PT], rw[W_PT];
+        auto fetch_regs = [&](int c0) {
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ) rin[k] = fetch_in(c0, q); }
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NWQ) rw[k] = fetch_w(c0, q); }
+        };
+        auto regs_to_lds = [&](const int off) {
+#pragma unroll
+            for (int k = 0; k < IN_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ) *reinterpret_cast<float4*>(in_lds + off + q * 4) = rin[k]; }
+#pragma unroll
+            for (int k = 0; k < W_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NWQ) *reinterpret_cast<float4*>(w_lds + off + q * 4) = rw[k]; }
+        };
+        if (c_begin < c_end) {
+            fetch_regs(c_begin);
+            regs_to_lds(0);
+        }
+        __syncthreads();
+        int cur = 0;                                          // float offset of the buffer being read
+        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
+            const bool more = c0 + C::CK < c_end;
+            if (more) fetch_regs(c0 + C::CK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            cur = C::BUF_FLOATS - cur;
+            if (more) regs_to_lds(cur);
+            __syncthreads();
+        }
+    } else if (C::PIPE && p.vec4) {
         // software pipeline: the next chunk's global loads are issued into registers BEFORE the MFMA stream of the
         // current chunk and written to LDS after it, so HBM/L2 latency hides under the matrix pipe.
         float4 rin[IN_PT], rw[W_PT];
@@ -479,6 +522,7 @@ __global__ void pack_conv_weight_bf16x3_kernel(const float* __restrict__ w, uint
 // tile shapes --------------------------------------------------------------------------------------
 //                       KT KH KW  CK  MI NI WM WN COLS
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
+using K3BigDB = ConvCfg<3, 3, 3, 2, 4, 2, 1, 4, 1, false, false, true>;   // same tile, 2-channel chunks, double-buffered LDS
 using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
 using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
 using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, true>;  // 128 co x 256 voxels
@@ -668,6 +712,13 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);   // (row balancing measured slower here)
             if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
             return launch_cfg<X3Small>(p, s, scratch, scratch_floats);
+        }
+        // the big tile runs double-buffered (measured 4.06 -> 3.66 ms on block_4x); STEMSEG_K3_DB=0 selects the single-buffer
+        // form for A/B measurements
+        static const bool use_db = [] { const char* e = getenv("STEMSEG_K3_DB"); return !(e && e[0] == '0'); }();
+        if (cfg == 1 && use_db && p.vec4) {
+            if (tile_cfg <= 0 || tile_cfg > 3) return launch_planned<K3BigDB, K3Med>(p, s, scratch, scratch_floats, 2, 2);
+            return launch_cfg<K3BigDB>(p, s, scratch, scratch_floats);
         }
         if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<K3Big, K3Med>(p, s, scratch, scratch_floats, 2, 2);
         if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
