@@ -523,6 +523,8 @@ __global__ void pack_conv_weight_bf16x3_kernel(const float* __restrict__ w, uint
 //                       KT KH KW  CK  MI NI WM WN COLS
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
 using K3BigDB = ConvCfg<3, 3, 3, 2, 4, 2, 1, 4, 1, false, false, true>;   // same tile, 2-channel chunks, double-buffered LDS
+// (measured: the double-buffered form only pays for this tile -- the smaller 3x3x3 tiles and the 2-D tiles already prefetch
+// through registers (PIPE); their DB twins were 2-9 % slower: more registers, fewer resident workgroups)
 using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
 using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
 using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, true>;  // 128 co x 256 voxels

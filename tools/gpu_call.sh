@@ -1,7 +1,5 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
-STEMSEG_BENCH_WATCHDOG=150 timeout 200 python bench.py > gpurun_out/bench_final.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench_final.log > gpurun_out/bench_final.json; cut -c1-200 gpurun_out/bench_final.json
-STEMSEG_BENCH_WATCHDOG=100 timeout 150 python bench.py --clips-per-step 1 --no-cpu-baseline > gpurun_out/bench_nc1.log 2>&1; tail -1 gpurun_out/bench_nc1.log | cut -c1-160
-rm -rf gpurun_out/prof_graph
-(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_graph -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline) > gpurun_out/prof_graph.log 2>&1; echo "prof graph exit $?"
-db=$(find gpurun_out/prof_graph -name "*.db" | head -1); python tools/prof_steady.py $db 2 > gpurun_out/prof_graph_steady.txt 2>&1; head -3 gpurun_out/prof_graph_steady.txt | cut -c1-170
-rm -f gpurun_out/prof_graph/*.db gpucore.*
+for db in 0 1; do
+STEMSEG_DB_ALL=$db STEMSEG_BENCH_WATCHDOG=100 timeout 150 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_dball$db.log 2>&1; echo "bench DB_ALL=$db exit $?"; tail -1 gpurun_out/bench_dball$db.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['conv_classes_eager'])"
+done
+STEMSEG_DB_ALL=1 timeout 300 python -m pytest tests -m gpu -q --timeout 200 -p no:cacheprovider -k "conv" > gpurun_out/tests_db.log 2>&1; echo "tests(DB_ALL) exit $?"; tail -2 gpurun_out/tests_db.log | cut -c1-200
