@@ -613,16 +613,19 @@ struct RowPlan { double cost; int nA, k; };
 template <class C>
 static RowPlan plan_rows(const ConvKParams& p0, bool have_scratch, int64_t scratch_floats, double cu_flops, int occ, double eff) {
     const int64_t slots = 256 * occ;
-    const int tiles_x = (int)ceil_div(p0.W, C::COLS * 32), n = (int)ceil_div(p0.H, C::ROWS);
-    const int64_t c = (int64_t)tiles_x * p0.T * ceil_div(p0.Cout, C::MT);
+    // 1x1 convs see their volume as ONE row of V voxels: there the cut runs along that row, in tiles of COLS * 32 voxels
+    const bool along_w = C::TAPS == 1 && p0.H == 1 && p0.T == 1;
+    const int tiles_x = (int)ceil_div(p0.W, C::COLS * 32);
+    const int n = along_w ? tiles_x : (int)ceil_div(p0.H, C::ROWS);
+    const int64_t c = along_w ? ceil_div(p0.Cout, C::MT) : (int64_t)tiles_x * p0.T * ceil_div(p0.Cout, C::MT);
     const int nchunks = (int)ceil_div(p0.Cin, C::CK);
     const double t_round = occ * 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * p0.Cin * C::TAPS / (cu_flops * eff);
     RowPlan best{(double)ceil_div(n * c, slots) * t_round, n, 1};
     const double t_plain = best.cost;
     static const int ks[] = {2, 3, 4, 6, 8};
     for (int nA = 0; nA < n && have_scratch; ++nA) {
-        const int64_t rowsB = p0.H - (int64_t)nA * C::ROWS;
-        const int64_t slabB = (int64_t)p0.Cout * p0.T * rowsB * p0.W;
+        const int64_t slabB = along_w ? (int64_t)p0.Cout * (p0.W - (int64_t)nA * C::COLS * 32)
+                                      : (int64_t)p0.Cout * p0.T * (p0.H - (int64_t)nA * C::ROWS) * p0.W;
         for (int k : ks) {
             if (k > nchunks || k * slabB > scratch_floats) continue;
             const double rounds = (double)ceil_div(nA * c, slots) + (double)ceil_div((n - nA) * c * k, slots) / k;
@@ -637,6 +640,22 @@ static RowPlan plan_rows(const ConvKParams& p0, bool have_scratch, int64_t scrat
 template <class C>
 static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int64_t scratch_floats, const RowPlan& plan) {
     if (plan.k <= 1) return launch_cfg<C>(p0, s, scratch, scratch_floats);
+    if (C::TAPS == 1 && p0.H == 1 && p0.T == 1) {           // cut along the flat voxel row (see plan_rows)
+        auto span = [&](int64_t x0, int64_t x1) {
+            ConvKParams q = p0;
+            q.in += x0; q.in_limit -= x0;
+            q.out += x0;
+            if (q.res) q.res += x0;
+            q.W = (int)(x1 - x0);
+            return q;
+        };
+        const int64_t xA = (int64_t)plan.nA * C::COLS * 32;
+        if (xA > 0) {
+            const int rc = launch_cfg<C>(span(0, xA), s, nullptr, 0);
+            if (rc) return rc;
+        }
+        return launch_cfg<C>(span(xA, p0.W), s, scratch, scratch_floats, plan.k);
+    }
     auto rows = [&](int r0, int r1) {
         ConvKParams q = p0;
         q.in += (int64_t)r0 * p0.in_ys; q.in_limit -= (int64_t)r0 * p0.in_ys; q.in_H = (r1 - r0) + C::KH - 1;
@@ -759,7 +778,15 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         if (cfg == 1) return launch_cfg<X1Big>(p, s, scratch, scratch_floats);
         return launch_cfg<X1Small>(p, s, scratch, scratch_floats);
     }
-    if (cfg == 1) return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
+    // big un-decoded 1x1 launches: same round-based cut as the 3x3 convs, along the flat voxel row
+    const bool plan1 = !flat && (tile_cfg <= 0 || tile_cfg > 2) && scratch != nullptr;
+    if (cfg == 1) {
+        if (plan1 && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512)
+            return launch_rows<K1Big>(p, s, scratch, scratch_floats, plan_rows<K1Big>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
+        return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
+    }
+    if (plan1 && num_workgroups<K1Small>(p.Cout, p.T, p.H, p.W) >= 1024)
+        return launch_rows<K1Small>(p, s, scratch, scratch_floats, plan_rows<K1Small>(p, true, scratch_floats, CU_FLOPS_F32, 5, 0.85));
     return launch_cfg<K1Small>(p, s, scratch, scratch_floats);
 }
 

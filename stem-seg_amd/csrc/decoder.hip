@@ -42,8 +42,8 @@ void* profile_begin(int tag, double work, hipStream_t s) {
     ProfRec r;
     r.tag = tag; r.work = work;
     if (hipEventCreate(&r.a) != hipSuccess) return nullptr;
-    if (hipEventCreate(&r.b) != hipSuccess) { hipEventDestroy(r.a); return nullptr; }
-    hipEventRecord(r.a, s);
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return nullptr; }
+    (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
     return reinterpret_cast<void*>(g_prof.size());   // index + 1
 }
@@ -51,7 +51,7 @@ void profile_end(void* handle, hipStream_t s) {
     if (!handle) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     const size_t i = reinterpret_cast<size_t>(handle) - 1;
-    if (i < g_prof.size()) hipEventRecord(g_prof[i].b, s);
+    if (i < g_prof.size()) (void)hipEventRecord(g_prof[i].b, s);
 }
 
 struct DecoderPlan {
@@ -205,8 +205,8 @@ extern "C" int stemseg_hip_profile_read(double* out_host, int32_t n_tags) {
             out_host[r.tag * 3 + 1] += r.work;
             out_host[r.tag * 3 + 2] += 1.0;
         }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
     return STEMSEG_OK;
@@ -312,7 +312,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (rc) return rc;
     const int64_t V16 = (int64_t)p.T16 * p.h[1] * p.w[1], V8 = (int64_t)p.T8 * p.h[2] * p.w[2], V4 = (int64_t)T * p.h[3] * p.w[3];
     if (bs) SS_HIP(hipStreamWaitEvent(s16, bs->done[0], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16, nullptr, 0, &fuse_epi);
+    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16, ws + p.S[1], p.Sfloats[1], &fuse_epi);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
                          slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16);
@@ -323,7 +323,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
                  p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(s8, bs->done[1], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, nullptr, 0, &fuse_epi);
+    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, ws + p.S[2], p.Sfloats[2], &fuse_epi);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8);
     if (rc) return rc;
@@ -333,7 +333,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
                  p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);
+    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
     if (rc) return rc;
     // 5. heads (:131-143)
     if (desc->n_out > 8) {
