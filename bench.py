@@ -8,7 +8,8 @@
 One "step" = a batch of --clips-per-step (default 4) synthetic clips (each T=8 frames, padded 480x864, ResNet-101-FPN,
 DAVIS heads: embedding decoder + separate seediness decoder): ONE encoder pass over all their frames (the encoder is
 per-frame), then per clip 3-D decoders -> fused heads -> fg mask -> fg gather -> sequential clustering -> read-back of the
-clustering record (K, instance list), with the input frames already resident in HBM.  value = clips / s.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
+clustering record (K, instance list), with the input frames already resident in HBM.  The step is captured as a hipGraph
+per lane; --lanes (default 3) steps are in flight on their own streams and workspaces.  value = clips / s.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
 are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -122,6 +123,9 @@ def main():
     ap.add_argument("--clips-per-step", type=int, default=4,
                     help="clips that share one encoder pass per step (frames are independent in the encoder; stacking clips fills "
                          "its small-map launches); decoders, fg gather and clustering run per clip.  1 = one clip per step")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="captured steps in flight on one GPU, each with its own workspaces and stream (graph mode): the kernels of "
+                         "one step fill the tail rounds and memory-bound phases of the other")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -169,10 +173,11 @@ def main():
     # The ~330 launches of a step are captured ONCE into a hipGraph (ClipPipeline.capture: encoder, both decoders, fg
     # mask, gather, clustering rounds, all on one stream) and replayed per clip: the launch-bound tail of small kernels
     # no longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
-    graph = None
+    graph, lanes = None, []
     if args.graph:
         try:
-            graph = pipe.capture(clips[0], overlap=bool(args.graph_overlap), n_clips=NC)
+            lanes = [pipe.capture(clips[0], overlap=bool(args.graph_overlap), n_clips=NC, lane=k) for k in range(max(1, args.lanes))]
+            graph = lanes[0]
             mark("capture done")
         except Exception as e:  # noqa: BLE001
             import traceback
@@ -182,18 +187,39 @@ def main():
             pipe.model.overlap_decoders = overlap
             torch.cuda.synchronize()
 
+    pending = [None] * len(lanes)
+
     def step_graph(i):
-        return read_back(graph.run(clips[i % len(clips)]))
+        """Step i goes to lane i % L: first consume (read back) what that lane produced L steps ago, then enqueue the new
+        batch on the lane's stream -- L steps are in flight."""
+        k = i % len(lanes)
+        m = None
+        if pending[k] is not None:
+            with torch.cuda.stream(lanes[k].stream):
+                m = read_back(pending[k])
+        pending[k] = lanes[k].run_async(clips[i % len(clips)])
+        return m
+
+    def drain():
+        m = None
+        for k in range(len(lanes)):
+            if pending[k] is not None:
+                with torch.cuda.stream(lanes[k].stream):
+                    m = read_back(pending[k])
+                pending[k] = None
+        return m
 
     run = step_graph if graph is not None else step
-    for i in range(2):
-        meta = run(i)
+    for i in range(2 * max(1, len(lanes))):
+        meta = run(i) or meta
         mark("pre-run %d done" % i)
+    meta = drain() or meta
     sync()
     hip.profile_enable(graph is None)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        meta = run(i)
+        meta = run(i) or meta
+    meta = drain() or meta
     sync()
     dt = time.perf_counter() - t0
     mark("timed region done")
@@ -238,7 +264,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + "
                                    "seediness decoders, fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE,
-                       "clips_per_step": NC, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
+                       "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),

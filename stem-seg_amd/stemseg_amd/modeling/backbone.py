@@ -102,6 +102,7 @@ class ResNetFPN(nn.Module):
         self.out_channels, self.is_3d = out_channels, False
         self._packed, self._sig, self._ws = None, None, {}
         self.precision = "f32"    # "f32" | "bf16x3" (see stemseg_hip.h)
+        self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
 
     # ---- FrozenBN folding: w' = w * scale[:, None, None, None], b' = shift (exact: eps == 0) -------------------
     def _signature(self):
@@ -189,7 +190,7 @@ class ResNetFPN(nn.Module):
         w, _keep = self._pack()
         assert len(out_volumes) % 4 == 0 and T % (len(out_volumes) // 4) == 0
         d = self._desc(T, H, W, len(out_volumes) // 4)
-        key = (T, H, W, frames.device.index)
+        key = (T, H, W, frames.device.index, self.lane)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = hip.lib().stemseg_hip_encoder_workspace_bytes(C.byref(d))

@@ -64,6 +64,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
         self.detached = False     # True: the call does not join; ``join()`` must follow (twin-decoder overlap)
         self.precision = "f32"    # "f32": exact fp32 MFMA | "bf16x3": 3-term bf16 split MFMA with fp32 accumulation
+        self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
 
     # ---- to be provided by the concrete decoder ---------------------------------------------------
     def _head_spec(self):
@@ -139,7 +140,7 @@ class SqueezeExpandTrunk(nn.Module):
         d.concurrency = int(self.concurrency)
         d.detached = int(bool(self.detached) and self.concurrency >= 1)
         d.precision = hip.PRECISIONS[self.precision]
-        key = (T, H4, W4, layout, dev.index)
+        key = (T, H4, W4, layout, dev.index, self.lane)
         ws = self._workspaces.get(key)
         if ws is None:
             nbytes = hip.lib().stemseg_hip_decoder_workspace_bytes(C.byref(d))

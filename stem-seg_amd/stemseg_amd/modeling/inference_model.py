@@ -104,9 +104,19 @@ class InferenceModel(nn.Module):
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
         self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
+        self.lane = 0
         self.eval()
 
     has_semseg_head = property(lambda self: self._model.semseg_head is not None)
+
+    def set_lane(self, lane):
+        """Every cached workspace (encoder, decoders, zero-haloed FPN buffers) exists once per lane, so steps enqueued on
+        different streams under different lanes do not share scratch memory; the weights are shared."""
+        m = self._model
+        self.lane = int(lane)
+        for mod in (m.backbone, m.embedding_head, m.seediness_head, m.semseg_head):
+            if mod is not None:
+                mod.lane = self.lane
 
     def set_precision(self, precision):
         """'f32' (exact fp32 MFMA, default) or 'bf16x3' (3-term bf16 split on the bf16 matrix cores, fp32 accumulate)."""
@@ -120,7 +130,7 @@ class InferenceModel(nn.Module):
     def _padded_feature_buffers(self, T, H, W, dev, slot=0):
         """Four zero-haloed buffers [256][T+2][h+2][pitch], allocated once per shape (halos stay zero); ``slot`` selects one
         of several independent sets (one per clip when clips share an encoder pass)."""
-        key = (T, H, W, dev.index, slot)
+        key = (T, H, W, dev.index, slot, self.lane)
         if key not in self._pads:
             Cn = self._model.backbone.out_channels
             self._pads[key] = [hip.alloc_padded(Cn, T, H // s, W // s, dev) for s in (32, 16, 8, 4)]

@@ -449,6 +449,21 @@ def test_step_batch_shares_the_encoder_pass(hip):
         outs2 = g.run(torch.cat(clips, 0))
         for o, r in zip(outs2, outs):
             assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
+        # two lanes: independent workspaces and streams, both steps in flight at once, results identical to one lane
+        g1 = pipe.capture(torch.cat(clips, 0), n_clips=3, lane=1)
+        rev = torch.cat(clips[::-1], 0)
+        ref_rev = [{k: v.clone() for k, v in o.items() if torch.is_tensor(v)} for o in g.run(rev)]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            a = g.run_async(torch.cat(clips, 0))
+            b = g1.run_async(rev)
+            g.wait()
+            g1.wait()
+            torch.cuda.synchronize()
+            for o, r in zip(a, outs):
+                assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
+            for o, r in zip(b, ref_rev):
+                assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
     finally:
         config.load_preset("defaults")
 
