@@ -55,6 +55,19 @@ def test_cabi_struct_sizes_and_argument_errors():
     assert g["pitch"] == 220 and g["ts"] == 122 * 220 and g["cs"] == 10 * 122 * 220 and g["interior"] == 122 * 220 + 220 + 1
     assert ctypes.sizeof(hip.ClusterMeta) == 4 + 4 + 8 + 8 + 64 * 8 * 4 * 2 + 64 * 4
     assert l.stemseg_hip_cluster_workspace_bytes(1000) >= 4000
+    e = hip.EncoderDesc()
+    e.struct_bytes = ctypes.sizeof(hip.EncoderDesc)
+    for i, n in enumerate((3, 4, 23, 3)):
+        e.blocks[i] = n
+    e.T, e.H, e.W, e.out_channels, e.precision, e.n_clips = 32, 480, 864, 256, 0, 4
+    assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) > 32 * 64 * 240 * 432 * 4
+    e.n_clips = 3                                                     # 32 frames are not 3 whole clips
+    assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0 and b"whole clips" in l.stemseg_hip_last_error()
+    e.n_clips, e.W = 4, 850                                           # frame size must be padded to multiples of 32
+    assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0
+    # mask materialisation: the crop must fit the up-sampled mask (davis.py:91-96 raises the same way)
+    rc = l.stemseg_hip_resample_instance_masks(ctypes.c_void_p(16), 24, 32, ctypes.c_float(4.0), 97, 128, 70, 100, ctypes.c_void_p(16), None)
+    assert rc != 0 and b"should be <= padded dims" in l.stemseg_hip_last_error()
 
 
 # ------------------------------------------------------------------------------------------------ small host functions

@@ -21,9 +21,9 @@ if [[ $what == all || $what == bench ]]; then
 fi
 if [[ $what == all || $what == prof ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1) > gpurun_out/prof.log 2>&1
   echo "prof exit $?" >> gpurun_out/prof.log
-  find gpurun_out/prof -name "*stats*" | head; tail -3 gpurun_out/prof.log
+  db=$(find gpurun_out/prof -name "*.db" | head -1); python tools/prof_steady.py $db 2 > gpurun_out/prof_steady.txt 2>&1; head -12 gpurun_out/prof_steady.txt; tail -3 gpurun_out/prof.log
 fi
 if [[ $what == pmc ]]; then
   # PMC passes on the dominant kernel only, counters in their own runs (no trace domains besides kernel-trace)
