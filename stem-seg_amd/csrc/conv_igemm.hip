@@ -634,6 +634,10 @@ static RowPlan plan_rows(const ConvKParams& p0, bool have_scratch, int64_t scrat
         }
     }
     if (best.cost > 0.97 * t_plain) best = RowPlan{t_plain, n, 1};      // not worth the extra launches
+    // STEMSEG_PLANNER=0: plain launches only (A/B measurements; with several steps in flight the other steps' kernels fill
+    // the tail rounds anyway and the cut only costs slab traffic)
+    static const bool off = [] { const char* e = getenv("STEMSEG_PLANNER"); return e && e[0] == '0'; }();
+    if (off) best = RowPlan{t_plain, n, 1};
     return best;
 }
 

@@ -1,9 +1,4 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
-STEMSEG_BENCH_WATCHDOG=150 timeout 200 python bench.py > gpurun_out/bench_final.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench_final.log > gpurun_out/bench_final.json; cut -c1-200 gpurun_out/bench_final.json
-STEMSEG_BENCH_WATCHDOG=100 timeout 150 python bench.py --precision bf16x3 --no-cpu-baseline > gpurun_out/bench_bf16x3.log 2>&1; echo "bench bf exit $?"; tail -1 gpurun_out/bench_bf16x3.log > gpurun_out/bench_bf16x3.json; cut -c1-200 gpurun_out/bench_bf16x3.json
-STEMSEG_BENCH_WATCHDOG=100 timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/bench_torchrun1.log 2>&1; echo "torchrun exit $?"; tail -1 gpurun_out/bench_torchrun1.log | cut -c1-160
-rm -rf gpurun_out/prof_graph
-(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_graph -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --lanes 1) > gpurun_out/prof_graph.log 2>&1; echo "prof graph exit $?"
-db=$(find gpurun_out/prof_graph -name "*.db" | head -1); python tools/prof_steady.py $db 2 > gpurun_out/prof_graph_steady.txt 2>&1; head -3 gpurun_out/prof_graph_steady.txt | cut -c1-170
-rm -f gpurun_out/prof_graph/*.db gpucore.*
-timeout 600 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider > gpurun_out/tests.log 2>&1; echo "tests exit $?"; tail -2 gpurun_out/tests.log | cut -c1-200
+for pl in 1 0 1 0; do
+STEMSEG_PLANNER=$pl STEMSEG_BENCH_WATCHDOG=100 timeout 150 python bench.py --steps 12 --warmup 2 --no-cpu-baseline > gpurun_out/bench_s.log 2>&1; echo -n "planner=$pl lanes=3: "; tail -1 gpurun_out/bench_s.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done
