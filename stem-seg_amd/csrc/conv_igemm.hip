@@ -53,9 +53,15 @@ struct ConvKParams {
 // fp32-MFMA rate.  k-groups of 16: lane half h carries CPH channels x TPG taps (CPH * TPG = 8).
 // DB: double-buffered LDS with a 2-channel chunk -- the next chunk is prefetched into registers under the MFMA stream and
 // written to the OTHER buffer, so a chunk costs one barrier and no exposed load latency (big 3x3x3 tile, fp32 only).
-template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false, bool DB_ = false>
+// FLAT (PMAX > 0): the N tile is a run of NSEG * 32 consecutive positions of the zero-haloed PLANE (row pitch <= PMAX floats)
+// instead of ROWS x 32 columns: a tap is the flat offset dy * pitch + dx, so maps whose width is not a multiple of 32
+// (W = 54: 64 columns computed for 54; flat: 56 for 54) lose almost nothing to tile quantisation.  Junk positions (halo
+// columns) are computed and not stored.  fp32 only, scalar epilogue.
+template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false, bool DB_ = false,
+          int PMAX_ = 0>
 struct ConvCfg {
-    static constexpr bool PIPE = PIPE_, BF = BF_, DB = DB_;
+    static constexpr bool PIPE = PIPE_, BF = BF_, DB = DB_, FLAT = PMAX_ > 0;
+    static constexpr int PMAX = PMAX_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
     static constexpr int NTHREADS = 64 * WM * WN;
@@ -64,7 +70,9 @@ struct ConvCfg {
     static constexpr int ROWS = NSEG / COLS;
     static constexpr int RH = ROWS + KH - 1;
     static constexpr int XP = ((COLS * 32 + KW - 1) + 3) / 4 * 4;
-    static constexpr int IN_CH_STRIDE = KT * RH * XP;
+    static constexpr int NT = NSEG * 32;                                // FLAT: voxels (flat plane positions) per tile
+    static constexpr int FL = NT + 2 * PMAX + 8;                        // FLAT: staged run per (channel, dt): tile + one row and 4 either side
+    static constexpr int IN_CH_STRIDE = FLAT ? KT * FL : KT * RH * XP;
     static constexpr int IN_FLOATS = CK * IN_CH_STRIDE;
     // bf16x3 grouping: taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
     static constexpr int TPG = TAPS >= 27 ? 4 : (TAPS >= 9 ? 2 : 1);
@@ -79,6 +87,7 @@ struct ConvCfg {
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
     static_assert(CK % 4 == 0 || (DB && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (DB)");
     static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+    static_assert(!FLAT || (!BF && !DB && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: fp32 3x3 taps only");
 };
 
 template <class C>
@@ -104,7 +113,9 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y;
     const int t = bx / p.tiles_y;
-    const int x0 = tx * (C::COLS * 32), y0 = ty * C::ROWS;
+    const int x0 = C::FLAT ? 0 : tx * (C::COLS * 32), y0 = C::FLAT ? 0 : ty * C::ROWS;
+    const int pitch = (int)p.in_ys;                           // FLAT: row pitch of the haloed plane
+    const int F0 = pitch + tx * C::NT;                        // FLAT: first flat position of this tile (row 1, column 0)
     const int co0 = blockIdx.y * C::MT;
 
     f32x16 acc[C::MI][C::NI];
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
-        b_ptr[ni] = in_lds + half * C::IN_CH_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+        b_ptr[ni] = C::FLAT ? in_lds + half * C::IN_CH_STRIDE + s * 32 + l31 + 3       // staged run starts at F0 - pitch - 4
+                            : in_lds + half * C::IN_CH_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
     }
 
     const float* b_ptr_bf[C::NI];      // bf16x3: lane half h owns channels [h*CPH, (h+1)*CPH) of every k-group
@@ -134,11 +146,21 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 
     // ---- staging helpers ------------------------------------------------------------------------------
     constexpr int XQ = C::XP / 4;
-    constexpr int NQ = C::CK * C::KT * C::RH * XQ;            // 16-B pieces of the input halo tile
+    constexpr int NQ = C::FLAT ? C::IN_FLOATS / 4 : C::CK * C::KT * C::RH * XQ;   // 16-B pieces of the input halo tile
     constexpr int MQ = C::MT / 4;
     constexpr int NWQ = C::BF ? 2 * C::G * 2 * C::MT : C::CK * C::TAPS * MQ;   // 16-B pieces of the weight slab
     constexpr int IN_PT = (NQ + C::NTHREADS - 1) / C::NTHREADS, W_PT = (NWQ + C::NTHREADS - 1) / C::NTHREADS;
     auto fetch_in = [&](int c0, int q) -> float4 {            // piece q of the input tile for chunk c0 (vec4 layout)
+        if constexpr (C::FLAT) {                              // [c][dt][FL]: flat run of the plane from F0 - pitch - 4
+            constexpr int FQ = C::FL / 4;
+            const int j4 = q % FQ, rr = q / FQ, dt = rr % C::KT, c = rr / C::KT;
+            const int f = F0 - pitch - 4 + 4 * j4;
+            const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + c < p.Cin && f >= 0 && 4 * j4 < C::NT + 2 * pitch + 8 && tile_base + rel + 4 <= p.in_limit)
+                v = *reinterpret_cast<const float4*>(in_tile + rel);
+            return v;
+        }
         const int xq = q % XQ;
         int rr = q / XQ;
         const int r = rr % C::RH;
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     auto stage_direct = [&](int c0) {                         // global -> LDS, no overlap (scalar fallback for odd strides)
         if (p.vec4) {
             for (int q = tid; q < NQ; q += C::NTHREADS) *reinterpret_cast<float4*>(in_lds + q * 4) = fetch_in(c0, q);
-        } else {
+        } else if constexpr (!C::FLAT) {                      // (flat tiles are only launched on 16-B aligned volumes)
             constexpr int NE = C::CK * C::KT * C::RH * C::XP;
             for (int q = tid; q < NE; q += C::NTHREADS) {
                 const int xx = q % C::XP;
@@ -239,6 +261,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
             return;
         }
         constexpr int NSUB = C::CK >= 4 ? C::CK / 4 : 1, NCP = C::CK >= 4 ? 2 : 1, WROWS = C::CK >= 4 ? 4 : 2;
+        const float* bdy[C::NI][3];                           // FLAT: row dy of the taps = + dy * pitch (runtime), rest immediates
+        if constexpr (C::FLAT) {
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni) {
+                bdy[ni][0] = b_ptr[ni]; bdy[ni][1] = b_ptr[ni] + pitch; bdy[ni][2] = b_ptr[ni] + 2 * pitch;
+            }
+        }
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
 #pragma unroll
@@ -251,12 +280,16 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
                         for (int cp = 0; cp < NCP; ++cp) {
                             const int tap = (dt * C::KH + dy) * C::KW + dx;
                             const int wrow = (sub * C::TAPS + tap) * WROWS + cp * 2;
-                            const int boff = (sub * 4 + cp * 2) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
+                            const int boff = C::FLAT ? (sub * 4 + cp * 2) * C::IN_CH_STRIDE + dt * C::FL + dx
+                                                     : (sub * 4 + cp * 2) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
                             float a[C::MI], b[C::NI];
 #pragma unroll
                             for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[buf_off + wrow * C::MT + mi * 32];
 #pragma unroll
-                            for (int ni = 0; ni < C::NI; ++ni) b[ni] = b_ptr[ni][buf_off + boff];
+                            for (int ni = 0; ni < C::NI; ++ni) {
+                                if constexpr (C::FLAT) b[ni] = bdy[ni][dy][boff];
+                                else b[ni] = b_ptr[ni][buf_off + boff];
+                            }
 #pragma unroll
                             for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
@@ -345,7 +378,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 
     // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel) ----
     const int co_base = co0 + wm * (C::MI * 32);
-    if (p.vec_epi) {
+    if (p.vec_epi && !C::FLAT) {
         // 16-B stores: each wave transposes its 32x32 accumulator tiles through LDS so that a lane owns 4 consecutive
         // voxels of one channel (the MFMA layout gives it 16 channels of ONE voxel -> 4-B stores, 4x the instructions)
         __syncthreads();                                       // all waves are done with the staged tiles
@@ -389,8 +422,13 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
-        const int y = y0 + s / C::COLS;
-        const int x = x0 + (s % C::COLS) * 32 + l31;
+        int y = y0 + s / C::COLS;
+        int x = x0 + (s % C::COLS) * 32 + l31;
+        if constexpr (C::FLAT) {                               // flat position -> (row, column) of the haloed plane -> output (y, x)
+            const int f = F0 + s * 32 + l31, y1 = f / pitch, x1 = f - y1 * pitch;
+            y = y1 - 1;
+            x = (x1 >= 1) ? x1 - 1 : p.W;                      // halo columns: nothing to store
+        }
         if (y < p.H && x < p.W) {
             int64_t off, roff = 0;
             if (p.dec_W > 0) {      // flat [C][V] launch: x is the voxel index, decode it for the destination layout
@@ -536,6 +574,17 @@ using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 
 using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
 using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true>;   //  64 co x (8 rows x 32 cols)
 
+// flat-tile forms for maps whose width wastes >= 10 % of a 32-column tile (8x / 16x maps: pitch 112 / 56)
+using K2FlatBig = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, false, false, 112>;   // 128 co x 256 flat positions
+using K2FlatMed = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, false, false, 112>;   // 128 co x 128
+using K3FlatMed = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 112>;   // 128 co x 128
+using K3FlatSmall = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 112>; // 128 co x 64
+// (pitch <= 56: 16x maps -- the staged run is tile + 2 * PMAX + 8 floats per channel plane, so a tighter PMAX stages less)
+using K2FlatBig56 = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, false, false, 56>;
+using K2FlatMed56 = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, false, false, 56>;
+using K3FlatMed56 = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 56>;
+using K3FlatSmall56 = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 56>;
+
 // bf16x3 twins of the tile shapes (register prefetch only where the wider fragments still fit 256 VGPRs)
 using X3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, true>;
 using X3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true, true>;
@@ -554,8 +603,10 @@ constexpr double CU_FLOPS_F32 = 0.46e12;
 
 template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0) {
-    p.tiles_x = (int)ceil_div(p.W, C::COLS * 32);
-    p.tiles_y = (int)ceil_div(p.H, C::ROWS);
+    p.tiles_x = C::FLAT ? (int)ceil_div((int64_t)p.H * p.in_ys, C::NT) : (int)ceil_div(p.W, C::COLS * 32);
+    p.tiles_y = C::FLAT ? 1 : (int)ceil_div(p.H, C::ROWS);
+    const int out_vec = p.vec_epi;                       // true output rows are 16-B aligned (decides the reduce kernel's form)
+    if (C::FLAT) p.vec_epi = 0;
     // split-K over the input-channel chunks when the layer alone cannot give every CU two workgroups
     const int nchunks = (int)ceil_div(p.Cin, C::CK);
     const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.T * ceil_div(p.Cout, C::MT);
@@ -567,7 +618,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     ksplit = (int)ceil_div(nchunks, p.chunks_per_split);
     SplitReduceParams rp;
     // 16-B reduce: the true output (and residual) rows are aligned (vec_epi as computed by the caller) and W % 4 == 0
-    const bool rp_vec = p.vec_epi && p.dec_W == 0 && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) && (slab % 4 == 0);
+    const bool rp_vec = out_vec && p.dec_W == 0 && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) && (slab % 4 == 0);
     if (ksplit > 1) {
         rp.partial = scratch; rp.bias = p.bias; rp.res = p.res; rp.out = p.out;
         rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys; rp.res_cs = p.res_cs; rp.res_ts = p.res_ts; rp.res_ys = p.res_ys;
@@ -577,11 +628,12 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         p.out = scratch; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.dec_H = p.dec_W = 0;
         p.out_cs = (int64_t)p.T * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
         p.out_split_stride = slab;
-        p.vec_epi = (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0);
+        p.vec_epi = !C::FLAT && (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0);
     } else p.out_split_stride = 0;
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT), (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
-    const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + C::ROWS : C::ROWS);   // 8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
+    constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
+    const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : tile_rows);   // 8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
     if (ksplit > 1) {
@@ -685,6 +737,19 @@ static int launch_planned(const ConvKParams& p, hipStream_t s, float* scratch, i
     return launch_rows<Big>(p, s, scratch, scratch_floats, a);
 }
 
+// fraction of the computed N positions that are real outputs, 2-D tile vs flat tile
+template <class C>
+static double tile_efficiency(const ConvKParams& p) {
+    if (C::FLAT) return (double)p.H * p.W / ((double)C::NT * ceil_div((int64_t)p.H * p.in_ys, C::NT));
+    return (double)p.H * p.W / ((double)C::ROWS * ceil_div(p.H, C::ROWS) * C::COLS * 32.0 * ceil_div(p.W, C::COLS * 32));
+}
+template <class Flat, class Tile2D>
+static bool prefer_flat(const ConvKParams& p, int tile_cfg, bool bf) {
+    static const bool off = [] { const char* e = getenv("STEMSEG_FLAT"); return e && e[0] == '0'; }();
+    if (off || bf || !p.vec4 || tile_cfg > 0 || p.dec_W > 0 || p.in_ys > Flat::PMAX || p.in_ys % 4 != 0 || p.W + 2 > p.in_ys) return false;
+    return tile_efficiency<Flat>(p) > 1.08 * tile_efficiency<Tile2D>(p);
+}
+
 template <class C>
 static int64_t num_workgroups(int Cout, int T, int H, int W) {
     return ceil_div(W, C::COLS * 32) * ceil_div(H, C::ROWS) * T * ceil_div(Cout, C::MT);
@@ -733,6 +798,10 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K3Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
             else cfg = 3;
         }
+        if (cfg == 2 && prefer_flat<K3FlatMed56, K3Med>(p, tile_cfg, bf)) return launch_cfg<K3FlatMed56>(p, s, scratch, scratch_floats);
+        if (cfg == 3 && prefer_flat<K3FlatSmall56, K3Small>(p, tile_cfg, bf)) return launch_cfg<K3FlatSmall56>(p, s, scratch, scratch_floats);
+        if (cfg == 2 && prefer_flat<K3FlatMed, K3Med>(p, tile_cfg, bf)) return launch_cfg<K3FlatMed>(p, s, scratch, scratch_floats);
+        if (cfg == 3 && prefer_flat<K3FlatSmall, K3Small>(p, tile_cfg, bf)) return launch_cfg<K3FlatSmall>(p, s, scratch, scratch_floats);
         if (bf) {
             if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);   // (row balancing measured slower here)
             if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
@@ -759,6 +828,10 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= need) cfg = 2;
             else cfg = 3;
         }
+        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg, bf)) return launch_cfg<K2FlatBig56>(p, s, scratch, scratch_floats);
+        if (cfg >= 2 && prefer_flat<K2FlatMed56, K2Med>(p, tile_cfg, bf)) return launch_cfg<K2FlatMed56>(p, s, scratch, scratch_floats);
+        if (cfg == 1 && prefer_flat<K2FlatBig, K2Big>(p, tile_cfg, bf)) return launch_cfg<K2FlatBig>(p, s, scratch, scratch_floats);
+        if (cfg >= 2 && prefer_flat<K2FlatMed, K2Med>(p, tile_cfg, bf)) return launch_cfg<K2FlatMed>(p, s, scratch, scratch_floats);
         if (bf) {
             if (cfg == 1) return launch_cfg<X2Big>(p, s, scratch, scratch_floats);
             if (cfg == 2) return launch_cfg<X2Med>(p, s, scratch, scratch_floats);
