@@ -246,6 +246,26 @@ def test_encoder_batch_of_8_odd_size_vs_oracle(hip, precision):
         assert report("encoder T=8 96x160 1/%d %s" % (s, precision), feats[s].cpu().numpy() / scale, ref[s].numpy() / scale) <= 1e-4
 
 
+def test_encoder_full_size_480x864_two_clips_vs_oracle(hip):
+    """BASELINE config 1 frame size (padded 480x864: the 8x / 16x maps are W = 108 / 54, where the flat-tile conv runs), four
+    frames as TWO clips of two through one encoder pass (n_clips = 2), R-50, vs the CPU oracle."""
+    from stemseg_amd.modeling.backbone import ResNetFPN
+    bb = ResNetFPN("R-50-FPN").eval()
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in bb.state_dict().items()], 53, prefix="backbone.")
+    bb.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(bb.state_dict()[k].shape) for k, v in sd.items()})
+    x = torch.from_numpy(synth.synth_frames(4, 480, 864, seed=53).astype(np.float32)).permute(0, 3, 1, 2) - \
+        torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
+    ref = oenc.resnet_fpn(x, {"backbone." + k: v for k, v in sd.items()}, "R-50-FPN")
+    bb = bb.cuda()
+    outs = [[torch.full((256, 2, 480 // s, 864 // s), float("nan"), device="cuda") for s in (4, 8, 16, 32)] for _ in range(2)]
+    bb.run_backbone_into(x.cuda(), [hip.dense_volume(o) for clip in outs for o in clip])
+    for c in range(2):
+        for o, s in zip(outs[c], (4, 8, 16, 32)):
+            r = ref[s][2 * c:2 * c + 2].permute(1, 0, 2, 3).numpy()
+            scale = max(1.0, float(np.abs(r).max()))
+            assert report("encoder 480x864 clip %d 1/%d" % (c, s), o.cpu().numpy() / scale, r / scale) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ GN / pool / upsample / heads
 @pytest.mark.parametrize("shape", [(256, 8, 4, 7), (128, 8, 30, 54), (64, 3, 5, 5)])
 def test_groupnorm_stats(hip, shape):
