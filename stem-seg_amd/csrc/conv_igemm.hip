@@ -390,31 +390,53 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
             const int s = wn * C::NI + ni;
             const int y = y0 + s / C::COLS;
             const int xs = x0 + (s % C::COLS) * 32;            // first voxel of this 32-wide segment
+            // residual and bias of two 32-channel sub-tiles at a time are requested up front: otherwise each of the loads
+            // below is waited for on its own, right where it is used, and the epilogue of a short-K conv becomes a chain of
+            // HBM latencies
+            constexpr int MG = C::MI >= 2 ? 2 : 1;
 #pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi) {
+            for (int m0 = 0; m0 < C::MI; m0 += MG) {
+                float4 rres[MG][4];
+                float rbias[MG][4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tl[((r & 3) + 8 * (r >> 2) + 4 * half) * TP + l31] = acc[mi][ni][r];
-                // no barrier needed: the tile buffer is private to this wave (wave-synchronous LDS traffic)
-                __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the ds_writes above have landed
+                for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = (lane >> 3) + 8 * j, c4 = (lane & 7) * 4;
-                    const int co = co_base + mi * 32 + row;
-                    const int x = xs + c4;
-                    if (y < p.H && x < p.W && co < p.Cout) {    // W % 4 == 0 is guaranteed by the launcher for this path
-                        float4 v = *reinterpret_cast<const float4*>(tl + row * TP + c4);
-                        const float bv = p.bias ? p.bias[co] : 0.f;
-                        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                        const int64_t off = (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
-                        if (p.res) {
-                            const float4 rv = *reinterpret_cast<const float4*>(p.res + (int64_t)co * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
-                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = (lane >> 3) + 8 * j, c4 = (lane & 7) * 4;
+                        const int co = co_base + (m0 + mg) * 32 + row;
+                        const int x = xs + c4;
+                        rres[mg][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        rbias[mg][j] = 0.f;
+                        if (y < p.H && x < p.W && co < p.Cout) {
+                            if (p.res) rres[mg][j] = *reinterpret_cast<const float4*>(p.res + (int64_t)co * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
+                            if (p.bias) rbias[mg][j] = p.bias[co];
                         }
-                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                        *reinterpret_cast<float4*>(p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)co * p.out_cs + off) = v;
                     }
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const int mi = m0 + mg;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tl[((r & 3) + 8 * (r >> 2) + 4 * half) * TP + l31] = acc[mi][ni][r];
+                    // no barrier needed: the tile buffer is private to this wave (wave-synchronous LDS traffic)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the ds_writes above have landed
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = (lane >> 3) + 8 * j, c4 = (lane & 7) * 4;
+                        const int co = co_base + mi * 32 + row;
+                        const int x = xs + c4;
+                        if (y < p.H && x < p.W && co < p.Cout) {    // W % 4 == 0 is guaranteed by the launcher for this path
+                            float4 v = *reinterpret_cast<const float4*>(tl + row * TP + c4);
+                            const float bv = rbias[mg][j];
+                            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                            const int64_t off = (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+                            const float4 rv = rres[mg][j];         // (acc + bias) + residual, as before
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            *reinterpret_cast<float4*>(p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)co * p.out_cs + off) = v;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);            // reads done before the next tile overwrites the buffer
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);            // reads done before the next tile overwrites the buffer
             }
         }
         return;
