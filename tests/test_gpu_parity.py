@@ -875,6 +875,74 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
+def test_sequence_end_to_end_tracks_and_masks(hip):
+    """A 14-frame sequence through the whole device path -- TrackGenerator (pre-processing, encoder, decoders, fg mask from the
+    clip-averaged seediness, gather, clustering, Hungarian stitching) and MaskMaterializer -- against the ORACLE chain (CPU
+    clustering / stitching twin, oracle mask resampling) run on the same head outputs: track ids per point, point counts,
+    lifetimes and final masks must be identical.  The sharded driver (run_sequence_sharded, single process) must agree too."""
+    from oracle import masks as omask
+    from stemseg_amd import config
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.main import TrackGenerator, fg_masks_from_seediness
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    from stemseg_amd.inference.output_utils import MaskMaterializer
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import run_sequence_sharded
+    from tests.oracle_ops import OracleChainerOps
+    config.load_preset("davis")
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 96, 128
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        model = InferenceModel()
+        sd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 61))).reshape(v.shape) for k, v in sd.items()}
+        new["seediness_head.conv_out.weight"] = new["seediness_head.conv_out.weight"] * 12.0
+        model._model.load_state_dict(new)
+        model = model.cuda()
+        frames = synth.synth_frames(14, 90, 120, seed=61)                   # resized to 96x128 by the pre-processing kernel
+        # thresholds from the data (random-init weights give an arbitrary seediness range): half of the pixels foreground,
+        # seeds from the upper quartile
+        from stemseg_amd.modeling.inference_model import preprocess_frames
+        probe = model.embed_frames(preprocess_frames(frames[:8])[0])[2].flatten().float()
+        thr = float(probe.median())
+        config.cfg.CLUSTERING.MIN_SEEDINESS_PROB = float(probe.quantile(0.75))
+        tg = TrackGenerator(model, "davis", seediness_thresh=thr, frame_overlap=4)
+        embeddings, fg, _ = tg.do_inference([f for f in frames])
+        (track, counts, life), mask_idxes, _, _, meta = tg.do_clustering(embeddings, fg)
+        assert len(track) == 14 and fg.shape == (14, 24, 32)
+        # oracle chain on the same head outputs
+        dicts = [dict(frames=list(e.subseq_frames), embeddings=e.embeddings.cpu(), bandwidths=e.bandwidths.cpu(), seediness=e.seediness.cpu())
+                 for e in embeddings]
+        c = config.cfg.CLUSTERING
+        ref_chain = OnlineChainer(SequentialClustering(c.PRIMARY_PROB_THRESHOLD, c.SECONDARY_PROB_THRESHOLD, c.MIN_SEEDINESS_PROB, 2,
+                                                       config.cfg.TRAINING.LOSSES.EMBEDDING.FREE_DIM_STDS, "cpu"), 1.0, ops=OracleChainerOps())
+        (rtrack, rcounts, rlife), ridx, _, _, rmeta = ref_chain.process(fg.cpu(), dicts)
+        n_inst = 0
+        for t in range(14):
+            assert torch.equal(track[t].cpu(), rtrack[t]), "frame %d: track labels differ" % t
+            n_inst = max(n_inst, int(track[t].max().item()) if track[t].numel() else 0)
+        assert dict(counts) == dict(rcounts) and dict(life) == dict(rlife) and n_inst >= 2 and sum(counts.values()) > 1000
+        assert [m["instance_labels"] for m in meta] == [m["instance_labels"] for m in rmeta]
+        # sharded driver, one process: identical tracks
+        clips_seen = {tuple(e.subseq_frames): e for e in embeddings}
+        (strack, scounts, _), _, _, _, _ = run_sequence_sharded(
+            14, lambda fr: (lambda e: (e.embeddings, e.bandwidths, e.seediness))(clips_seen[tuple(sorted(set(fr)))]), tg.chainer, "davis",
+            frame_overlap=4, seediness_thresh=thr)
+        assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(strack, track)) and dict(scounts) == dict(counts)
+        # masks at the original 90x120 size
+        keep, masks = MaskMaterializer(-1).process_sequence((90, 120), mask_idxes, track, life, (24, 32), 4.0, 10)
+        maps = np.zeros((14, 24, 32), np.int64)
+        for t in range(14):
+            maps[t][mask_idxes[t][0].cpu().numpy(), mask_idxes[t][1].cpu().numpy()] = track[t].cpu().numpy()
+        ref_masks = omask.condensed_masks(maps, omask.instances_to_keep(dict(life), -1, 10), (90, 120), 96, 128).numpy()
+        assert keep == omask.instances_to_keep(dict(life), -1, 10)
+        bad = masks.cpu().numpy() != ref_masks
+        print("[parity] sequence end to end: %d tracks kept, %d fg points, masks differ in %d / %d pixels" % (len(keep), sum(counts.values()), bad.sum(), bad.size))
+        assert bad.mean() < 1e-4
+    finally:
+        config.load_preset("defaults")
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_clip_pipeline_end_to_end_vs_oracle(hip, precision):
     """One clip through ClipPipeline.step (the bench's unit of work) at a reduced size vs the oracle pipeline:
