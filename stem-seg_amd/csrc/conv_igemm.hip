@@ -268,36 +268,45 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
                 bdy[ni][0] = b_ptr[ni]; bdy[ni][1] = b_ptr[ni] + pitch; bdy[ni][2] = b_ptr[ni] + 2 * pitch;
             }
         }
+        // software-pipelined k-steps: the operands of step i + 1 are requested from LDS BEFORE the eight MFMAs of step i are
+        // issued, so their latency hides under 512 cycles of matrix work (left to itself the compiler reads each A pair right
+        // in front of the MFMAs that consume it and waits for it there).  Measured neutral at 2 waves per SIMD -- the other
+        // wave already covered those waits -- but it keeps a single resident wave from stalling.
+        constexpr int NSTEPS = NSUB * C::TAPS * NCP;
+        auto ld = [&](const int i, float (&a)[C::MI], float (&b)[C::NI]) {
+            const int cp = i % NCP, tap = (i / NCP) % C::TAPS, sub = i / (NCP * C::TAPS);
+            const int dt = tap / (C::KH * C::KW), dy = (tap / C::KW) % C::KH, dx = tap % C::KW;
+            const int wrow = (sub * C::TAPS + tap) * WROWS + cp * 2;
+            const int boff = C::FLAT ? (sub * 4 + cp * 2) * C::IN_CH_STRIDE + dt * C::FL + dx
+                                     : (sub * 4 + cp * 2) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
+            for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[buf_off + wrow * C::MT + mi * 32];
 #pragma unroll
-            for (int dt = 0; dt < C::KT; ++dt) {
+            for (int ni = 0; ni < C::NI; ++ni) {
+                if constexpr (C::FLAT) b[ni] = bdy[ni][dy][boff];
+                else b[ni] = b_ptr[ni][buf_off + boff];
+            }
+        };
+        auto mm = [&](const float (&a)[C::MI], const float (&b)[C::NI]) {
 #pragma unroll
-                for (int dy = 0; dy < C::KH; ++dy) {
+            for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-                    for (int dx = 0; dx < C::KW; ++dx) {
+                for (int ni = 0; ni < C::NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        };
+        float a0[C::MI], b0[C::NI], a1[C::MI], b1[C::NI];
+        ld(0, a0, b0);
 #pragma unroll
-                        for (int cp = 0; cp < NCP; ++cp) {
-                            const int tap = (dt * C::KH + dy) * C::KW + dx;
-                            const int wrow = (sub * C::TAPS + tap) * WROWS + cp * 2;
-                            const int boff = C::FLAT ? (sub * 4 + cp * 2) * C::IN_CH_STRIDE + dt * C::FL + dx
-                                                     : (sub * 4 + cp * 2) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
-                            float a[C::MI], b[C::NI];
-#pragma unroll
-                            for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[buf_off + wrow * C::MT + mi * 32];
-#pragma unroll
-                            for (int ni = 0; ni < C::NI; ++ni) {
-                                if constexpr (C::FLAT) b[ni] = bdy[ni][dy][boff];
-                                else b[ni] = b_ptr[ni][buf_off + boff];
-                            }
-#pragma unroll
-                            for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-                                for (int ni = 0; ni < C::NI; ++ni)
-                                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                        }
-                    }
-                }
+        for (int i = 0; i < NSTEPS; i += 2) {
+            if (i + 1 < NSTEPS) ld(i + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);             // (the scheduler would otherwise sink the reads back to their uses)
+            mm(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < NSTEPS) {
+                if (i + 2 < NSTEPS) ld(i + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
