@@ -86,9 +86,10 @@ def make_clip(seed, device):
     return x.to(device)
 
 
-def cpu_baseline(sd, frames_cpu):
+def cpu_baseline(sd, frames_cpu, gpu_out=None):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned against reference-generated goldens)
-    on the host cores: ONE clip of the same workload, 1 timed run (no warm-up; ~10-30 s)."""
+    on the host cores: ONE clip of the same workload, 1 timed run (no warm-up; ~10-30 s).  With ``gpu_out`` (the HIP path's
+    result for the same clip) the two are also compared: the full-size parity check of this very run."""
     from oracle import pipeline as opipe
     # more threads than ~32 make torch's CPU conv / GroupNorm path slower on the 2-socket host (141 s with 256)
     n = min(os.cpu_count() or 1, 32)
@@ -96,9 +97,27 @@ def cpu_baseline(sd, frames_cpu):
     t0 = time.time()
     out = opipe.embed_and_cluster_clip(frames_cpu, sd, BACKBONE, "xyff", 4, True, free_dim_stds=[0.3, 0.3])
     dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 clip (T=8, 480x864, %s, DAVIS heads), 1 timed run incl. first-call overhead; %d fg points, %d instances"
-                      % (BACKBONE, out["labels"].shape[0], len(out["meta"]["instance_labels"]))}
+    res = {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "1 clip (T=8, 480x864, %s, DAVIS heads), 1 timed run incl. first-call overhead; %d fg points, %d instances"
+                     % (BACKBONE, out["labels"].shape[0], len(out["meta"]["instance_labels"]))}
+    if gpu_out is not None:
+        import numpy as np
+        g_emb, g_seed = gpu_out["emb"].cpu().numpy(), gpu_out["seed"].cpu().numpy()
+        g_fg = gpu_out["fg"].cpu().numpy().astype(bool)
+        n = int(gpu_out["frame_offsets"][-1].item())
+        g_lab = np.full(g_fg.size, -2, np.int64)
+        g_lab[gpu_out["voxel_index"][:n].cpu().numpy()] = gpu_out["labels"][:n].cpu().numpy()
+        c_fg = np.asarray(out["fg"]).astype(bool)
+        c_lab = np.full(c_fg.size, -2, np.int64)
+        c_lab[np.flatnonzero(c_fg.reshape(-1))] = np.asarray(out["labels"])
+        both = (g_fg & c_fg).reshape(-1)
+        res["parity_vs_hip_path"] = {
+            "emb_max_abs_err": float(np.abs(g_emb - np.asarray(out["emb"])).max()),
+            "seediness_max_abs_err": float(np.abs(g_seed - np.asarray(out["seed"])).max()),
+            "fg_points_hip": int(g_fg.sum()), "fg_points_cpu": int(c_fg.sum()), "fg_mask_disagreements": int((g_fg != c_fg).sum()),
+            "labels_identical_fraction_on_common_fg": float((g_lab[both] == c_lab[both]).mean()) if both.any() else None,
+            "note": "fg / label differences come from points whose seediness or probability sits within the float tolerance of a threshold"}
+    return res
 
 
 def mark(msg):
@@ -279,7 +298,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items()}, clips[0][:T].cpu())
+                pipe.model.set_lane(0)
+                gpu_out = pipe.step(clips[0][:T].contiguous())
+                torch.cuda.synchronize()
+                res["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items()}, clips[0][:T].cpu(), gpu_out)
             except Exception as e:  # noqa: BLE001  (never lose the GPU number because the baseline leg failed)
                 res["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(res))
