@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
-TRAFFIC_BLOCK4X_GB = 1.15         # measured offline with PMC counters (cannot be read from inside the process)
+TRAFFIC_BLOCK4X_GB = 0.87         # measured offline with PMC counters (cannot be read from inside the process)
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # same guide: bf16 MFMA, dense (the 2:1-sparse 5 PF figure is not used)
 T, H, W = 8, 480, 864             # BASELINE config 1: DAVIS-shape 480p (480x854 padded to a multiple of 32)
 BACKBONE = "R-101-FPN"

@@ -45,6 +45,7 @@ struct ConvKParams {
     int64_t res_cs, res_ts, res_ys;
     int dec_H, dec_W;
     int vec_epi;                 // 16-B epilogue through an LDS transpose (dense, aligned outputs only)
+    int t_fastest;               // tile order: t-planes of one (x, y) tile are neighbours in launch order (3-D taps)
 };
 
 // bf16x3 ("3xBF16") mode: every fp32 operand x is split as x = hi + lo (+ residual <= 2^-18 |x|) with hi, lo bf16, and
@@ -109,10 +110,20 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int tx = bx % p.tiles_x;
-    bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y;
-    const int t = bx / p.tiles_y;
+    // 3-D taps: t runs fastest, so the workgroups resident on one XCD at a time cover all t-planes of a few (x, y) tiles and
+    // the t-1 / t+1 planes every tile needs are L2 hits instead of a second and third HBM fetch (STEMSEG_T_FASTEST=0: x fastest)
+    int tx, ty, t;
+    if (C::KT > 1 && p.t_fastest) {
+        t = bx % p.T;
+        bx /= p.T;
+        tx = bx % p.tiles_x;
+        ty = bx / p.tiles_x;
+    } else {
+        tx = bx % p.tiles_x;
+        bx /= p.tiles_x;
+        ty = bx % p.tiles_y;
+        t = bx / p.tiles_y;
+    }
     const int x0 = C::FLAT ? 0 : tx * (C::COLS * 32), y0 = C::FLAT ? 0 : ty * C::ROWS;
     const int pitch = (int)p.in_ys;                           // FLAT: row pitch of the haloed plane
     const int F0 = pitch + tx * C::NT;                        // FLAT: first flat position of this tile (row 1, column 0)
@@ -817,6 +828,8 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.vec_epi = (!flat && p.W % 4 == 0 && al16(p.out, p.out_cs, p.out_ts, p.out_ys, p.T, p.H) &&
                  (!p.res || al16(p.res, p.res_cs, p.res_ts, p.res_ys, p.T, p.H))) ? 1 : 0;
     p.tiles_x = p.tiles_y = 0;
+    static const bool t_fast = [] { const char* e = getenv("STEMSEG_T_FASTEST"); return !(e && e[0] == '0'); }();
+    p.t_fastest = t_fast ? 1 : 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(in.ptr) % 16 == 0) && (in.c_stride % 4 == 0) &&
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
     p.vec4 = aligned ? 1 : 0;
