@@ -875,6 +875,50 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
+def test_config0_vs_reference_cpu_path(hip, golden):
+    """BASELINE configs[0] -- one synthetic 8 x 256 x 448 clip, random-init ResNet-50 -- through the whole HIP path (uint8 frames
+    -> pre-processing -> encoder -> decoders -> fg mask -> gather -> clustering -> chainer) against what the REFERENCE itself
+    computed on CPU for the same frames and weights (tests/golden/config0.npz): maps <= 1e-3, foreground mask and instance
+    labels compared point by point."""
+    from stemseg_amd import config
+    from stemseg_amd.inference.main import TrackGenerator
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from tests.test_oracle_vs_golden import config0_inputs
+    g = golden("config0")
+    sd, frames, thr, min_seed = config0_inputs(g)
+    config.load_preset("davis")
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 256, 448
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    config.cfg.CLUSTERING.MIN_SEEDINESS_PROB = min_seed
+    try:
+        model = InferenceModel()
+        msd = model._model.state_dict()
+        model._model.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])).reshape(msd[k].shape) for k in msd})
+        model = model.cuda()
+        tg = TrackGenerator(model, "davis", seediness_thresh=thr, frame_overlap=4)
+        embeddings, fg, _ = tg.do_inference([f for f in frames])
+        e = embeddings[0]
+        assert tuple(e.embeddings.shape) == tuple(g["shape"].tolist())
+        assert report("config0 emb vs reference", e.embeddings.cpu().numpy().reshape(-1)[::5], g["emb"]) <= 1e-3
+        assert report("config0 seediness vs reference", e.seediness.cpu().numpy().reshape(-1)[::5], g["seed"]) <= 1e-3
+        assert report("config0 bandwidth (rel) vs reference", e.bandwidths.cpu().numpy().reshape(-1)[::5] / g["bw"], np.ones_like(g["bw"])) <= 1e-3
+        ref_fg = np.unpackbits(g["fg_bits"])[:int(np.prod(g["fg_shape"]))].reshape(g["fg_shape"]).astype(bool)
+        got_fg = fg.cpu().numpy().astype(bool)
+        (track, counts, life), mask_idxes, _, _, meta = tg.do_clustering(embeddings, fg)
+        ref_lab = np.full(ref_fg.size, -2, np.int64)
+        ref_lab[np.flatnonzero(ref_fg.reshape(-1))] = g["labels"].astype(np.int64)
+        got_lab = np.full(ref_fg.size, -2, np.int64)
+        got_lab[np.flatnonzero(got_fg.reshape(-1))] = torch.cat([t.cpu() for t in track]).numpy()
+        both = (ref_fg & got_fg).reshape(-1)
+        agree = float((ref_lab[both] == got_lab[both]).mean())
+        print("[parity] config0 vs reference: fg %d vs %d (%d pixels differ), %d instances vs %d, labels identical on %.4f of the common fg"
+              % (got_fg.sum(), ref_fg.sum(), (got_fg != ref_fg).sum(), len(meta[0]["instance_labels"]), len(g["instance_labels"]), agree))
+        assert (got_fg != ref_fg).sum() <= 20 and agree >= 0.999
+        assert meta[0]["instance_labels"] == g["instance_labels"].tolist()
+    finally:
+        config.load_preset("defaults")
+
+
 def test_sequence_end_to_end_tracks_and_masks(hip):
     """A 14-frame sequence through the whole device path -- TrackGenerator (pre-processing, encoder, decoders, fg mask from the
     clip-averaged seediness, gather, clustering, Hungarian stitching) and MaskMaterializer -- against the ORACLE chain (CPU

@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "encoder", "model_davis", "cluster", "chainer", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "encoder", "model_davis", "cluster", "chainer", "misc"]
 
 
 def _save(name, **arrays):
@@ -260,6 +260,45 @@ def gen_model_davis():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_config0():
+    """BASELINE configs[0]: one synthetic 8 x 256 x 448 clip, random-init ResNet-50, through the REFERENCE's CPU path --
+    InferenceModel.forward (encoder, both decoders, bandwidth activation), fg mask = seediness > 0.25, OnlineChainer /
+    SequentialClustering.  Float maps are stored as every 5th value, labels and the fg mask whole."""
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    cfg.merge_from_file(os.path.join(ref_shim.REFERENCE_ROOT, "stemseg", "config", "davis_1.yaml"))
+    cfg.INPUT.update_param("MIN_DIM", 256)
+    cfg.INPUT.update_param("MAX_DIM", 448)
+    cfg.MODEL.BACKBONE.update_param("TYPE", "R-50-FPN")
+    from stemseg.modeling.inference_model import InferenceModel
+    from stemseg.inference.clusterers import SequentialClustering
+    from stemseg.inference.online_chainer import OnlineChainer
+    model = InferenceModel(None, cpu_workers=0, preload_images=False, semseg_output_type=None, resize_scale=1.0)
+    _load_synth_weights(model._model, 71)
+    with torch.no_grad():
+        model._model.seediness_head.conv_out.weight.mul_(30.0)       # spread the random-init seediness over (0, 1)
+    frames = synth.synth_frames(8, 256, 448, seed=71)
+    res = model([f for f in frames], [list(range(8))])
+    e = res["embeddings"][0]
+    thr = float(np.float32(e.seediness.median()))                    # half of the pixels foreground (the threshold is a CLI knob)
+    min_seed = float(np.float32(e.seediness.flatten().quantile(0.9)))
+    fg = (e.seediness[0] > thr).byte()
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, min_seed, 2, [0.3, 0.3], "cpu"), 1.0)
+    d = dict(frames=list(e.subseq_frames), embeddings=e.embeddings.clone(), bandwidths=e.bandwidths.clone(), seediness=e.seediness.clone())
+    (track, counts, life), _, _, _, meta = ch.process(fg, [d])
+    out = {"emb": e.embeddings.numpy().reshape(-1)[::5].copy(), "bw": e.bandwidths.numpy().reshape(-1)[::5].copy(),
+           "seed": e.seediness.numpy().reshape(-1)[::5].copy(), "shape": np.array(e.embeddings.shape, np.int64),
+           "fg_bits": np.packbits(fg.numpy().astype(bool).reshape(-1)), "fg_shape": np.array(fg.shape, np.int64),
+           "labels": np.concatenate([l.numpy() for l in track]).astype(np.int16),
+           "instance_labels": np.array(meta[0]["instance_labels"], np.int64),
+           "pt_counts": np.array(sorted(counts.items()), np.int64).reshape(-1, 2),
+           "thresholds": np.array([thr, min_seed], np.float64)}
+    print("config0: %d fg points, %d instances" % (int(fg.sum()), len(meta[0]["instance_labels"])))
+    _save("config0", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def _cluster_cases():
     """(name, emb[N,E], bw[N,Ev], seed[N,1], kwargs)"""
     cases = []
@@ -480,6 +519,8 @@ def main():
         gen_semseg()
     elif g == "masks":
         gen_masks()
+    elif g == "config0":
+        gen_config0()
     elif g == "encoder":
         gen_encoder()
     elif g == "model_davis":
