@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "encoder", "model_davis", "cluster", "chainer", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "model_ytvis", "encoder", "model_davis", "cluster", "chainer", "misc"]
 
 
 def _save(name, **arrays):
@@ -299,6 +299,53 @@ def gen_config0():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_model_ytvis():
+    """BASELINE configs[2] flow at a reduced size through the REFERENCE: youtube_vis.yaml (7-channel embedding head with its own
+    seediness, 40+1-channel semseg head with inter [256]*4), --resize_embeddings (resize_scale 4): semseg logits resized x4 and
+    averaged over the clips, fg mask = sigmoid(fg logit) > 0.5, class argmax; OnlineChainer(embedding_resize_factor=4) resizes
+    embeddings / bandwidths / seediness x4 and clusters at full resolution, two overlapping clips stitched."""
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    cfg.merge_from_file(os.path.join(ref_shim.REFERENCE_ROOT, "stemseg", "config", "youtube_vis.yaml"))
+    cfg.INPUT.update_param("MIN_DIM", 96)
+    cfg.INPUT.update_param("MAX_DIM", 128)
+    cfg.MODEL.BACKBONE.update_param("TYPE", "R-50-FPN")
+    from stemseg.modeling.inference_model import InferenceModel
+    from stemseg.inference.clusterers import SequentialClustering
+    from stemseg.inference.online_chainer import OnlineChainer
+    from stemseg.inference.main import get_subsequence_frames
+    model = InferenceModel(None, cpu_workers=0, preload_images=False, semseg_output_type="argmax", resize_scale=4.0,
+                           semseg_generation_on_gpu=False)
+    _load_synth_weights(model._model, 81)
+    with torch.no_grad():
+        model._model.embedding_head.conv_seediness.weight.mul_(6.0)      # spread, but do not saturate, the sigmoid (ties!)
+    frames = synth.synth_frames(12, 96, 128, seed=81)
+    subseqs, _ = get_subsequence_frames(12, 8, "ytvis", 4)
+    res = model([f for f in frames], subseqs)
+    fg_probs, mc = res["fg_masks"], res["multiclass_masks"]
+    fg = (fg_probs > 0.5).byte()
+    s0 = res["embeddings"][0].seediness
+    min_seed = float(np.float32(s0.flatten().quantile(0.9)))
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, min_seed, 2, [0.3, 0.3], "cpu"), 4.0)
+    dicts = [dict(frames=list(e.subseq_frames), embeddings=e.embeddings.clone(), bandwidths=e.bandwidths.clone(), seediness=e.seediness.clone())
+             for e in res["embeddings"]]
+    (track, counts, life), _, _, _, meta = ch.process(fg, dicts)
+    out = {"subseqs": np.array(subseqs, np.int64), "min_seed": np.float64(min_seed),
+           "fg_probs": fg_probs.numpy().reshape(-1)[::3].copy(), "fg_shape": np.array(fg.shape, np.int64),
+           "fg_bits": np.packbits(fg.numpy().astype(bool).reshape(-1)), "multiclass": mc.numpy().astype(np.int8),
+           "labels": np.concatenate([l.numpy() for l in track]).astype(np.int16),
+           "pt_counts": np.array(sorted(counts.items()), np.int64).reshape(-1, 2),
+           "lifetimes": np.array(sorted(life.items()), np.int64).reshape(-1, 2)}
+    for i, e in enumerate(res["embeddings"]):
+        out["c%d_emb" % i] = e.embeddings.numpy().reshape(-1)[::3].copy()
+        out["c%d_seed" % i] = e.seediness.numpy().reshape(-1)[::3].copy()
+        out["c%d_instance_labels" % i] = np.array(meta[i]["instance_labels"], np.int64)
+    print("model_ytvis: fg %d of %d, tracks %s" % (int(fg.sum()), fg.numel(), sorted(counts.items())[:8]))
+    _save("model_ytvis", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def _cluster_cases():
     """(name, emb[N,E], bw[N,Ev], seed[N,1], kwargs)"""
     cases = []
@@ -521,6 +568,8 @@ def main():
         gen_masks()
     elif g == "config0":
         gen_config0()
+    elif g == "model_ytvis":
+        gen_model_ytvis()
     elif g == "encoder":
         gen_encoder()
     elif g == "model_davis":
