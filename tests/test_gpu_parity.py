@@ -986,6 +986,52 @@ def test_ytvis_flow_vs_reference(hip, golden):
         config.load_preset("defaults")
 
 
+def test_kitti_flow_vs_reference(hip, golden):
+    """KITTI-MOTS preset ('xyt' embeddings: the time coordinate is an embedding dimension, no free dims; in-head seediness; 3+1
+    channel semseg head through the fused heads kernel) at a reduced wide-aspect size, 14 frames as three overlapping clips, vs
+    the REFERENCE's own CPU result (tests/golden/model_kitti.npz): semseg fg / class probabilities, embeddings, stitched tracks."""
+    from stemseg_amd import config
+    from stemseg_amd.inference.main import TrackGenerator
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    g = golden("model_kitti")
+    config.load_preset("kittimots")
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 96, 320
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    config.cfg.CLUSTERING.MIN_SEEDINESS_PROB = float(g["min_seed"])
+    try:
+        model = InferenceModel(semseg_output_type="probs")
+        msd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 91))).reshape(v.shape) for k, v in msd.items()}
+        new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 6.0
+        model._model.load_state_dict(new)
+        model = model.cuda()
+        frames = synth.synth_frames(14, 60, 190, seed=91)
+        tg = TrackGenerator(model, "kittimots", frame_overlap=4)
+        out = model([f for f in frames], g["subseqs"].tolist())
+        assert report("kitti semseg fg prob vs reference", out["fg_masks"].cpu().numpy().reshape(-1)[::3], g["fg_probs"]) <= 1e-3
+        assert report("kitti class probs vs reference", out["multiclass_masks"].cpu().numpy().reshape(-1)[::5], g["class_probs"]) <= 1e-3
+        for i, e in enumerate(out["embeddings"]):
+            assert report("kitti clip %d emb vs reference" % i, e.embeddings.cpu().numpy().reshape(-1)[::3], g["c%d_emb" % i]) <= 1e-3
+        embeddings, fg, _ = tg.do_inference([f for f in frames])
+        ref_fg = np.unpackbits(g["fg_bits"])[:int(np.prod(g["fg_shape"]))].reshape(g["fg_shape"]).astype(bool)
+        got_fg = fg.cpu().numpy().astype(bool)
+        (track, counts, life), _, _, _, meta = tg.do_clustering(embeddings, fg)
+        ref_lab = np.full(ref_fg.size, -2, np.int64)
+        ref_lab[np.flatnonzero(ref_fg.reshape(-1))] = g["labels"].astype(np.int64)
+        got_lab = np.full(ref_fg.size, -2, np.int64)
+        got_lab[np.flatnonzero(got_fg.reshape(-1))] = torch.cat([t.cpu() for t in track]).numpy()
+        both = (ref_fg & got_fg).reshape(-1)
+        agree = float((ref_lab[both] == got_lab[both]).mean())
+        print("[parity] kitti flow vs reference: fg %d vs %d (%d pixels differ), labels identical on %.4f of the common fg, tracks %s"
+              % (got_fg.sum(), ref_fg.sum(), (got_fg != ref_fg).sum(), agree, sorted(counts.items())[:8]))
+        assert (got_fg != ref_fg).mean() < 1e-3 and agree >= 0.999
+        assert sorted(counts.items()) == [tuple(r) for r in g["pt_counts"].tolist()] or (got_fg != ref_fg).any()
+        for i in range(3):
+            assert meta[i]["instance_labels"] == g["c%d_instance_labels" % i].tolist()
+    finally:
+        config.load_preset("defaults")
+
+
 def test_sequence_end_to_end_tracks_and_masks(hip):
     """A 14-frame sequence through the whole device path -- TrackGenerator (pre-processing, encoder, decoders, fg mask from the
     clip-averaged seediness, gather, clustering, Hungarian stitching) and MaskMaterializer -- against the ORACLE chain (CPU

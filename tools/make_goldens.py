@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "model_ytvis", "encoder", "model_davis", "cluster", "chainer", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "misc"]
 
 
 def _save(name, **arrays):
@@ -346,6 +346,50 @@ def gen_model_ytvis():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_model_kitti():
+    """KITTI-MOTS preset (kitti_mots_2.yaml: 'xyt' embeddings -- the time coordinate is part of the embedding, no free dims --
+    in-head seediness, 3+1-channel semseg head, MIN_SEEDINESS_PROB from the config family) through the REFERENCE at a reduced,
+    wide-aspect size: 14 frames, clips of 8 with overlap 4, fg from the semseg head, tracks stitched by the reference chainer."""
+    import ref_shim
+    cfg = ref_shim.install()
+    import torch
+    cfg.merge_from_file(os.path.join(ref_shim.REFERENCE_ROOT, "stemseg", "config", "kitti_mots_2.yaml"))
+    cfg.INPUT.update_param("MIN_DIM", 96)
+    cfg.INPUT.update_param("MAX_DIM", 320)
+    cfg.MODEL.BACKBONE.update_param("TYPE", "R-50-FPN")
+    from stemseg.modeling.inference_model import InferenceModel
+    from stemseg.inference.clusterers import SequentialClustering
+    from stemseg.inference.online_chainer import OnlineChainer
+    from stemseg.inference.main import get_subsequence_frames
+    model = InferenceModel(None, cpu_workers=0, preload_images=False, semseg_output_type="probs", resize_scale=1.0,
+                           semseg_generation_on_gpu=False)
+    _load_synth_weights(model._model, 91)
+    with torch.no_grad():
+        model._model.embedding_head.conv_seediness.weight.mul_(6.0)
+    frames = synth.synth_frames(14, 60, 190, seed=91)                 # KITTI-like 1 : 3.2 aspect -> resized 96 x 304 -> padded 96 x 320
+    subseqs, _ = get_subsequence_frames(14, 8, "kittimots", 4)
+    res = model([f for f in frames], subseqs)
+    fg_probs, mc = res["fg_masks"], res["multiclass_masks"]
+    fg = (fg_probs > 0.5).byte()
+    min_seed = float(np.float32(res["embeddings"][0].seediness.flatten().quantile(0.3)))
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, min_seed, 0, [], "cpu"), 1.0)
+    dicts = [dict(frames=list(e.subseq_frames), embeddings=e.embeddings.clone(), bandwidths=e.bandwidths.clone(), seediness=e.seediness.clone())
+             for e in res["embeddings"]]
+    (track, counts, life), _, _, _, meta = ch.process(fg, dicts)
+    out = {"subseqs": np.array(subseqs, np.int64), "min_seed": np.float64(min_seed),
+           "fg_probs": fg_probs.numpy().reshape(-1)[::3].copy(), "fg_shape": np.array(fg.shape, np.int64),
+           "fg_bits": np.packbits(fg.numpy().astype(bool).reshape(-1)), "class_probs": mc.numpy().reshape(-1)[::5].copy(),
+           "labels": np.concatenate([l.numpy() for l in track]).astype(np.int16),
+           "pt_counts": np.array(sorted(counts.items()), np.int64).reshape(-1, 2),
+           "lifetimes": np.array(sorted(life.items()), np.int64).reshape(-1, 2)}
+    for i, e in enumerate(res["embeddings"]):
+        out["c%d_emb" % i] = e.embeddings.numpy().reshape(-1)[::3].copy()
+        out["c%d_instance_labels" % i] = np.array(meta[i]["instance_labels"], np.int64)
+    print("model_kitti: clips %s, fg %d of %d, tracks %s" % (subseqs, int(fg.sum()), fg.numel(), sorted(counts.items())[:8]))
+    _save("model_kitti", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def _cluster_cases():
     """(name, emb[N,E], bw[N,Ev], seed[N,1], kwargs)"""
     cases = []
@@ -570,6 +614,8 @@ def main():
         gen_config0()
     elif g == "model_ytvis":
         gen_model_ytvis()
+    elif g == "model_kitti":
+        gen_model_kitti()
     elif g == "encoder":
         gen_encoder()
     elif g == "model_davis":
