@@ -115,6 +115,56 @@ def test_config0_reference_cpu_path(golden):
     assert out["meta"]["instance_labels"] == g["instance_labels"].tolist()
 
 
+@pytest.mark.parametrize("flow", ["model_ytvis", "model_kitti"])
+def test_preset_flows_oracle_composition(golden, flow):
+    """The oracle pieces composed the way the reference's InferenceModel / TrackGenerator compose them, vs the reference's own
+    result: encoder -> embedding decoder (in-head seediness) + semseg decoder per clip -> logits (x4 for --resize_embeddings)
+    averaged over the clips -> fg = sigmoid > 0.5 -> chainer (x4 resize of the head outputs, clustering, stitching)."""
+    import torch.nn.functional as F
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    from tests.oracle_ops import OracleChainerOps
+    g = golden(flow)
+    yt = flow == "model_ytvis"
+    mode, E, n_free, stds = ("xyff", 4, 2, [0.3, 0.3]) if yt else ("xyt", 3, 0, [])
+    n_cls, inter_sem = (42, (256, 256, 256, 256)) if yt else (4, (256, 256, 128, 128))
+    wseed, size, min_max, n_frames, scale = (81, (96, 128), (96, 128), 12, 4.0) if yt else (91, (60, 190), (96, 320), 14, 1.0)
+    names = oenc.backbone_param_shapes("R-50-FPN") + \
+        odec.decoder_param_shapes("embedding_head.", mode=mode, embedding_size=E, seediness_output=True) + \
+        odec.decoder_param_shapes("semseg_head.", kind="semseg", n_classes=n_cls, inter=inter_sem)
+    sd = synth.synth_state_dict(names, wseed)
+    sd["embedding_head.conv_seediness.weight"] = sd["embedding_head.conv_seediness.weight"] * np.float32(6.0)
+    x, _ = opipe.preprocess_frames(synth.synth_frames(n_frames, size[0], size[1], seed=wseed), *min_max)
+    feats = oenc.resnet_fpn(x, sd, "R-50-FPN")
+    acc, cnt, dicts = {}, {}, []
+    Ev = E - n_free
+    for i, sub in enumerate(g["subseqs"].tolist()):
+        stacks = [feats[s][sub].permute(1, 0, 2, 3).contiguous() for s in (32, 16, 8, 4)]
+        out = odec.embedding_decoder(stacks, sd, mode, True)
+        emb, bw, seed = out[:odec.nb_embedding_dims(mode)], opipe.bandwidth_activation(out[odec.nb_embedding_dims(mode):odec.nb_embedding_dims(mode) + Ev]), out[-1:]
+        assert np.abs(emb.numpy().reshape(-1)[::3] - g["c%d_emb" % i]).max() <= TOL
+        logits = odec.semseg_decoder(stacks, sd)
+        if scale != 1.0:
+            logits = F.interpolate(logits[None], scale_factor=(1.0, scale, scale), mode="trilinear", align_corners=False)[0]
+        for j, t in enumerate(sub):
+            acc[t] = acc[t] + logits[:, j] if t in acc else 0. + logits[:, j]
+            cnt[t] = cnt.get(t, 0) + 1
+        dicts.append(dict(frames=list(sub), embeddings=emb, bandwidths=bw, seediness=seed))
+    mean = torch.stack([acc[t] / float(cnt[t]) for t in sorted(acc)], 0)
+    fg_prob, mc = odec.semseg_masks(mean, "argmax" if yt else "probs")
+    assert np.abs(fg_prob.numpy().reshape(-1)[::3] - g["fg_probs"]).max() <= TOL
+    fg = (fg_prob > 0.5).to(torch.uint8)
+    ref_fg = np.unpackbits(g["fg_bits"])[:int(np.prod(g["fg_shape"]))].reshape(g["fg_shape"]).astype(bool)
+    assert np.array_equal(fg.numpy().astype(bool), ref_fg)
+    if yt:
+        assert (mc.numpy() == g["multiclass"]).mean() > 0.999
+    chain = OnlineChainer(SequentialClustering(0.5, 0.3, float(g["min_seed"]), n_free, stds, "cpu"), scale, ops=OracleChainerOps())
+    (track, counts, life), _, _, _, meta = chain.process(fg, dicts)
+    assert np.array_equal(torch.cat(track).numpy(), g["labels"].astype(np.int64))
+    assert sorted(counts.items()) == [tuple(r) for r in g["pt_counts"].tolist()]
+    assert sorted(life.items()) == [tuple(r) for r in g["lifetimes"].tolist()]
+
+
 def test_mask_materialisation(golden):
     """oracle/masks.py vs the PNGs written by the reference's DavisOutputGenerator (tools/make_goldens.py::gen_masks)."""
     from oracle import masks as omask
