@@ -18,6 +18,16 @@
 // fp32 MFMA issues one instruction per 64 cycles per SIMD, so 6 LDS reads per 8 MFMAs (MI=4, NI=2) leave
 // the LDS pipe < 15 % busy; two workgroups per CU (<= 80 KB LDS, <= 256 VGPRs each) overlap one group's
 // staging with the other's MFMA stream.
+//
+// The same template also serves the encoder's 2-D convolutions (KT = 1; the frames of a clip are the T axis) and every
+// 1x1 convolution (one flat row of voxels).  Variants, all selected per launch by launch_conv3d():
+//   PIPE  next chunk prefetched into registers under the current chunk's MFMA stream
+//   DB    2-channel chunks + two LDS buffers, one barrier per chunk            (big 3x3x3 tile)
+//   FLAT  N tile = a run of the zero-haloed plane instead of rows x 32 columns  (maps whose width wastes a 32-column tile)
+//   BF    bf16x3 split on v_mfma_f32_32x32x16_bf16, fp32 accumulate             (opt-in precision mode)
+// plus split-K with a deterministic slab reduce, an XCD-aware (and, for 3-D taps, t-fastest) tile order, and a launch
+// planner that cuts big launches into whole rows + split-K rows so that their workgroups fill whole rounds of the chip.
+// A/B switches (environment, read once): STEMSEG_K3_DB, STEMSEG_FLAT, STEMSEG_PLANNER, STEMSEG_T_FASTEST (= 0 to disable).
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
