@@ -903,7 +903,9 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
         // expansion convs with a short K (<= 8 channel chunks) are bound by their output / residual traffic: the 128-voxel
         // tile keeps twice as many workgroups in flight (measured, tools/conv_sweep.py: 64->256 +res 233 -> 167 us)
-        if (!bf && p.Cin <= 256 && p.Cout >= 4 * p.Cin) cfg = 2;
+        // -- up to ~2000 workgroups of the big tile; beyond that (several clips per encoder pass) the big tile wins again
+        // (T = 32 sweep: 64->256 +res 532 vs 570 us, 128->512 +res 372 vs 438 us)
+        if (!bf && p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
     }
     if (bf) {
         if (cfg == 1) return launch_cfg<X1Big>(p, s, scratch, scratch_floats);

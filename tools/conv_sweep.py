@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from stemseg_amd import hip  # noqa: E402
 
 hip.require_gpu()
-T = 8
+T = int(os.environ.get("SWEEP_T", "8"))       # frames per encoder pass (bench default: 4 clips x 8)
 REPS = int(os.environ.get("REPS", "20"))
 
 
