@@ -56,6 +56,7 @@ struct ConvKParams {
     int dec_H, dec_W;
     int vec_epi;                 // 16-B epilogue through an LDS transpose (dense, aligned outputs only)
     int t_fastest;               // tile order: t-planes of one (x, y) tile are neighbours in launch order (3-D taps)
+    int n_co;                    // output-channel tiles (Cout / MT), the fastest-running part of the workgroup index
 };
 
 // bf16x3 ("3xBF16") mode: every fp32 operand x is split as x = hi + lo (+ residual <= 2^-18 |x|) with hi, lo bf16, and
@@ -120,6 +121,10 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
         bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
+    // the output-channel tile runs fastest: the Cout / MT workgroups that read the SAME input tile are neighbours in launch
+    // order on one XCD, so the tile comes from HBM once and from that XCD's L2 for the others (1x1 expansions have up to 16)
+    const int co_tile = bx % p.n_co;
+    bx /= p.n_co;
     // 3-D taps: t runs fastest, so the workgroups resident on one XCD at a time cover all t-planes of a few (x, y) tiles and
     // the t-1 / t+1 planes every tile needs are L2 hits instead of a second and third HBM fetch (STEMSEG_T_FASTEST=0: x fastest)
     int tx, ty, t;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
     const int x0 = C::FLAT ? 0 : tx * (C::COLS * 32), y0 = C::FLAT ? 0 : ty * C::ROWS;
     const int pitch = (int)p.in_ys;                           // FLAT: row pitch of the haloed plane
     const int F0 = pitch + tx * C::NT;                        // FLAT: first flat position of this tile (row 1, column 0)
-    const int co0 = blockIdx.y * C::MT;
+    const int co0 = co_tile * C::MT;
 
     f32x16 acc[C::MI][C::NI];
 #pragma unroll
@@ -682,7 +687,8 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         p.out_split_stride = slab;
         p.vec_epi = !C::FLAT && (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0);
     } else p.out_split_stride = 0;
-    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T), (unsigned)ceil_div(p.Cout, C::MT), (unsigned)ksplit);
+    p.n_co = (int)ceil_div(p.Cout, C::MT);
+    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), 1, (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
     constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
     const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : tile_rows);   // 8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
