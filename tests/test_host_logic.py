@@ -267,3 +267,21 @@ def test_fg_mask_and_clip_assembly_semantics(golden):
     sub = g["seq5__subseqs"].tolist()[0]
     assert sub == [0, 0, 0, 0, 1, 2, 3, 4] and g["seq5_c0_frames"].tolist() == [0, 1, 2, 3, 4]
     assert g["seq5_c0_emb"].shape[1] == 5
+
+
+def test_instances_to_keep_and_mask_lut_vs_golden(golden):
+    """Track selection for the writers (davis.py:57-66): stable sort by lifetime, outliers dropped, max_tracks cut -- vs the
+    reference's own selection; and the label -> plane-index table the scatter kernel consumes."""
+    from stemseg_amd.inference.output_utils import MaskMaterializer, instances_to_keep
+    g = golden("masks")
+    for name in g["__names"].tolist():
+        max_tracks = int(g[name + "__dims"][7])
+        life = dict(zip(g[name + "__lifetime_keys"].tolist(), g[name + "__lifetime_vals"].tolist()))
+        keep = instances_to_keep(life, -1, max_tracks)
+        assert keep == g[name + "__keep"].tolist()
+        lut = MaskMaterializer(-1)._lut(keep, "cpu").tolist()
+        assert lut[0] == 0                                            # slot of the outlier label (-1 + 1)
+        for n, k in enumerate(keep):
+            assert lut[k + 1] == n + 1
+        assert sum(1 for v in lut if v) == len(keep)
+    assert instances_to_keep({3: 5, 1: 5, -1: 9, 2: 7}, -1, 2) == [2, 3]      # ties keep the dict's order; outlier dropped
