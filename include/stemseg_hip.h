@@ -290,10 +290,18 @@ int stemseg_hip_cluster(const float* emb, const float* bw, const float* seed, in
 
 /* online_chainer.py:291-343: label-pair statistics on the overlap frames.  lut_a / lut_b map (label + 1)
  * to a row / column index or -1 (ignore; the outlier label -1 maps through slot 0).  Outputs (int64,
- * zeroed by the call): inter [Ka][Kb], cnt_a [Ka], cnt_b [Kb]. */
+ * zeroed by the call): inter [Ka][Kb], cnt_a [Ka], cnt_b [Kb].  No limit on Ka, Kb or on the label values
+ * (the LUTs are indexed by id): small tables are counted in LDS, large ones with global atomics. */
 int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t* labels_b, int64_t n,
                                const int32_t* lut_a, int32_t lut_a_len, const int32_t* lut_b, int32_t lut_b_len,
                                int32_t Ka, int32_t Kb, int64_t* inter, int64_t* cnt_a, int64_t* cnt_b, void* stream);
+
+/* online_chainer.py:304-308 (`unique()` of the overlap labels) and :43-49 (`highest id + 1`) in one pass:
+ * present[id] = 1 for every label id in [0, cap) that occurs, *max_plus_1 = max(label) + 1 over labels >= 0
+ * (0 when there is none; ids >= cap still count towards the maximum).  accumulate = 0 zeroes both outputs
+ * first; accumulate = 1 adds to what earlier calls left (several frames' label arrays -> one id set). */
+int stemseg_hip_label_presence(const int64_t* labels, int64_t n, uint8_t* present, int32_t cap,
+                               int64_t* max_plus_1, int32_t accumulate, void* stream);
 
 /* in-place relabel: labels[i] = map[labels[i] + 1] for labels[i] + 1 in [0, map_len) (online_chainer.py:219-229) */
 int stemseg_hip_relabel(int64_t* labels, int64_t n, const int64_t* map, int32_t map_len, void* stream);

@@ -39,7 +39,7 @@ def _digest():
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "libstemseg_hip.stamp")
+    stamp = os.path.join(OBJDIR, "libstemseg_hip.stamp")      # csrc/build/ is git-ignored
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         if verbose:

@@ -389,6 +389,37 @@ __global__ __launch_bounds__(256) void overlap_counts_kernel(const long long* la
     }
 }
 
+// Large label sets (Ka*Kb+Ka+Kb beyond the LDS budget): same statistics with one wave-uniform check and global atomics.
+__global__ __launch_bounds__(256) void overlap_counts_global_kernel(const long long* la, const long long* lb, long long n,
+                                                                    const int* lut_a, int len_a, const int* lut_b, int len_b,
+                                                                    int Kb, unsigned long long* inter,
+                                                                    unsigned long long* cnt_a, unsigned long long* cnt_b) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long a = la[i] + 1, b = lb[i] + 1;
+        const int ia = (a >= 0 && a < len_a) ? lut_a[a] : -1;
+        const int ib = (b >= 0 && b < len_b) ? lut_b[b] : -1;
+        if (ia >= 0) atomicAdd(&cnt_a[ia], 1ull);
+        if (ib >= 0) atomicAdd(&cnt_b[ib], 1ull);
+        if (ia >= 0 && ib >= 0) atomicAdd(&inter[(long long)ia * Kb + ib], 1ull);
+    }
+}
+
+// Which ids occur (online_chainer.py:304-308's torch.unique, minus the sort: the flags are indexed by id) and the
+// highest id + 1 (TrackContainer.add_labels :43-49).  present[id] = 1 for 0 <= id < cap; ids >= cap only raise max.
+__global__ __launch_bounds__(256) void label_presence_kernel(const long long* labels, long long n, unsigned char* present,
+                                                             int cap, unsigned long long* max_plus_1) {
+    unsigned long long m = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = labels[i];
+        if (l >= 0) {
+            if (l < cap && !present[l]) present[l] = 1;     // benign race: every writer stores 1
+            m = max(m, (unsigned long long)l + 1ull);
+        }
+    }
+    for (int o = 32; o; o >>= 1) m = max(m, (unsigned long long)__shfl_xor((long long)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_plus_1, m);
+}
+
 __global__ void relabel_kernel(long long* labels, long long n, const long long* map, int map_len) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long k = labels[i] + 1;
@@ -491,18 +522,43 @@ extern "C" int stemseg_hip_cluster(const float* emb, const float* bw, const floa
 extern "C" int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t* labels_b, int64_t n, const int32_t* lut_a,
                                           int32_t lut_a_len, const int32_t* lut_b, int32_t lut_b_len, int32_t Ka, int32_t Kb,
                                           int64_t* inter, int64_t* cnt_a, int64_t* cnt_b, void* stream) {
-    SS_CHECK_ARG(Ka >= 0 && Kb >= 0 && Ka <= 256 && Kb <= 256 && (int64_t)Ka * Kb + Ka + Kb <= 12288, "overlap_counts: too many labels");
+    SS_CHECK_ARG(Ka >= 0 && Kb >= 0 && n >= 0 && lut_a_len >= 0 && lut_b_len >= 0, "overlap_counts: negative size");
+    SS_CHECK_ARG((int64_t)Ka * Kb < (1ll << 31), "overlap_counts: Ka * Kb = %lld does not fit the index type", (long long)Ka * Kb);
     hipStream_t s = as_stream(stream);
     if (Ka * Kb) SS_HIP(hipMemsetAsync(inter, 0, sizeof(int64_t) * Ka * Kb, s));
     if (Ka) SS_HIP(hipMemsetAsync(cnt_a, 0, sizeof(int64_t) * Ka, s));
     if (Kb) SS_HIP(hipMemsetAsync(cnt_b, 0, sizeof(int64_t) * Kb, s));
     if (n == 0 || (Ka == 0 && Kb == 0)) return STEMSEG_OK;
-    SS_CHECK_ARG(labels_a && labels_b && lut_a && lut_b, "overlap_counts: null pointer");
-    const size_t sh = sizeof(unsigned int) * ((size_t)Ka * Kb + Ka + Kb);
-    hipLaunchKernelGGL(overlap_counts_kernel, dim3(grid_for(n, 256 * 8, 512)), dim3(256), sh, s,
-                       reinterpret_cast<const long long*>(labels_a), reinterpret_cast<const long long*>(labels_b), (long long)n,
-                       lut_a, lut_a_len, lut_b, lut_b_len, Ka, Kb, reinterpret_cast<unsigned long long*>(inter),
-                       reinterpret_cast<unsigned long long*>(cnt_a), reinterpret_cast<unsigned long long*>(cnt_b));
+    SS_CHECK_ARG(labels_a && labels_b && lut_a && lut_b && inter && cnt_a && cnt_b, "overlap_counts: null pointer");
+    const long long nh = (long long)Ka * Kb + Ka + Kb;
+    if (nh <= 12288) {              // the usual case (<= max_instances ids per side): per-workgroup LDS histogram
+        hipLaunchKernelGGL(overlap_counts_kernel, dim3(grid_for(n, 256 * 8, 512)), dim3(256), sizeof(unsigned int) * nh, s,
+                           reinterpret_cast<const long long*>(labels_a), reinterpret_cast<const long long*>(labels_b), (long long)n,
+                           lut_a, lut_a_len, lut_b, lut_b_len, Ka, Kb, reinterpret_cast<unsigned long long*>(inter),
+                           reinterpret_cast<unsigned long long*>(cnt_a), reinterpret_cast<unsigned long long*>(cnt_b));
+    } else {                        // any number of labels: global atomics (contention is spread over the large table)
+        hipLaunchKernelGGL(overlap_counts_global_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s,
+                           reinterpret_cast<const long long*>(labels_a), reinterpret_cast<const long long*>(labels_b), (long long)n,
+                           lut_a, lut_a_len, lut_b, lut_b_len, Kb, reinterpret_cast<unsigned long long*>(inter),
+                           reinterpret_cast<unsigned long long*>(cnt_a), reinterpret_cast<unsigned long long*>(cnt_b));
+    }
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_label_presence(const int64_t* labels, int64_t n, uint8_t* present, int32_t cap, int64_t* max_plus_1,
+                                          int32_t accumulate, void* stream) {
+    SS_CHECK_ARG(n >= 0 && cap >= 0 && max_plus_1 && (present || cap == 0), "label_presence: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (!accumulate) {
+        if (cap) SS_HIP(hipMemsetAsync(present, 0, (size_t)cap, s));
+        SS_HIP(hipMemsetAsync(max_plus_1, 0, sizeof(int64_t), s));
+    }
+    if (n == 0) return STEMSEG_OK;
+    SS_CHECK_ARG(labels, "label_presence: null labels");
+    hipLaunchKernelGGL(label_presence_kernel, dim3(grid_for(n, 256 * 4, 1024)), dim3(256), 0, s,
+                       reinterpret_cast<const long long*>(labels), (long long)n, present, cap,
+                       reinterpret_cast<unsigned long long*>(max_plus_1));
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }

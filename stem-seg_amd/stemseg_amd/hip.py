@@ -102,6 +102,7 @@ SIGNATURES = {
     "stemseg_hip_cluster_workspace_bytes": (C.c_size_t, [_I64]),
     "stemseg_hip_cluster": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, C.POINTER(ClusterParams), _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "stemseg_hip_overlap_counts": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "stemseg_hip_label_presence": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _P]),
     "stemseg_hip_relabel": (C.c_int, [_P, _I64, _P, _I32, _P]),
     "stemseg_hip_semseg_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I64, C.POINTER(C.c_int32), _I32, _P]),
     "stemseg_hip_semseg_masks": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _P, _P, _P]),
@@ -382,6 +383,18 @@ def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):
                                            ptr(lut_a, torch.int32), lut_a.numel(), ptr(lut_b, torch.int32), lut_b.numel(),
                                            Ka, Kb, ptr(inter), ptr(ca), ptr(cb), stream()))
     return inter[:Ka * Kb].view(Ka, Kb), ca[:Ka], cb[:Kb]
+
+
+def label_presence(labels_list, cap):
+    """-> (present uint8 [cap] on the device, max_plus_1 int64 [1] on the device) over all tensors of ``labels_list``
+    (int64, same device); no synchronisation."""
+    dev = labels_list[0].device
+    present = torch.empty(max(int(cap), 1), dtype=torch.uint8, device=dev)
+    mx = torch.empty(1, dtype=torch.int64, device=dev)
+    for k, l in enumerate(labels_list):
+        check(lib().stemseg_hip_label_presence(ptr(l, torch.int64) if l.numel() else None, l.numel(), ptr(present), int(cap),
+                                               ptr(mx), int(k > 0), stream()))
+    return present[:int(cap)], mx
 
 
 def relabel(labels, mapping):

@@ -34,14 +34,14 @@ def get_subsequence_frames(seq_len, subseq_len, dataset_name, frame_overlap=-1):
 
 
 @torch.no_grad()
-def fg_masks_from_seediness(embedding_maps, threshold):
+def fg_masks_from_seediness(embedding_maps, threshold, device=None):
     """Mean seediness over the clips containing each frame, > threshold -> uint8 [n_frames, h, w] on the device
     (inference/main.py:93-103).  Accumulation order = clip order, exactly like the reference's ``+=``."""
     hip.require_gpu()
     acc, cnt = {}, {}
     for entry in embedding_maps:
         frames, seed = entry[0], entry[3]
-        seed = seed.cuda().contiguous()
+        seed = (seed if seed.is_cuda else seed.to(device if device is not None else "cuda")).contiguous()
         for i, t in enumerate(frames):
             plane = seed[0, i].contiguous()
             if t not in acc:
@@ -64,7 +64,11 @@ class TrackGenerator(object):
         self.seediness_fg_threshold = kwargs.get("seediness_thresh", 0.25)
         self.frame_overlap = kwargs.get("frame_overlap", -1)
         self.clustering_device = kwargs.get("clustering_device", "cuda:0")
-        self.chainer = OnlineChainer(self.create_clusterer(), embedding_resize_factor=resize_scale, ops=kwargs.get("ops"))
+        ops = kwargs.get("ops")
+        if ops is None:
+            from .online_chainer import HipChainerOps
+            ops = HipChainerOps(self.clustering_device)
+        self.chainer = OnlineChainer(self.create_clusterer(), embedding_resize_factor=resize_scale, ops=ops)
 
     def create_clusterer(self):
         c = cfg.CLUSTERING
@@ -73,7 +77,7 @@ class TrackGenerator(object):
                                     free_dim_stds=cfg.TRAINING.LOSSES.EMBEDDING.FREE_DIM_STDS, device=self.clustering_device)
 
     def get_fg_masks_from_seediness(self, inference_output):
-        return fg_masks_from_seediness(inference_output['embeddings'], self.seediness_fg_threshold)
+        return fg_masks_from_seediness(inference_output['embeddings'], self.seediness_fg_threshold, self.clustering_device)
 
     def do_inference(self, frames):
         n = len(frames)
@@ -81,7 +85,8 @@ class TrackGenerator(object):
         out = self.model(frames, subseq_idxes)
         fg_masks = out["fg_masks"]
         if torch.is_tensor(fg_masks):            # semseg head present: its foreground probability > 0.5 (main.py:142-144)
-            fg_masks = torch.stack([hip.fg_mask(p.contiguous(), 1.0, 0.5) for p in fg_masks.cuda()], 0)
+            fg_masks = fg_masks if fg_masks.is_cuda else fg_masks.to(self.clustering_device)
+            fg_masks = torch.stack([hip.fg_mask(p.contiguous(), 1.0, 0.5) for p in fg_masks], 0)
         else:                                    # otherwise the seediness map, averaged over clips, > threshold (:145-147)
             fg_masks = self.get_fg_masks_from_seediness(out)
         return out["embeddings"], fg_masks, out["multiclass_masks"]

@@ -73,15 +73,21 @@ class TrackContainer(object):
 
 
 class HipChainerOps(object):
-    """Device operations of the chainer on libstemseg_hip.so (tests may inject an oracle-backed twin)."""
+    """Device operations of the chainer on libstemseg_hip.so (tests may inject an oracle-backed twin).  Tensors stay on the
+    device they arrive on (the model's); host tensors go to ``device`` (TrackGenerator's ``clustering_device``)."""
 
-    device = "cuda"
+    def __init__(self, device=None):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.index is None and torch.cuda.is_available():
+            self.device = torch.device("cuda", torch.cuda.current_device())
 
     def to_device(self, t):
-        return t.to("cuda", non_blocking=True) if torch.is_tensor(t) else t
+        if not torch.is_tensor(t) or t.is_cuda:
+            return t
+        return t.to(self.device, non_blocking=True)
 
     def resize(self, x, scale):
-        return hip.upsample_trilinear(x.contiguous().float(), 1, int(scale), int(scale))
+        return hip.upsample_trilinear(x.contiguous().float(), 1, _int_scale(scale), _int_scale(scale))
 
     def gather(self, emb, bw, seed, fg):
         e, b, s, vox, offs = hip.fg_gather(emb.contiguous(), bw.contiguous(), seed.contiguous(), fg.contiguous())
@@ -96,12 +102,27 @@ class HipChainerOps(object):
         offs = pts["offs"].cpu().tolist()                 # synchronises
         return offs, hip.read_cluster_meta(meta_dev)
 
+    def present_ids(self, labels_list, cap=None):
+        """Ascending ids > 0 that occur in the (device, int64) label arrays -- the reference's ``unique()`` minus the outlier
+        id (online_chainer.py:304-308).  ``cap``: an exclusive upper bound on the ids when the caller has one (labels are
+        always below next_track_label + max_instances); without it one extra pass finds the maximum first."""
+        ls = [l.contiguous() for l in labels_list]
+        if not ls:
+            return []
+        if cap is None:
+            _, mx = hip.label_presence(ls, 0)
+            cap = int(mx.item())
+        present, mx = hip.label_presence(ls, cap)
+        host = torch.cat([present.to(torch.int64), mx]).cpu()           # one read-back
+        assert int(host[-1]) <= cap, "label %d beyond the stated bound %d" % (int(host[-1]) - 1, cap)
+        return [i for i in torch.nonzero(host[:-1]).flatten().tolist() if i > 0]
+
     def overlap_counts(self, la, lb, ids_a, ids_b):
         """ids_*: ascending candidate ids (> 0).  -> inter [Ka,Kb], cnt_a, cnt_b as numpy int64."""
         def lut(ids):
             t = torch.full((max(ids) + 2 if ids else 1,), -1, dtype=torch.int32)
-            for k, i in enumerate(ids):
-                t[i + 1] = k
+            if ids:
+                t[torch.as_tensor(ids, dtype=torch.int64) + 1] = torch.arange(len(ids), dtype=torch.int32)
             return t.to(la.device)
         inter, ca, cb = hip.overlap_counts(la.contiguous(), lb.contiguous(), lut(ids_a), lut(ids_b), len(ids_a), len(ids_b))
         return inter.cpu().numpy(), ca.cpu().numpy(), cb.cpu().numpy()
@@ -116,8 +137,20 @@ class HipChainerOps(object):
         return labels
 
     def max_label(self, labels_list):
-        nz = [l for l in labels_list if l.numel() > 0]
-        return int(torch.cat(nz).max().item()) if nz else None
+        nz = [l.contiguous() for l in labels_list if l.numel() > 0]
+        if not nz:
+            return None
+        _, mx = hip.label_presence(nz, 0)
+        m = int(mx.item()) - 1
+        return m if m >= 0 else -1            # all outliers: the reference's lab.max() is -1, max(0, -1) keeps 0
+
+
+def _int_scale(scale):
+    s = int(round(float(scale)))
+    if s < 1 or abs(float(scale) - s) > 1e-9:
+        raise NotImplementedError("embedding resize factor %r: the HIP trilinear kernel takes positive integer scales (the "
+                                  "reference only ever passes 1.0 or 4.0, inference/main.py:209-213)" % (scale,))
+    return s
 
 
 class OnlineChainer(object):
@@ -180,7 +213,7 @@ class OnlineChainer(object):
             overlap = sorted(set(frames).intersection(prev_frames))        # previous clip only (:201-202)
             existing = track.get_labels(overlap)
             current = [labels_per_frame[j] for j, t in enumerate(frames) if t in overlap]
-            associations = self.associate_clusters(existing, current)[0]
+            associations = self.associate_clusters(existing, current, next_track_label + self.clusterer.max_instances)[0]
             mapping = {cur: assoc for assoc, cur in associations}
             new_frames, new_labels = [], []
             for j, t in enumerate(frames):
@@ -217,26 +250,24 @@ class OnlineChainer(object):
         per_frame = [labels[offs[j]:offs[j + 1]] for j in range(len(offs) - 1)]
         return per_frame, pts, info
 
-    def associate_clusters(self, labels_1, labels_2):
+    def associate_clusters(self, labels_1, labels_2, id_bound=None):
         """Hungarian matching on 1 - IoU over the overlap frames (online_chainer.py:291-343).  Every returned pair is
-        accepted -- there is no IoU threshold.  Returns the reference's 5-tuple."""
+        accepted -- there is no IoU threshold.  Returns the reference's 5-tuple.  ``id_bound`` (optional): an exclusive upper
+        bound on the label ids, saves the pass that would find it."""
         la = labels_1 if torch.is_tensor(labels_1) else torch.cat(list(labels_1))
         lb = labels_2 if torch.is_tensor(labels_2) else torch.cat(list(labels_2))
         assert la.shape == lb.shape, "Shape mismatch: {}, {}".format(la.shape, lb.shape)
         if la.numel() == 0:
             return [], set(), set(), np.zeros(0, np.float32), (np.zeros((0, 0), np.float32), [], [])
-        hi = self.ops.max_label([la, lb]) or 0
-        cand = list(range(1, hi + 1))
-        # the outlier id is never associated; ids <= 0 other than -1 do not occur (labels start at 1)
-        inter, ca, cb = self.ops.overlap_counts(la, lb, cand, cand)
-        ids_1 = [c for k, c in enumerate(cand) if ca[k] > 0]
-        ids_2 = [c for k, c in enumerate(cand) if cb[k] > 0]
+        # only the ids that occur on the overlap frames enter the statistics (the reference's unique(), :304-308): the table
+        # is K1 x K2 <= a few hundred cells however large the track ids have grown
+        ids_1 = self.ops.present_ids([la], id_bound)
+        ids_2 = self.ops.present_ids([lb], id_bound)
         assert not set(ids_1).intersection(ids_2), "Labels overlap: {}, {}".format(ids_1, ids_2)
-        r = [cand.index(c) for c in ids_1]
-        c_ = [cand.index(c) for c in ids_2]
-        I = inter[np.ix_(r, c_)].astype(np.float32)
-        A = ca[r].astype(np.float32)[:, None]
-        B = cb[c_].astype(np.float32)[None, :]
+        inter, ca, cb = self.ops.overlap_counts(la, lb, ids_1, ids_2)
+        I = inter.astype(np.float32).reshape(len(ids_1), len(ids_2))
+        A = ca.astype(np.float32)[:, None]
+        B = cb.astype(np.float32)[None, :]
         U = (A + B - I).astype(np.float32)
         iou = (I / U).astype(np.float32) if I.size else np.zeros_like(I)
         costs = (1. - iou.astype(np.float64)).astype(np.float32)             # `1. - iou.item()` stored as float32 (:327)

@@ -37,6 +37,11 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
         if seediness_output:
             self.conv_seediness = nn.Conv3d(c4, 1, kernel_size=1, padding=0, bias=False)
             self.seediness_channels = 1
+        n_head = n_emb + self.variance_channels + self.seediness_channels
+        if n_head > 8:
+            raise NotImplementedError("embedding head with %d output channels (mode '%s', EMBEDDING_SIZE %d%s): the fused HIP "
+                                      "heads kernel emits at most 8 (every preset of the reference needs <= 7)"
+                                      % (n_head, experimental_dims, embedding_size, ", seediness" if seediness_output else ""))
         self.tanh_activation = tanh_activation
         self.register_buffer("time_scale", torch.tensor(1.0, dtype=torch.float32))
         # inference_model.py:148 applies exp()*10 to the variance channels afterwards; the pipeline can ask the

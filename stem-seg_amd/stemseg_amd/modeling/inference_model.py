@@ -96,8 +96,10 @@ class InferenceModel(nn.Module):
         with torch.no_grad():
             self._model = build_model()
         if restore_path:
-            sd = torch.load(restore_path, map_location="cpu")['model']
-            self._model.load_state_dict(sd, strict=False)
+            self.load_checkpoint_state(torch.load(restore_path, map_location="cpu")['model'])
+        if float(resize_scale) < 1 or float(resize_scale) != int(resize_scale):
+            raise NotImplementedError("resize_scale %r: the HIP trilinear kernel takes positive integer scales (the reference "
+                                      "passes 1.0, or 4.0 under --resize_embeddings, inference/main.py:209-213)" % (resize_scale,))
         self.resize_scale = resize_scale
         self.semseg_output_type = semseg_output_type
         self.outputs_on_cpu = outputs_on_cpu
@@ -108,6 +110,15 @@ class InferenceModel(nn.Module):
         self.eval()
 
     has_semseg_head = property(lambda self: self._model.semseg_head is not None)
+
+    def load_checkpoint_state(self, sd):
+        """Reference checkpoints (``torch.load(path)['model']``, inference_model.py:24) carry training-only entries (loss
+        buffers) next to the weights: unexpected keys are ignored, but every parameter of this model must be present --
+        a key-name drift would otherwise leave random weights behind silently."""
+        res = self._model.load_state_dict(sd, strict=False)
+        if res.missing_keys:
+            raise KeyError("checkpoint lacks %d parameter(s) of the model, e.g. %s" % (len(res.missing_keys), res.missing_keys[:5]))
+        return res
 
     def set_lane(self, lane):
         """Every cached workspace (encoder, decoders, zero-haloed FPN buffers) exists once per lane, so steps enqueued on

@@ -50,6 +50,11 @@ class OracleChainerOps(object):
     def read(self, pts, meta):
         return pts["offs"].tolist(), meta
 
+    def present_ids(self, labels_list, cap=None):
+        ids = np.unique(np.concatenate([l.numpy().reshape(-1) for l in labels_list])) if labels_list else np.zeros(0, np.int64)
+        assert cap is None or ids.size == 0 or ids.max() < cap
+        return [int(i) for i in ids if i > 0]
+
     def overlap_counts(self, la, lb, ids_a, ids_b):
         la, lb = la.numpy(), lb.numpy()
         inter = np.array([[np.sum((la == a) & (lb == b)) for b in ids_b] for a in ids_a], np.int64).reshape(len(ids_a), len(ids_b))

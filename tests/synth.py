@@ -89,3 +89,65 @@ def synth_cluster_case(T, H, W, K, E=4, Ev=2, seed=0, bg_fraction=0.15, noise=0.
     extra = rng.uniform(size=(T, H, W)) < bg_fraction * 0.1
     fg = np.where(extra, 1, fg).astype(np.uint8)
     return emb, bw, sd, fg
+
+
+def synth_long_sequence(n_clips, H=24, W=48, births_per_clip=4, seed=0, T=8, overlap=4):
+    """A long sequence whose TRACK IDS KEEP GROWING: every clip (T frames, stride T - overlap) sees ``births_per_clip`` new
+    instances appear on its first non-overlap frame; each lives for T frames and then dies, so it is born unmatched in one
+    clip, matched in the next two, and the sequence-wide id counter climbs by ~births_per_clip per clip (the regime of
+    long KITTI-MOTS sequences).  Returns emb [4,F,H,W], bw [2,F,H,W], seed [1,F,H,W] float32 and fg [F,H,W] uint8."""
+    stride = T - overlap
+    F = stride * (n_clips - 1) + T
+    rng = np.random.RandomState(7000 + seed)
+    emb = (10 + 3 * rng.standard_normal((4, F, H, W))).astype(np.float32)
+    bw = (25 + rng.uniform(0, 1, (2, F, H, W))).astype(np.float32)
+    sd = rng.uniform(0, 0.2, (1, F, H, W)).astype(np.float32)
+    fg = np.zeros((F, H, W), np.uint8)
+    rows = 3
+    ch, cw = H // rows, W // births_per_clip
+    bh, bwid = max(2, ch - 3), max(2, cw - 4)
+    k = 0
+    for gen in range(-2, n_clips):                      # generations -2, -1 populate the first clip's overlap-free start
+        first = stride * gen + overlap
+        for j in range(births_per_clip):
+            y0, x0 = (gen % rows) * ch + 1, j * cw + 2
+            free = (0.6 * ((k * 7) % 5 - 2), 0.6 * ((k * 3) % 5 - 2))
+            k += 1
+            for t in range(max(first, 0), min(first + T, F)):
+                c = np.array([-1 + 2 * (y0 + bh / 2) / H, -1.3 + 2.6 * (x0 + bwid / 2) / W, free[0], free[1]], np.float32)
+                nz = (0.04 * rng.standard_normal((4, bh, bwid))).astype(np.float32)
+                emb[:, t, y0:y0 + bh, x0:x0 + bwid] = c[:, None, None] + nz
+                sd[0, t, y0:y0 + bh, x0:x0 + bwid] = np.clip(1 - np.sqrt((nz ** 2).sum(0)), 0, 1)
+                fg[t, y0:y0 + bh, x0:x0 + bwid] = 1
+    fg = np.where(rng.uniform(size=fg.shape) < 0.01, 1, fg).astype(np.uint8)
+    return emb, bw, sd, fg
+
+
+def long_sequence_case(golden_npz, to_tensor):
+    """(fg, clip dicts, expected) of the ``chainer_long`` golden: inputs regenerated from the stored seed (checksums
+    verified), expected outputs as the reference's chainer produced them."""
+    import zlib
+    g = golden_npz
+    n_clips = int(g["n_clips"])
+    emb, bw, sd, fg = synth_long_sequence(n_clips, seed=int(g["seed"]))
+    assert [zlib.crc32(a.tobytes()) for a in (emb, bw, sd, fg)] == g["input_crc"].tolist(), "synthetic inputs drifted"
+    F = fg.shape[0]
+    clips = [list(range(4 * i, 4 * i + 8)) for i in range(n_clips)]
+    assert clips[-1][-1] == F - 1
+    dicts = [dict(frames=list(fr), embeddings=to_tensor(emb[:, fr].copy()), bandwidths=to_tensor(bw[:, fr].copy()),
+                  seediness=to_tensor(sd[:, fr].copy())) for fr in clips]
+    track = np.split(g["track_labels"].astype(np.int64), np.cumsum(g["track_sizes"])[:-1])
+    inst = np.split(g["instance_labels"], np.cumsum(g["instance_label_sizes"])[:-1])
+    exp = dict(track=track, counts=[tuple(r) for r in g["pt_counts"].tolist()], life=[tuple(r) for r in g["lifetimes"].tolist()],
+               instance_labels=[a.tolist() for a in inst])
+    return fg, dicts, exp
+
+
+def check_long_sequence(result, exp):
+    (track, counts, life), _, _, _, meta = result
+    assert len(track) == len(exp["track"])
+    for t, l in enumerate(track):
+        assert np.array_equal(l.cpu().numpy(), exp["track"][t]), "frame %d: track labels differ from the reference" % t
+    assert sorted(counts.items()) == exp["counts"] and sorted(life.items()) == exp["life"]
+    assert [m["instance_labels"] for m in meta] == exp["instance_labels"]
+    return max(counts)

@@ -817,6 +817,37 @@ def test_overlap_counts_and_relabel(hip):
     assert np.array_equal(t.cpu().numpy(), ref)
 
 
+def test_overlap_counts_ids_beyond_500_and_large_tables(hip):
+    """Label VALUES may be arbitrarily large (track ids only grow, online_chainer.py:43-49) and the id sets arbitrarily big:
+    the LDS table serves K1 x K2 up to 12k cells, global atomics beyond; both exact vs numpy."""
+    from stemseg_amd.inference.online_chainer import HipChainerOps
+    from tests.oracle_ops import OracleChainerOps
+    ops, ref = HipChainerOps(), OracleChainerOps()
+    rs = np.random.RandomState(9)
+    for ids_a, ids_b, n in (([3, 501, 777, 1203], [1204, 1210, 4000], 20000),                       # few ids, large values
+                            (list(range(5, 305)), list(range(1000, 1300)), 200000)):                 # 300 x 300: global-atomic path
+        la = np.where(rs.uniform(size=n) < 0.2, -1, rs.choice(ids_a, n)).astype(np.int64)
+        lb = np.where(rs.uniform(size=n) < 0.3, -1, rs.choice(ids_b, n)).astype(np.int64)
+        assert ops.present_ids([dev(la)]) == ref.present_ids([torch.from_numpy(la)])
+        assert ops.present_ids([dev(la[: n // 2]), dev(la[n // 2:])], cap=max(ids_a) + 1) == sorted(set(la[la > 0].tolist()))
+        assert ops.max_label([dev(la), dev(lb)]) == max(la.max(), lb.max()) and ops.max_label([dev(np.full(7, -1, np.int64))]) == -1
+        got = ops.overlap_counts(dev(la), dev(lb), ids_a, ids_b)
+        exp = ref.overlap_counts(torch.from_numpy(la), torch.from_numpy(lb), ids_a, ids_b)
+        assert all(np.array_equal(x, y) for x, y in zip(got, exp))
+    with pytest.raises(AssertionError):
+        ops.present_ids([dev(np.array([5, 900], np.int64))], cap=100)                                # a wrong bound is caught
+
+
+def test_chainer_track_ids_beyond_500_on_gpu_vs_golden(hip, golden):
+    """The 48-clip sequence whose track ids the reference drives to 527 (tests/golden/chainer_long.npz): tracks, counts,
+    lifetimes and per-clip instance lists identical through the HIP chainer."""
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    fg, dicts, exp = synth.long_sequence_case(golden("chainer_long"), dev)
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cuda:0"), 1.0)
+    assert synth.check_long_sequence(ch.process(torch.from_numpy(fg), dicts), exp) > 500
+
+
 # ------------------------------------------------------------------------------------------------ chainer / model end to end
 @pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single"])
 def test_chainer_on_gpu_vs_golden(hip, golden, tag):

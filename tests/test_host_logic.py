@@ -252,6 +252,14 @@ def test_chainer_bookkeeping_vs_golden(golden, tag):
     assert all(d["embeddings"] is None for d in dicts)       # reference clears the tensors (online_chainer.py:239)
 
 
+def test_chainer_track_ids_beyond_500_vs_golden(golden):
+    """48 clips with births and deaths in every clip: the reference's track ids reach 527 (online_chainer.py:43-49 hands out
+    highest id + 1).  The association only ever looks at the ids present on the overlap frames (:304-308)."""
+    fg, dicts, exp = synth.long_sequence_case(golden("chainer_long"), torch.from_numpy)
+    top = synth.check_long_sequence(_make_chainer().process(torch.from_numpy(fg), dicts), exp)
+    assert top > 500
+
+
 def test_chainer_resize_path(golden):
     g = golden("chainer")
     e = torch.from_numpy(g["resize__in"])

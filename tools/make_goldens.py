@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "chainer_long", "misc"]
 
 
 def _save(name, **arrays):
@@ -538,6 +538,39 @@ def gen_chainer():
     _save("chainer", **out)
 
 
+def gen_chainer_long():
+    """48 clips whose track ids climb past 190 (tests/synth.synth_long_sequence) through the reference's chainer: the
+    regime where a max-id-sized association table breaks.  Only the OUTPUTS are stored (the inputs are regenerated from
+    the seed; their checksums are kept to detect drift)."""
+    import ref_shim
+    ref_shim.install()
+    import zlib
+    import torch
+    from stemseg.inference.clusterers import SequentialClustering
+    from stemseg.inference.online_chainer import OnlineChainer
+    from stemseg.inference.main import get_subsequence_frames
+    n_clips, seed = 48, 3
+    emb, bw, sd, fg = synth.synth_long_sequence(n_clips, seed=seed)
+    F = fg.shape[0]
+    subseqs, _ = get_subsequence_frames(F, 8, "kittimots", 4)
+    assert len(subseqs) == n_clips
+    dicts = [dict(frames=list(fr), embeddings=torch.from_numpy(emb[:, fr].copy()), bandwidths=torch.from_numpy(bw[:, fr].copy()),
+                  seediness=torch.from_numpy(sd[:, fr].copy())) for fr in subseqs]
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0)
+    (track_labels, pt_counts, lifetimes), _, subseq_labels, _, meta = ch.process(torch.from_numpy(fg), dicts)
+    out = {"n_clips": np.int64(n_clips), "seed": np.int64(seed),
+           "input_crc": np.array([zlib.crc32(a.tobytes()) for a in (emb, bw, sd, fg)], np.int64),
+           "track_sizes": np.array([l.numel() for l in track_labels], np.int64),
+           "track_labels": np.concatenate([l.numpy() for l in track_labels]).astype(np.int32),
+           "pt_counts": np.array(sorted(pt_counts.items()), np.int64).reshape(-1, 2),
+           "lifetimes": np.array(sorted(lifetimes.items()), np.int64).reshape(-1, 2),
+           "instance_label_sizes": np.array([len(m["instance_labels"]) for m in meta], np.int64),
+           "instance_labels": np.concatenate([np.array(m["instance_labels"], np.int64) for m in meta])}
+    print("chainer_long: %d frames, %d clips, highest track id %d" % (F, n_clips, max(pt_counts)))
+    assert max(pt_counts) > 150
+    _save("chainer_long", **out)
+
+
 # ------------------------------------------------------------------------------------------------
 def gen_misc():
     import ref_shim
@@ -624,6 +657,8 @@ def main():
         gen_cluster()
     elif g == "chainer":
         gen_chainer()
+    elif g == "chainer_long":
+        gen_chainer_long()
     elif g == "misc":
         gen_misc()
 
