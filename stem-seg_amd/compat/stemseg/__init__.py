@@ -1,1 +1,1 @@
-"""Reference-compatible namespace for the MI355X hot path (re-exports of stemseg_amd; see ../README.md)."""
+"""Skeleton ``stemseg`` package: only reached when no sabarim/STEm-Seg checkout is importable (see ../README.md)."""

@@ -1,1 +1,3 @@
-from stemseg_amd.utils.global_registry import GlobalRegistry  # noqa: F401
+"""``from stemseg.utils import Timer, RepoPaths`` (utils/__init__.py:1-3)."""
+from stemseg_amd.utils.paths import RepoPaths  # noqa: F401
+from stemseg_amd.utils.timer import Timer  # noqa: F401

@@ -62,3 +62,24 @@ def load_preset(preset):
     for k, v in vars(new).items():
         setattr(cfg, k, copy.deepcopy(v))
     return cfg
+
+
+# ---- external configuration sources (stemseg_amd.overlay: the reference's own global cfg) -----------------------------
+_sources = []
+
+
+def register_source(fn):
+    """fn(cfg) copies values into ``cfg``; called by ``refresh()`` -- i.e. whenever a model is built or run."""
+    if fn not in _sources:
+        _sources.append(fn)
+
+
+def unregister_source(fn):
+    if fn in _sources:
+        _sources.remove(fn)
+
+
+def refresh():
+    for fn in _sources:
+        fn(cfg)
+    return cfg

@@ -8,6 +8,7 @@ Two HIP launches per frame (scatter, fused resample); nothing is synchronised.
 import torch
 
 from ... import hip
+from ... import config as _config
 from ...config import cfg
 from ...modeling.inference_model import compute_resize_params_2
 
@@ -41,6 +42,7 @@ class MaskMaterializer(object):
         Returns (instances_to_keep, uint8 [F, image_height, image_width] on the device: n + 1 where instance
         instances_to_keep[n] covers the pixel)."""
         hip.require_gpu()
+        _config.refresh()
         assert len(track_mask_idxes) == len(track_mask_labels)
         assert max_tracks < 256
         mask_h, mask_w = mask_dims

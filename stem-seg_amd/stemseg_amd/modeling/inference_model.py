@@ -19,12 +19,10 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from .. import config as _config
 from ..config import cfg
-from .backbone import BACKBONE_REGISTRY
-from .embedding_decoder import EMBEDDING_HEAD_REGISTRY
 from .embedding_utils import get_nb_free_dims  # noqa: F401  (re-export, as in the reference's import surface)
-from .seediness_decoder import SEEDINESS_HEAD_REGISTRY
-from .semseg_decoder import SEMSEG_HEAD_REGISTRY
+from .model_builder import build_model
 
 EmbeddingMapEntry = namedtuple("EmbeddingMapEntry", ["subseq_frames", "embeddings", "bandwidths", "seediness"])
 
@@ -50,6 +48,7 @@ def preprocess_frames(frames, device="cuda"):
     to cfg MIN/MAX_DIM, mean-subtract (no /255, std 1 with the reference's configs), zero-pad right/bottom to multiples of
     32 -- one HIP launch (inference_image_loader.py:23-43, data/common.py:12-30, image_list.py:93-104)."""
     hip.require_gpu()
+    _config.refresh()
     x = torch.as_tensor(np.ascontiguousarray(frames)) if not torch.is_tensor(frames) else frames
     assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[-1] == 3, "frames: uint8 [T, H, W, 3]"
     x = x.to(device).contiguous()
@@ -61,40 +60,12 @@ def preprocess_frames(frames, device="cuda"):
     return out, (nh, nw)
 
 
-def build_model():
-    """backbone + heads from the global cfg (model_builder.py:247-369 minus the losses)."""
-    m = nn.Module()
-    m.backbone = BACKBONE_REGISTRY[cfg.MODEL.BACKBONE.TYPE](cfg)
-    e = cfg.MODEL.EMBEDDINGS
-    norm = lambda c: nn.GroupNorm(e.GN_NUM_GROUPS, c)  # noqa: E731
-    assert e.NORMALIZATION_LAYER == "gn" and e.POOL_TYPE == "avg"
-    m.embedding_head = EMBEDDING_HEAD_REGISTRY[e.HEAD_TYPE](
-        m.backbone.out_channels, e.INTER_CHANNELS, e.EMBEDDING_SIZE, tanh_activation=e.TANH_ACTIVATION,
-        seediness_output=not cfg.MODEL.USE_SEEDINESS_HEAD, experimental_dims=cfg.MODEL.EMBEDDING_DIM_MODE,
-        PoolType=nn.AvgPool3d, NormType=norm)
-    m.seediness_head = None
-    if cfg.MODEL.USE_SEEDINESS_HEAD:
-        s = cfg.MODEL.SEEDINESS
-        m.seediness_head = SEEDINESS_HEAD_REGISTRY[s.HEAD_TYPE](
-            m.backbone.out_channels, s.INTER_CHANNELS, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(s.GN_NUM_GROUPS, c))
-    m.semseg_head = None
-    if cfg.MODEL.USE_SEMSEG_HEAD:
-        g = cfg.MODEL.SEMSEG
-        assert g.NORMALIZATION_LAYER == "gn" and g.POOL_TYPE == "avg"
-        m.semseg_head = SEMSEG_HEAD_REGISTRY[g.HEAD_TYPE](
-            m.backbone.out_channels, cfg.INPUT.NUM_CLASSES, inter_channels=g.INTER_CHANNELS, feature_scales=g.FEATURE_SCALE,
-            foreground_channel=g.FOREGROUND_CHANNEL, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(g.GN_NUM_GROUPS, c))
-        m.semseg_feature_map_scale = list(g.FEATURE_SCALE)
-    m.embedding_head_feature_map_scale = list(e.SCALE)
-    return m
-
-
 class InferenceModel(nn.Module):
     def __init__(self, restore_path=None, cpu_workers=0, preload_images=False, semseg_output_type=None, resize_scale=1.0,
                  semseg_generation_on_gpu=True, outputs_on_cpu=False):
         super().__init__()
         with torch.no_grad():
-            self._model = build_model()
+            self._model = build_model(restore_pretrained_backbone_wts=False)
         if restore_path:
             self.load_checkpoint_state(torch.load(restore_path, map_location="cpu")['model'])
         if float(resize_scale) < 1 or float(resize_scale) != int(resize_scale):
@@ -109,7 +80,19 @@ class InferenceModel(nn.Module):
         self.lane = 0
         self.eval()
 
+    semseg_outputs_on_cpu = False       # True under stemseg_amd.overlay: the reference's writers index these on the host
     has_semseg_head = property(lambda self: self._model.semseg_head is not None)
+    mask_scale = property(lambda self: self._model.semseg_output_scale)                 # inference_model.py:43-45
+
+    @staticmethod
+    def load_images(image_paths):
+        """BGR uint8 arrays like ``cv2.imread(path, cv2.IMREAD_COLOR)`` (inference_model.py:51-53); PIL when cv2 is absent."""
+        try:
+            import cv2
+            return [cv2.imread(p, cv2.IMREAD_COLOR) for p in image_paths]
+        except ImportError:
+            from PIL import Image
+            return [np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1]) for p in image_paths]
 
     def load_checkpoint_state(self, sd):
         """Reference checkpoints (``torch.load(path)['model']``, inference_model.py:24) carry training-only entries (loss
@@ -258,7 +241,7 @@ class InferenceModel(nn.Module):
             return [], []
         cnt = torch.as_tensor(counts, dtype=torch.float32).to(acc.device)
         fg, mc = hip.semseg_masks(acc, cnt, self.semseg_output_type)
-        if self.outputs_on_cpu:
+        if self.outputs_on_cpu or self.semseg_outputs_on_cpu:
             fg, mc = fg.cpu(), (mc.cpu() if mc is not None else None)
         return fg, (mc if mc is not None else [])
 
@@ -274,11 +257,15 @@ class InferenceModel(nn.Module):
         """images: list/array of uint8 BGR frames [H0,W0,3] (or a pre-processed float tensor [N,3,H,W] on the device);
         subseq_idxes: list of frame-index lists (duplicates allowed, inference/main.py:37-39)."""
         hip.require_gpu()
+        _config.refresh()
         m = self._model
+        dev = next(m.parameters()).device
         if torch.is_tensor(images) and images.dtype == torch.float32 and images.dim() == 4:
-            frames = images.cuda()
+            frames = images if images.is_cuda else images.to(dev)
         else:
-            frames, _ = preprocess_frames(np.stack([np.asarray(im) for im in images], 0))
+            if len(images) and isinstance(images[0], (str, bytes)):                     # file paths, as inference/main.py:137-138 passes
+                images = self.load_images(images)
+            frames, _ = preprocess_frames(np.stack([np.asarray(im) for im in images], 0), dev)
         H, W = frames.shape[-2:]
         cache, deps = {}, {}
         for i, sub in enumerate(subseq_idxes):
