@@ -11,6 +11,15 @@ per-frame), then per clip 3-D decoders -> fused heads -> fg mask -> fg gather ->
 clustering record (K, instance list), with the input frames already resident in HBM.  The step is captured as a hipGraph
 per lane; --lanes (default 3) steps are in flight on their own streams and workspaces.  value = clips / s.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
 are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py --sequence [--frames 64|36]      # BASELINE configs[3]: ONE long sequence sharded over the ranks
+
+--sequence: a step = the whole sequence through ``pipeline.run_sequence_sharded`` -- clips dealt round-robin to the ranks
+(64 frames / overlap 4 -> 15 clips; 36 frames -> exactly 8, one per GPU at N = 8), every rank embeds its clips (hipGraph
+replay of encoder + decoders + heads), ONE all-gather (RCCL over xGMI) of the head outputs INSIDE the timed region, then the
+replicated chain (cross-clip fg mask, clustering, Hungarian stitching).  value = clips / s of the whole job (strong scaling:
+the sequence is fixed); the line also carries the all-gather's bytes / time and a checksum of the stitched track labels that
+must be the same at every N.  The default mode and this one share the model, weights and kernels.
 """
 import argparse
 import json
@@ -25,8 +34,9 @@ sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
-TRAFFIC_BLOCK4X_GB = 0.87         # measured offline with PMC counters (cannot be read from inside the process)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_conv3d_block4x_latest.json")   # written by tools/pmc_conv.py's summary step
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # same guide: bf16 MFMA, dense (the 2:1-sparse 5 PF figure is not used)
+PEAK_HBM_GBPS = 8000.0            # same guide: HBM3E, ~8 TB/s
 T, H, W = 8, 480, 864             # BASELINE config 1: DAVIS-shape 480p (480x854 padded to a multiple of 32)
 BACKBONE = "R-101-FPN"
 
@@ -86,20 +96,26 @@ def make_clip(seed, device):
     return x.to(device)
 
 
-def cpu_baseline(sd, frames_cpu, gpu_out=None):
-    """The CPU oracle (a restatement of the reference's PyTorch path, pinned against reference-generated goldens)
-    on the host cores: ONE clip of the same workload, 1 timed run (no warm-up; ~10-30 s).  With ``gpu_out`` (the HIP path's
-    result for the same clip) the two are also compared: the full-size parity check of this very run."""
+def cpu_baseline(sd, frames_cpu, gpu_out=None, runs=3):
+    """The CPU oracle (a restatement of the reference's PyTorch path, pinned against reference-generated goldens) on the
+    host cores: ONE clip of the same workload, 1 warm-up + ``runs`` timed runs, median.  Threads: the
+    box's cores up to 32 -- measured, torch's CPU conv / GroupNorm path gets SLOWER beyond that on the 2-socket host (141 s
+    per clip with all 256 hardware threads) -- both counts are reported.  With ``gpu_out`` (the HIP path's result for the
+    same clip) the two are also compared: the full-size parity check of this very run."""
     from oracle import pipeline as opipe
-    # more threads than ~32 make torch's CPU conv / GroupNorm path slower on the 2-socket host (141 s with 256)
     n = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n)
-    t0 = time.time()
-    out = opipe.embed_and_cluster_clip(frames_cpu, sd, BACKBONE, "xyff", 4, True, free_dim_stds=[0.3, 0.3])
-    dt = time.time() - t0
-    res = {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": "1 clip (T=8, 480x864, %s, DAVIS heads), 1 timed run incl. first-call overhead; %d fg points, %d instances"
-                     % (BACKBONE, out["labels"].shape[0], len(out["meta"]["instance_labels"]))}
+    times, out = [], None
+    for i in range(1 + runs):
+        t0 = time.time()
+        out = opipe.embed_and_cluster_clip(frames_cpu, sd, BACKBONE, "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+        times.append(time.time() - t0)
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    res = {"value": round(1.0 / med, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "host_hw_threads": os.cpu_count(), "kind": "port",
+           "sample": "1 clip (T=8, 480x864, %s, DAVIS heads): 1 warm-up (%.1f s) + %d timed runs, median %.2f s (min %.2f, max %.2f); "
+                     "%d fg points, %d instances; torch %s CPU backend"
+                     % (BACKBONE, times[0], runs, med, timed[0], timed[-1], out["labels"].shape[0], len(out["meta"]["instance_labels"]), torch.__version__)}
     if gpu_out is not None:
         import numpy as np
         g_emb, g_seed = gpu_out["emb"].cpu().numpy(), gpu_out["seed"].cpu().numpy()
@@ -118,6 +134,78 @@ def cpu_baseline(sd, frames_cpu, gpu_out=None):
             "labels_identical_fraction_on_common_fg": float((g_lab[both] == c_lab[both]).mean()) if both.any() else None,
             "note": "fg / label differences come from points whose seediness or probability sits within the float tolerance of a threshold"}
     return res
+
+
+def sequence_mode(args, pipe, device, rank, world, use_dist):
+    """One step = the whole sequence (see the module docstring).  Every rank ends with the same stitched tracks."""
+    import zlib
+    import torch.distributed as dist
+    from stemseg_amd import hip
+    from stemseg_amd.inference.main import get_subsequence_frames
+    from stemseg_amd.pipeline import run_sequence_sharded
+    F, overlap = args.frames, 4
+    n_src = (F + T - 1) // T
+    frames = torch.cat([make_clip(5000 + i, device) for i in range(n_src)], 0)[:F].contiguous()      # same frames on every rank
+    clips, _ = get_subsequence_frames(F, T, "davis", overlap)
+    pipe.model.overlap_decoders = False
+    if args.no_graph:
+        def embed(fr):
+            return pipe.embed(frames[torch.as_tensor(fr, device=device)])
+    else:
+        g = pipe.capture_embed(frames[:T].contiguous())
+
+        def embed(fr):
+            return g.run(frames[torch.as_tensor(fr, device=device)])
+    chainer = pipe.tg.chainer
+    stats, ag_ms, res = {}, [], None
+
+    def one():
+        return run_sequence_sharded(F, embed, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats)
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+    for _ in range(max(args.warmup, 1)):
+        res = one()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one()
+        ag_ms.append(stats["allgather_ms"])
+    sync()
+    dt = time.perf_counter() - t0
+    (track, counts, life) = res[0]
+    crc = zlib.crc32(torch.cat([t.cpu() for t in track]).numpy().tobytes()) if track else 0
+    if use_dist:
+        t = torch.tensor([dt, float(crc)], dtype=torch.float64, device=device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dt = float(tmax[0].item())
+        assert float(tmax[1].item()) == float(tmin[1].item()), "ranks disagree on the stitched tracks"
+    if rank == 0:
+        n_clips = len(clips)
+        print(json.dumps({
+            "metric": "clips/sec (T=8, 480p) embed+cluster, one %d-frame sequence sharded over the GPUs" % F,
+            "value": round(n_clips * args.steps / dt, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt round-robin "
+                                   "to %d rank(s), %s, both decoders; all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + "
+                                   "clustering + Hungarian stitching" % (F, overlap, n_clips, world, BACKBONE),
+                       "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "eager" if args.no_graph else "hipGraph replay",
+                       "switches": library_switches()},
+            "exchange": {"collective": "all_gather (RCCL)" if world > 1 else "none (one rank)", "bytes_received_per_rank": stats["allgather_bytes"],
+                         "ms_median": round(sorted(ag_ms)[len(ag_ms) // 2], 3) if ag_ms else 0.0, "inside_timed_region": True},
+            "result": {"frames": len(track), "fg_points": int(sum(counts.values())), "highest_track_id": int(max(list(counts) + [0])),
+                       "label_checksum_crc32": int(crc), "note": "the checksum must be identical for every --gpus N"}}))
+
+
+def library_switches():
+    """The A/B switches the library reads from the environment (csrc/conv_igemm.hip), as set for this run."""
+    return {k: os.environ.get(k, "default") for k in ("STEMSEG_K3_DB", "STEMSEG_FLAT", "STEMSEG_PLANNER", "STEMSEG_T_FASTEST")}
 
 
 def mark(msg):
@@ -145,6 +233,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=3,
                     help="captured steps in flight on one GPU, each with its own workspaces and stream (graph mode): the kernels of "
                          "one step fill the tail rounds and memory-bound phases of the other")
+    ap.add_argument("--sequence", action="store_true",
+                    help="BASELINE configs[3]: one long sequence, clips sharded round-robin over the ranks, RCCL all-gather of the head "
+                         "outputs inside the timed region, replicated stitching (see the module docstring)")
+    ap.add_argument("--frames", type=int, default=64, help="--sequence: frames of the sequence (64 -> 15 clips at overlap 4; 36 -> 8)")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -167,6 +259,11 @@ def main():
     hip.require_gpu()
     pipe, sd = build_pipeline(device)
     pipe.model.set_precision(args.precision)
+    if args.sequence:
+        sequence_mode(args, pipe, device, rank, world, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     NC = max(1, args.clips_per_step)
     clips = [torch.cat([make_clip(1000 + rank * 97 + i * NC + c, device) for c in range(NC)], 0) for i in range(2)]
 
@@ -263,18 +360,39 @@ def main():
 
     if rank == 0:
         clips_total = args.steps * world * NC
-        # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes), measured inside the timed region
+        # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes)
         peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / 3.0
-        k3 = [prof[t] for t in (8, 4, 2) if t in prof]
+        k3 = [prof[t] for t in hip.PROFILE_CONV_TAGS["conv3x3x3"] if t in prof]
         ms = sum(p[0] for p in k3)
         fl = sum(p[1] for p in k3)
         launches = sum(p[2] for p in k3)
         ach = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        per_clip = 1.0 / (n_roof * NC)
+
         def cls(tags):
             sel = [prof[t] for t in tags if t in prof]
-            m, f = sum(q[0] for q in sel) / (n_roof * NC), sum(q[1] for q in sel) / (n_roof * NC)
-            return {"ms_per_clip": round(m, 3), "gflop_per_clip": round(f / 1e9, 1), "tflops": round(f / m / 1e9, 1) if m > 0 else None}
-        breakdown = {"conv3x3x3": cls((8, 4, 2)), "conv1x3x3": cls((28, 24, 22)), "conv1x1x1": cls((18, 14, 16, 12))}
+            m, f = sum(q[0] for q in sel) * per_clip, sum(q[1] for q in sel) * per_clip
+            return {"ms_per_clip": round(m, 3), "gflop_per_clip": round(f / 1e9, 1), "tflops": round(f / m / 1e9, 1) if m > 0 else None,
+                    "frac_of_mfma_peak": round(f / m / 1e9 / peak, 3) if m > 0 else None}
+        breakdown = {name: cls(tags) for name, tags in hip.PROFILE_CONV_TAGS.items()}
+        # whole step against the MFMA roof: every convolution FLOP of a clip (encoder + both decoders) over the TIMED region
+        conv_flop_clip = sum(prof[t][1] for tags in hip.PROFILE_CONV_TAGS.values() for t in tags if t in prof) * per_clip
+        whole_tf = conv_flop_clip * clips_total / world / dt / 1e12
+        # the streaming kernels against the HBM roof: algorithmic bytes (inputs read once + outputs written once) / elapsed
+        hbm = []
+        for tag, name in sorted(hip.PROFILE_HBM_TAGS.items()):
+            if tag in prof and prof[tag][0] > 0:
+                m_, by, n_ = prof[tag]
+                hbm.append({"kernel": name, "launches_per_clip": round(n_ * per_clip, 2), "mb_per_clip": round(by * per_clip / 1e6, 2),
+                            "us_per_clip": round(1e3 * m_ * per_clip, 1), "gb_per_s": round(by / m_ / 1e6, 1),
+                            "frac_of_hbm_peak": round(by / m_ / 1e6 / PEAK_HBM_GBPS, 3)})
+        traffic, traffic_note = None, "not collected in this process: PMC counters need their own rocprofv3 --pmc passes (tools/gpu_round.sh pmc)"
+        if args.precision == "f32" and os.path.exists(TRAFFIC_FILE):
+            try:
+                tj = json.load(open(TRAFFIC_FILE))
+                traffic, traffic_note = tj["gb_per_launch_group"], "offline, %s: %s" % (os.path.relpath(TRAFFIC_FILE, ROOT), tj["note"])
+            except Exception as e:  # noqa: BLE001
+                traffic_note = "could not read %s: %r" % (TRAFFIC_FILE, e)
         res = {
             "metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(clips_total / dt, 4), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -284,17 +402,22 @@ def main():
             "config": {"workload": "BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + "
                                    "seediness decoders, fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE,
                        "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
-                       "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}},
+                       "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
+                       "switches": library_switches()},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": TRAFFIC_BLOCK4X_GB if args.precision == "f32" else None,
-                         "traffic_note": "GB per block_4x conv (its two row sub-launches + the split-K reduce; algorithmic 0.322 GB), FETCH_SIZE x2 + "
-                                         "WRITE_SIZE from separate rocprofv3 --pmc passes, profiles/r01_pmc_conv3d_block4x.txt",
+                         "traffic": traffic, "traffic_note": traffic_note,
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                         "how": "hipEvent pairs around every 3x3x3 conv launch (incl. its split-K reduce) over %d eager steps after the "
-                                "timed region; a launch = one kernel launch of the conv (the block_4x conv issues two)" % n_roof,
+                         "how": "hipEvent pairs (in-library profiler, on the launch's own stream) around every tagged launch over %d eager "
+                                "single-stream steps right after the timed region; conv launches include their split-K reduce; a launch = one "
+                                "kernel launch of the conv (the planner may cut the block_4x conv in two)" % n_roof,
                          "hip_graph_replay_in_timed_region": graph is not None,
-                         "conv_classes_eager": breakdown},
+                         "whole_step": {"bound": "mfma", "gflop_per_clip": round(conv_flop_clip / 1e9, 1), "achieved": round(whole_tf, 2),
+                                        "peak": round(peak, 1), "unit": "TFLOP/s per GPU", "frac": round(whole_tf / peak, 4),
+                                        "how": "all convolution FLOPs of the clips processed / the timed region itself (graph replay, %d steps in flight)"
+                                               % (len(lanes) if graph is not None else 1)},
+                         "conv_classes_eager": breakdown,
+                         "hbm_kernels_eager": {"peak_gb_per_s": PEAK_HBM_GBPS, "bytes": "algorithmic: inputs read once + outputs written once", "kernels": hbm}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -461,6 +461,7 @@ extern "C" int stemseg_hip_fg_gather(const float* emb, const float* bw, const fl
     int* counts = reinterpret_cast<int*>(scratch);
     long long* offsets = reinterpret_cast<long long*>(reinterpret_cast<char*>(scratch) + round_up((int64_t)nb * 4, 8));
     hipStream_t s = as_stream(stream);
+    void* ev = profile_begin(45, (double)V * (1.0 + 4.0 * (E + Ev + 1)), s);     // mask + head channels read once (writes <= that)
     hipLaunchKernelGGL(gather_count_kernel, dim3(nb), dim3(256), 0, s, fg, V, counts);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)counts, offsets, nb);
@@ -470,6 +471,7 @@ extern "C" int stemseg_hip_fg_gather(const float* emb, const float* bw, const fl
     p.emb_out = emb_out; p.bw_out = bw_out; p.seed_out = seed_out; p.vox = voxel_index;
     p.frame_offsets = reinterpret_cast<long long*>(frame_offsets); p.block_offsets = offsets;
     hipLaunchKernelGGL(gather_scatter_kernel, dim3(nb), dim3(256), 0, s, p);
+    profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
@@ -510,11 +512,14 @@ extern "C" int stemseg_hip_cluster(const float* emb, const float* bw, const floa
     p.meta = meta_dev; p.labels = reinterpret_cast<long long*>(labels); p.masks = opt_masks; p.probs = opt_probs;
     p.nblk = grid_for(n_max, CL_THREADS * 4, CL_MAX_BLOCKS);
     static_assert(sizeof(StemsegClusterMeta) % 4 == 0 && sizeof(ClusterState) % 4 == 0, "word-zeroed in the round -1 launch");
+    // compulsory bytes: every point's inputs read once, its int64 label written once (36 B / point for E+Ev = 6)
+    void* ev = profile_begin(46, (double)n_max * (4.0 * (E + Ev + 1) + 8.0), s);
     for (int round = -1; round < params->max_instances; ++round) {
         hipLaunchKernelGGL(cluster_round_kernel, dim3(p.nblk), dim3(CL_THREADS), 0, s, p, round);
         SS_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(cluster_final_kernel, dim3(grid_for(n_max, CL_THREADS, 2048)), dim3(CL_THREADS), 0, s, p);
+    profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }

@@ -264,9 +264,13 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
     {
         const int Ho = p.H / 2, Wo = p.W / 2;
         const int blocks = (int)(ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T);
+        void* ev = profile_begin(47, 4.0 * ((double)3 * T * p.H * p.W + 64.0 * T * Ho * Wo), s);
         hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        profile_end(ev, s);
         SS_LAUNCH_CHECK();
+        ev = profile_begin(48, 4.0 * 64.0 * T * ((double)Ho * Wo + (double)p.V[0] / T), s);
         hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid1d(64 * p.V[0])), dim3(256), 0, s, (const float*)(ws + p.S0), ws + p.X1, (int64_t)64 * T, Ho, Wo);
+        profile_end(ev, s);
         SS_LAUNCH_CHECK();
     }
     // residual stages (resnet.py:105-113)
@@ -282,7 +286,9 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             SS_CHECK_ARG(!first || (wts->down_w[bi] && wts->down_b[bi]), "encoder_forward: block %d needs a projection shortcut", bi);
             float* xin = x;
             if (stride2) {
+                void* ev = profile_begin(49, 4.0 * 2.0 * (double)cin * V, s);       // (the kept quarter is read, sector granularity aside)
                 hipLaunchKernelGGL(subsample2_kernel, dim3(grid1d((int64_t)cin * V)), dim3(256), 0, s, (const float*)x, ws + p.XS, (int64_t)cin * T, 2 * h, 2 * w);
+                profile_end(ev, s);
                 SS_LAUNCH_CHECK();
                 xin = ws + p.XS;
             }
@@ -324,8 +330,10 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         if (rc) return rc;
         if (k < 3) {
             Padded2D gf(256, T, h, w), gc(256, T, p.h[k + 1], p.w[k + 1]);
+            void* ev = profile_begin(50, 4.0 * 256.0 * (2.0 * p.V[k] + p.V[k + 1]), s);         // fine read + written, coarse read
             hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid1d(256 * p.V[k])), dim3(256), 0, s, ws + p.L[k] + gf.interior,
                                (const float*)(ws + p.L[k + 1] + gc.interior), (int64_t)256 * T, h, w, gf.ts, gf.pitch, gc.ts, gc.pitch);
+            profile_end(ev, s);
             SS_LAUNCH_CHECK();
         }
         // the output conv runs once per clip: each clip's map goes to its own (usually zero-haloed) consumer volume

@@ -112,16 +112,20 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
         if (!needs_grid) p.axis[o] = 0;
         SS_CHECK_ARG(!needs_grid || (gt && gy && gx), "heads: grid vectors required for channel %d", o);
     }
+    void* ev = profile_begin(44, 4.0 * (double)p.V * (Cin + hs.n_out), s);
+    int rc;
     switch (hs.n_out) {
-        case 1: return launch_heads_n<1>(p, s);
-        case 2: return launch_heads_n<2>(p, s);
-        case 3: return launch_heads_n<3>(p, s);
-        case 4: return launch_heads_n<4>(p, s);
-        case 5: return launch_heads_n<5>(p, s);
-        case 6: return launch_heads_n<6>(p, s);
-        case 7: return launch_heads_n<7>(p, s);
-        default: return launch_heads_n<8>(p, s);
+        case 1: rc = launch_heads_n<1>(p, s); break;
+        case 2: rc = launch_heads_n<2>(p, s); break;
+        case 3: rc = launch_heads_n<3>(p, s); break;
+        case 4: rc = launch_heads_n<4>(p, s); break;
+        case 5: rc = launch_heads_n<5>(p, s); break;
+        case 6: rc = launch_heads_n<6>(p, s); break;
+        case 7: rc = launch_heads_n<7>(p, s); break;
+        default: rc = launch_heads_n<8>(p, s); break;
     }
+    profile_end(ev, s);
+    return rc;
 }
 
 }  // namespace stemseg

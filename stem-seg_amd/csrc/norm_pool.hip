@@ -91,7 +91,7 @@ struct GnApplyParams {
     int C, T, H, W, To, cpg;
 };
 
-// one thread per output element, x fastest (coalesced stores; the 27 pool reads hit L1/L2)
+// Scalar form, any destination layout: one thread per output element, x fastest.
 template <bool POOL>
 __global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p) {
     const int64_t HW = (int64_t)p.H * p.W;
@@ -135,13 +135,71 @@ __global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p
     }
 }
 
+// Streaming form of the un-pooled apply for dense destinations (block_4x -> its slice of the concat buffer: 106 MB in,
+// 106 MB out per decoder at 480p): grid.y = channel, 16-B loads and stores along the contiguous [T][H][W] run of the
+// channel, 32-bit indices, the (scale, shift) pair is uniform per workgroup.
+__global__ __launch_bounds__(256) void gn_relu_stream_kernel(const GnApplyParams p, unsigned n4) {
+    const int c = blockIdx.y, g = c / p.cpg;
+    const float a = p.stats[2 * g + 1] * p.gamma[c];
+    const float b = p.beta[c] - p.stats[2 * g] * a;
+    const float4* src = reinterpret_cast<const float4*>(p.x + (int64_t)c * p.T * p.H * p.W);
+    float4* dst = reinterpret_cast<float4*>(p.out + (int64_t)c * p.out_cs);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        float4 v = src[i];
+        v.x = fmaxf(fmaf(v.x, a, b), 0.f); v.y = fmaxf(fmaf(v.y, a, b), 0.f);
+        v.z = fmaxf(fmaf(v.z, a, b), 0.f); v.w = fmaxf(fmaf(v.w, a, b), 0.f);
+        dst[i] = v;
+    }
+}
+
+// Pooled apply, 4 outputs along x per thread: the 3 x 3 x 3 window of 4 neighbouring outputs is 9 rows of 6 inputs, each
+// normalised / rectified ONCE (the scalar form does it 27 times per output), then three-term row sums slide along x.
+// grid.y = (channel, pooled t); the destination may be dense or zero-haloed (scalar stores: its rows start at +1).
+__global__ __launch_bounds__(256) void gn_relu_pool4_kernel(const GnApplyParams p, unsigned wq, unsigned n_items) {
+    const unsigned item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= n_items) return;
+    const int c = blockIdx.y / p.To, to = blockIdx.y - c * p.To;
+    const int y = (int)(item / wq), x0 = (int)(item - (unsigned)y * wq) * 4;
+    const int g = c / p.cpg;
+    const float a = p.stats[2 * g + 1] * p.gamma[c];
+    const float b = p.beta[c] - p.stats[2 * g] * a;
+    const int HW = p.H * p.W;
+    const float* xc = p.x + (int64_t)c * p.T * HW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = -1; dt <= 1; ++dt) {
+        const int t = 2 * to + dt;
+        if (t < 0 || t >= p.T) continue;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= p.H) continue;
+            const float* row = xc + t * HW + yy * p.W;
+            float r[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int xx = x0 - 1 + k;
+                r[k] = (xx >= 0 && xx < p.W) ? fmaxf(fmaf(row[xx], a, b), 0.f) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += (r[j] + r[j + 1]) + r[j + 2];
+        }
+    }
+    float* o = p.out + (int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)y * p.out_ys + x0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (x0 + j < p.W) o[j] = acc[j] / 27.0f;
+}
+
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s) {
     SS_CHECK_ARG(x && stats && scratch, "groupnorm_stats: null pointer");
     SS_CHECK_ARG(groups > 0 && C % groups == 0 && S > 0, "groupnorm_stats: C=%d not divisible by groups=%d", C, groups);
     const int64_t ge = (int64_t)(C / groups) * S;
+    void* ev = profile_begin(41, 4.0 * (double)C * (double)S, s);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SPLIT, groups), dim3(256), 0, s, x, ge, scratch);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups), dim3(64), 0, s, (const double*)scratch, (double)ge, eps, stats);
+    profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
@@ -157,9 +215,23 @@ int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, 
     p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
     p.C = C; p.T = T; p.H = H; p.W = W; p.To = To; p.cpg = C / groups;
     const int64_t total = (int64_t)C * To * H * W;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
-    if (pool) hipLaunchKernelGGL(gn_relu_pool_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gn_relu_pool_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    const int64_t S = (int64_t)T * H * W;
+    const bool small = S < (1ll << 31) && total < (1ll << 40);      // 32-bit offsets inside a channel
+    void* ev = profile_begin(pool ? 43 : 42, 4.0 * ((double)C * S + (double)total), s);
+    if (pool && small && C * To <= 65535) {
+        const unsigned wq = (unsigned)ceil_div(W, 4), items = wq * (unsigned)H;
+        hipLaunchKernelGGL(gn_relu_pool4_kernel, dim3((unsigned)ceil_div(items, 256), (unsigned)(C * To)), dim3(256), 0, s, p, wq, items);
+    } else if (!pool && C <= 65535 && S % 4 == 0 && S / 4 < (1ll << 31) && out.t_stride == (int64_t)H * W && out.y_stride == W &&
+               out.c_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out.ptr) % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0)) {
+        const unsigned n4 = (unsigned)(S / 4);
+        const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n4, 256 * 4), 4096));   // ~4 float4 per thread
+        hipLaunchKernelGGL(gn_relu_stream_kernel, dim3(bx, (unsigned)C), dim3(256), 0, s, p, n4);
+    } else {
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+        if (pool) hipLaunchKernelGGL(gn_relu_pool_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gn_relu_pool_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    }
+    profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }

@@ -60,6 +60,56 @@ __global__ __launch_bounds__(256) void upsample_trilinear_kernel(const UpParams 
     }
 }
 
+// 16-B-store form for the x2 / x4 up-samplings of the path (decoder stages: (1|2, 2, 2); --resize_embeddings: (1, 4, 4)):
+// one thread = 4 consecutive outputs of one row.  For an integer x-scale SX the 4 outputs 4j .. 4j+3 read the inputs
+// j*4/SX - 1 .. (SX = 2: 2j-1 .. 2j+2, four of them; SX = 4: j-1 .. j+1, three), so each of the 4 source rows (t0|t1 x y0|y1)
+// is loaded ONCE into registers with clamped indices; the interpolation weights still come from src_index() and every
+// lerp keeps the contraction pattern of the scalar kernel, so the result is the same bit for bit (at the borders the
+// clamped neighbour enters with weight exactly 0 or duplicates the edge value, as in ATen).  grid.y = (channel, t_out):
+// 32-bit index math, one division per thread.
+template <int SX>
+__global__ __launch_bounds__(256) void upsample_vec4_kernel(const UpParams p, unsigned wq, unsigned n_items) {
+    static_assert(SX == 2 || SX == 4, "x scale 2 or 4");
+    const unsigned item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= n_items) return;
+    const int c = blockIdx.y / p.To, to = blockIdx.y - c * p.To;
+    const int yo = (int)(item / wq), j = (int)(item - (unsigned)yo * wq);
+    int t0, t1, y0, y1;
+    float wt, wy;
+    src_index(to, p.rt, p.T, t0, t1, wt);
+    src_index(yo, p.ry, p.H, y0, y1, wy);
+    const int HW = p.H * p.W;
+    const float* b = p.in + (int64_t)c * p.T * HW;
+    const float* rows[4] = {b + t0 * HW + y0 * p.W, b + t0 * HW + y1 * p.W, b + t1 * HW + y0 * p.W, b + t1 * HW + y1 * p.W};
+    constexpr int NV = SX == 2 ? 4 : 3;
+    const int xb = (SX == 2 ? 2 * j : j) - 1;                 // first input column this thread needs
+    float v[4][NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int xx = min(max(xb + k, 0), p.W - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r][k] = rows[r][xx];
+    }
+    const float ut = __fsub_rn(1.f, wt), uy = __fsub_rn(1.f, wy);
+    auto lerp = [](float a, float wa, float b2, float wb) { return __fmaf_rn(a, wa, __fmul_rn(b2, wb)); };
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x0, x1;
+        float wx;
+        src_index(4 * j + k, p.rx, p.W, x0, x1, wx);
+        const float ux = __fsub_rn(1.f, wx);
+        // position of x0 in v[]: SX = 2 -> outputs 0,1,2,3 start at 2j-1, 2j, 2j, 2j+1; SX = 4 -> j-1, j-1, j, j
+        constexpr int r2[4] = {0, 1, 1, 2}, r4[4] = {0, 0, 1, 1};
+        const int i0 = SX == 2 ? r2[k] : r4[k];
+        const float r00 = lerp(v[0][i0], ux, v[0][i0 + 1], wx), r01 = lerp(v[1][i0], ux, v[1][i0 + 1], wx);
+        const float r10 = lerp(v[2][i0], ux, v[2][i0 + 1], wx), r11 = lerp(v[3][i0], ux, v[3][i0 + 1], wx);
+        o[k] = lerp(lerp(r00, uy, r01, wy), ut, lerp(r10, uy, r11, wy), wt);
+    }
+    *reinterpret_cast<float4*>(p.out + (int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)yo * p.out_ys + 4 * j) =
+        make_float4(o[0], o[1], o[2], o[3]);
+}
+
 struct CopyParams {
     const float* in;
     float* out;
@@ -94,8 +144,20 @@ int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy,
     p.C = C; p.T = T; p.H = H; p.W = W; p.To = T * st; p.Ho = H * sy; p.Wo = W * sx;
     p.rt = 1.0f / (float)st; p.ry = 1.0f / (float)sy; p.rx = 1.0f / (float)sx;
     const int64_t total = (int64_t)C * p.To * p.Ho * p.Wo;
-    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(blocks), dim3(256), 0, s, p);
+    void* ev = profile_begin(40, 4.0 * ((double)C * T * H * W + (double)total), s);
+    const bool vec = (sx == 2 || sx == 4) && p.Wo % 4 == 0 && (int64_t)C * p.To <= 65535 && (int64_t)T * H * W < (1ll << 31) &&
+                     (int64_t)p.Ho * p.Wo < (1ll << 32) && (reinterpret_cast<uintptr_t>(out.ptr) % 16 == 0) && out.c_stride % 4 == 0 &&
+                     out.t_stride % 4 == 0 && out.y_stride % 4 == 0;
+    if (vec) {
+        const unsigned wq = (unsigned)(p.Wo / 4), items = wq * (unsigned)p.Ho;
+        const dim3 grid((unsigned)ceil_div(items, 256), (unsigned)(C * p.To));
+        if (sx == 2) hipLaunchKernelGGL(upsample_vec4_kernel<2>, grid, dim3(256), 0, s, p, wq, items);
+        else hipLaunchKernelGGL(upsample_vec4_kernel<4>, grid, dim3(256), 0, s, p, wq, items);
+    } else {
+        const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+        hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(blocks), dim3(256), 0, s, p);
+    }
+    profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }

@@ -166,8 +166,15 @@ def profile_enable(on):
     check(lib().stemseg_hip_profile_enable(int(on)))
 
 
-def profile_read(n_tags=32):
-    """{tag: (ms, flops, launches)} for the convolution launches since the last read (synchronises)."""
+# profiler tags: convolutions by tile class (work = FLOP) and the streaming kernels (work = algorithmic bytes)
+PROFILE_CONV_TAGS = {"conv3x3x3": (8, 4, 2), "conv1x3x3": (28, 24, 22), "conv1x1x1": (18, 14, 16, 12)}
+PROFILE_HBM_TAGS = {40: "upsample_trilinear", 41: "gn_stats (partial + finalize)", 42: "gn_relu (apply)", 43: "gn_relu_pool (apply + AvgPool3d)",
+                    44: "heads", 45: "fg_gather (count + scan + scatter)", 46: "cluster (all rounds + final)", 47: "stem_conv7x7",
+                    48: "maxpool3x3s2", 49: "subsample2", 50: "upsample2x_add (FPN top-down)"}
+
+
+def profile_read(n_tags=64):
+    """{tag: (ms, work, launches)} for the tagged launches since the last read (synchronises)."""
     buf = (C.c_double * (3 * n_tags))()
     check(lib().stemseg_hip_profile_read(buf, n_tags))
     return {t: (buf[3 * t], buf[3 * t + 1], int(buf[3 * t + 2])) for t in range(n_tags) if buf[3 * t + 2] > 0}

@@ -61,6 +61,12 @@ class ClipPipeline(object):
         return outs
 
     @torch.no_grad()
+    def capture_embed(self, example_frames, lane=0):
+        """hipGraph of ``embed`` alone (encoder + decoders + heads of one clip): for drivers that cluster later, e.g. the sharded
+        sequence path, where clustering waits for the cross-clip foreground mask.  ``run`` returns static (emb, bw, seed)
+        tensors that the next replay overwrites."""
+        return GraphedStep(self, example_frames, False, None, lane, embed_only=True)
+
     def capture(self, example_frames, overlap=False, n_clips=None, lane=0):
         """Capture ``step`` for clips of ``example_frames``' shape into ONE hipGraph (~330 kernel nodes on a single stream:
         measured, the decoders' fork/join branch streams buy nothing once every conv fills the chip, and single-stream
@@ -73,12 +79,14 @@ class ClipPipeline(object):
 
 
 class GraphedStep(object):
-    def __init__(self, pipe, example_frames, overlap=False, n_clips=None, lane=0):
+    def __init__(self, pipe, example_frames, overlap=False, n_clips=None, lane=0, embed_only=False):
         self.pipe = pipe
         self.lane = lane
         self.stream = torch.cuda.Stream(device=example_frames.device)       # replays of this lane are ordered on this stream
         pipe.model.set_lane(lane)
         fn = pipe.step if n_clips is None else (lambda x: pipe.step_batch(x, n_clips))     # n_clips: ``run`` returns a list
+        if embed_only:
+            fn = pipe.embed
         prev = pipe.model.overlap_decoders
         pipe.model.overlap_decoders = bool(overlap)       # True = capture the fork/join branch streams too (experimental)
         try:
@@ -126,9 +134,12 @@ def shard_clips(n_clips, rank, world_size):
 
 @torch.no_grad()
 def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
-                         fg_mask_fn=None, group=None):
+                         fg_mask_fn=None, group=None, stats=None):
     """embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w], seed [1,T,h,w]) on this rank's device.
-    Returns OnlineChainer.process(...) output, identical on every rank."""
+    Returns OnlineChainer.process(...) output, identical on every rank.  ``stats`` (dict, optional) receives the exchange's
+    size and duration: ``allgather_bytes`` (payload received per rank), ``allgather_ms`` (device time of the collective on
+    this rank), ``n_clips``, ``clips_this_rank``."""
+    import time
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if distributed else 0
@@ -137,35 +148,44 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     mine = shard_clips(len(clips), rank, world)
     per_rank = (len(clips) + world - 1) // world
     packed = None
-    outs = {}
+    E = Ev = None
     for slot, ci in enumerate(mine):
         emb, bw, seed = embed_clip_fn(clips[ci])
-        blk = torch.cat([emb, bw, seed], 0)                         # [E+Ev+1, T, h, w]
         if packed is None:
-            packed = torch.zeros((per_rank,) + tuple(blk.shape), dtype=blk.dtype, device=blk.device)
-        packed[slot] = blk
-        outs[ci] = (emb.shape[0], bw.shape[0])
+            E, Ev = emb.shape[0], bw.shape[0]
+            packed = torch.zeros((per_rank, E + Ev + seed.shape[0]) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device)
+        packed[slot, :E], packed[slot, E:E + Ev], packed[slot, E + Ev:] = emb, bw, seed
+    ag_ms, ag_bytes = 0.0, 0
     if distributed and world > 1:
-        # every rank owns >= 1 clip whenever len(clips) >= world; otherwise learn the block shape from rank 0
-        shape = torch.tensor(list(packed.shape) if packed is not None else [0] * 5, dtype=torch.int64,
-                             device=packed.device if packed is not None else _default_device())
-        shapes = [torch.zeros_like(shape) for _ in range(world)]
-        dist.all_gather(shapes, shape, group=group)
-        full = next(s for s in shapes if int(s[0]) > 0).tolist()
-        if packed is None:
-            packed = torch.zeros(full, dtype=torch.float32, device=shape.device)
+        if len(clips) < world:
+            # some ranks own no clip: they learn the block shape and the channel split from the others (tiny exchange)
+            dev = packed.device if packed is not None else _default_device()
+            info = torch.tensor((list(packed.shape) + [E, Ev]) if packed is not None else [0] * 7, dtype=torch.int64, device=dev)
+            infos = [torch.zeros_like(info) for _ in range(world)]
+            dist.all_gather(infos, info, group=group)
+            full = next(i for i in infos if int(i[0]) > 0).tolist()
+            E, Ev = int(full[5]), int(full[6])
+            if packed is None:
+                packed = torch.zeros(full[:5], dtype=torch.float32, device=dev)
         gathered = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(gathered, packed.contiguous(), group=group)   # the one data-path collective
+        on_gpu = packed.is_cuda
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        else:
+            t0 = time.perf_counter()
+        dist.all_gather(gathered, packed.contiguous(), group=group)     # THE data-path collective (RCCL over xGMI on the box)
+        if on_gpu:
+            e1.record()
+            e1.synchronize()
+            ag_ms = e0.elapsed_time(e1)
+        else:
+            ag_ms = 1e3 * (time.perf_counter() - t0)
+        ag_bytes = packed.numel() * packed.element_size() * (world - 1)
     else:
         gathered = [packed]
-    E = Ev = None
-    for v in outs.values():
-        E, Ev = v
-    if distributed and world > 1:
-        dims = torch.tensor([E or 0, Ev or 0], dtype=torch.int64, device=packed.device)
-        all_dims = [torch.zeros_like(dims) for _ in range(world)]
-        dist.all_gather(all_dims, dims, group=group)
-        E, Ev = next((int(d[0]), int(d[1])) for d in all_dims if int(d[0]) > 0)
+    if stats is not None:
+        stats.update(allgather_ms=ag_ms, allgather_bytes=ag_bytes, n_clips=len(clips), clips_this_rank=len(mine), world=world)
     entries = []
     for ci, frames in enumerate(clips):
         blk = gathered[ci % world][ci // world]

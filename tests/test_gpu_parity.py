@@ -305,7 +305,7 @@ def test_gn_relu_pool(hip, pool, shape):
 
 
 @pytest.mark.parametrize("scale", [(1, 2, 2), (2, 2, 2), (1, 4, 4)])
-@pytest.mark.parametrize("shape", [(16, 2, 3, 5), (7, 4, 15, 27), (3, 1, 1, 1)])
+@pytest.mark.parametrize("shape", [(16, 2, 3, 5), (7, 4, 15, 27), (3, 1, 1, 1), (5, 3, 6, 8), (4, 2, 15, 54), (3, 2, 5, 2), (2, 1, 4, 6)])
 def test_upsample_trilinear(hip, scale, shape):
     x = _rand(shape, 10)
     ref = F.interpolate(torch.from_numpy(x)[None], scale_factor=tuple(float(s) for s in scale), mode="trilinear", align_corners=False)[0].numpy()
@@ -314,6 +314,11 @@ def test_upsample_trilinear(hip, scale, shape):
     # same products and sums in the same order as ATen's CPU kernel, none fused: bit-identical (what keeps the clusterer's
     # arg-max stable after --resize_embeddings)
     assert np.array_equal(got, ref), "%d of %d values differ in the last bits" % ((got != ref).sum(), got.size)
+    # into a channel slice of a wider (concat) buffer, as the decoder does: same values, neighbours untouched
+    C, T, H, W = shape
+    cat = torch.zeros(C + 3, T * scale[0], H * scale[1], W * scale[2], device="cuda")
+    hip.upsample_trilinear(dev(x), *scale, vout=hip.dense_volume(cat[3:]))
+    assert np.array_equal(cat[3:].cpu().numpy(), ref) and float(cat[:3].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("layout", [0, 1])
