@@ -69,10 +69,16 @@ struct ConvKParams {
 // instead of ROWS x 32 columns: a tap is the flat offset dy * pitch + dx, so maps whose width is not a multiple of 32
 // (W = 54: 64 columns computed for 54; flat: 56 for 54) lose almost nothing to tile quantisation.  Junk positions (halo
 // columns) are computed and not stored.  fp32 only, scalar epilogue.
+// GL (with DB): the next chunk goes global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, LDS image
+// lane-linear = exactly the [piece] order of the staging loops), issued before the chunk's MFMA stream and retired by the
+// vmcnt(0) in front of the chunk's one barrier: no staging registers (-40 VGPRs on the big tile), no ds_write pass between
+// the MFMA stream and the barrier.  Out-of-range pieces (tile columns past the row end, the run before the plane's first
+// row) are fetched from a clamped in-bounds address instead of being zero-filled: they only feed positions that are never
+// stored.  Needs Cin % CK == 0 and Cout % MT == 0 (the launcher falls back to the register-staged twin otherwise).
 template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false, bool DB_ = false,
-          int PMAX_ = 0>
+          int PMAX_ = 0, bool GL_ = false>
 struct ConvCfg {
-    static constexpr bool PIPE = PIPE_, BF = BF_, DB = DB_, FLAT = PMAX_ > 0;
+    static constexpr bool PIPE = PIPE_, BF = BF_, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
     static constexpr int PMAX = PMAX_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
@@ -99,7 +105,8 @@ struct ConvCfg {
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
     static_assert(CK % 4 == 0 || (DB && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (DB)");
     static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
-    static_assert(!FLAT || (!BF && !DB && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: fp32 3x3 taps only");
+    static_assert(!FLAT || (!BF && (!DB || GL) && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: fp32 3x3 taps only");
+    static_assert(!GL || (DB && !BF), "direct-to-LDS staging is the double-buffered fp32 form");
 };
 
 template <class C>
@@ -224,6 +231,51 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
         if (ch < p.Cin && co0 + mq * 4 < p.Cout) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * p.Cout + mq * 4);
         return v;
     };
+    // GL: source address of piece q (same decomposition as fetch_in / fetch_w), clamped into the volume
+    auto addr_in = [&](int c0, int q) -> const float* {
+        int64_t rel;
+        if constexpr (C::FLAT) {
+            constexpr int FQ = C::FL / 4;
+            const int j4 = q % FQ, rr = q / FQ, dt = rr % C::KT, c = rr / C::KT;
+            const int f = max(F0 - pitch - 4 + 4 * j4, 0);
+            rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + f;
+        } else {
+            const int xq = q % XQ;
+            int rr = q / XQ;
+            const int r = rr % C::RH;
+            rr /= C::RH;
+            const int dt = rr % C::KT;
+            const int c = rr / C::KT;
+            const int yy = min(y0 + r, p.in_H - 1);
+            rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xq * 4;
+        }
+        const int64_t last = p.in_limit - 4 - tile_base;      // last 16-B piece inside the volume, relative to in_tile
+        return in_tile + (rel < last ? rel : last);
+    };
+    auto addr_w = [&](int c0, int q) -> const float* {
+        const int mq = q % MQ;
+        if constexpr (C::CK == 2) {
+            const int row2 = q / MQ, tap = row2 >> 1, e = row2 & 1;
+            return p.wpk + ((int64_t)(c0 / 4) * (C::TAPS * 4) + tap * 4 + ((c0 >> 1) & 1) * 2 + e) * p.Cout + co0 + mq * 4;
+        } else {
+            const int row = q / MQ;
+            return p.wpk + (int64_t)(c0 / 4) * (C::TAPS * 4) * p.Cout + co0 + (int64_t)row * p.Cout + mq * 4;
+        }
+    };
+    auto glds_chunk = [&](int c0, const int off) {            // enqueue the whole chunk c0 into the buffer at float offset `off`
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+        for (int k = 0; k < IN_PT; ++k) {
+            const int q = tid + k * C::NTHREADS;
+            if (q < NQ) __builtin_amdgcn_global_load_lds((gptr_t)addr_in(c0, q), (lptr_t)(in_lds + off + (q - lane) * 4), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < W_PT; ++k) {
+            const int q = tid + k * C::NTHREADS;
+            if (q < NWQ) __builtin_amdgcn_global_load_lds((gptr_t)addr_w(c0, q), (lptr_t)(w_lds + off + (q - lane) * 4), 16, 0, 0);
+        }
+    };
     auto stage_direct = [&](int c0) {                         // global -> LDS, no overlap (scalar fallback for odd strides)
         if (p.vec4) {
             for (int q = tid; q < NQ; q += C::NTHREADS) *reinterpret_cast<float4*>(in_lds + q * 4) = fetch_in(c0, q);
@@ -309,7 +361,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
             for (int mi = 0; mi < C::MI; ++mi) a[mi] = a_ptr[buf_off + wrow * C::MT + mi * 32];
 #pragma unroll
             for (int ni = 0; ni < C::NI; ++ni) {
-                if constexpr (C::FLAT) b[ni] = bdy[ni][dy][boff];
+                if constexpr (C::FLAT) b[ni] = bdy[ni][dy][buf_off + boff];
                 else b[ni] = b_ptr[ni][buf_off + boff];
             }
         };
@@ -339,7 +391,21 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 
     const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
     const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
-    if constexpr (C::DB) {
+    if constexpr (C::DB && C::GL) {
+        // double-buffered LDS filled by LDS-DMA: chunk i+1 is enqueued into the idle buffer, chunk i's MFMA stream runs, and
+        // the __syncthreads() that ends the chunk carries the vmcnt(0) that retires the DMA (the compiler puts no wait in
+        // front of the ds_reads: checked in the ISA) -- one barrier per chunk, nothing between the last MFMA and the barrier
+        if (c_begin < c_end) glds_chunk(c_begin, 0);
+        __syncthreads();
+        int cur = 0;
+        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
+            if (c0 + C::CK < c_end) glds_chunk(c0 + C::CK, C::BUF_FLOATS - cur);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            cur = C::BUF_FLOATS - cur;
+            __syncthreads();
+        }
+    } else if constexpr (C::DB) {
         // double-buffered LDS (launcher guarantees vec4): prefetch chunk i+1 into registers, run chunk i's MFMA stream from
         // buffer i % 2, write the registers to the other buffer, ONE barrier per chunk
         float4 rin[IN_PT], rw[W_PT];
@@ -642,6 +708,23 @@ using K2FlatMed56 = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, false, false, 56>;
 using K3FlatMed56 = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 56>;
 using K3FlatSmall56 = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 56>;
 
+// direct-to-LDS twins (double-buffered, half the channel chunk so the two buffers fit the same LDS budget as the register-
+// staged form they replace); STEMSEG_GLDS is a bit mask: 1 = big 3x3x3 tile, 2 = other 3x3x3 tiles, 4 = 1x3x3 tiles (0 = off)
+using K3BigGL = ConvCfg<3, 3, 3, 2, 4, 2, 1, 4, 1, false, false, true, 0, true>;
+using K3MedGL = ConvCfg<3, 3, 3, 2, 2, 2, 2, 2, 1, false, false, true, 0, true>;
+using K3SmallGL = ConvCfg<3, 3, 3, 2, 2, 1, 2, 2, 1, false, false, true, 0, true>;
+using K3FlatMedGL = ConvCfg<3, 3, 3, 2, 2, 2, 2, 2, 4, false, false, true, 112, true>;
+using K3FlatSmallGL = ConvCfg<3, 3, 3, 2, 2, 1, 2, 2, 2, false, false, true, 112, true>;
+using K3FlatMed56GL = ConvCfg<3, 3, 3, 2, 2, 2, 2, 2, 4, false, false, true, 56, true>;
+using K3FlatSmall56GL = ConvCfg<3, 3, 3, 2, 2, 1, 2, 2, 2, false, false, true, 56, true>;
+using K2BigGL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 1, false, false, true, 0, true>;
+using K2MedGL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 1, false, false, true, 0, true>;
+using K2SmallGL = ConvCfg<1, 3, 3, 4, 2, 1, 2, 2, 1, false, false, true, 0, true>;
+using K2FlatBigGL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 8, false, false, true, 112, true>;
+using K2FlatMedGL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 4, false, false, true, 112, true>;
+using K2FlatBig56GL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 8, false, false, true, 56, true>;
+using K2FlatMed56GL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 4, false, false, true, 56, true>;
+
 // bf16x3 twins of the tile shapes (register prefetch only where the wider fragments still fit 256 VGPRs)
 using X3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, true>;
 using X3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true, true>;
@@ -657,6 +740,9 @@ using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 // sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
 // MFMA peak)
 constexpr double CU_FLOPS_F32 = 0.46e12;
+#ifndef STEMSEG_GLDS_DEFAULT
+#define STEMSEG_GLDS_DEFAULT 0
+#endif
 
 template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0) {
@@ -808,6 +894,17 @@ static bool prefer_flat(const ConvKParams& p, int tile_cfg, bool bf) {
     return tile_efficiency<Flat>(p) > 1.08 * tile_efficiency<Tile2D>(p);
 }
 
+static int glds_mask() {
+    static const int m = [] { const char* e = getenv("STEMSEG_GLDS"); return e ? atoi(e) : STEMSEG_GLDS_DEFAULT; }();
+    return m;
+}
+// GL twin when its class is switched on and the launch meets its contract, else the register-staged form
+template <class GLCfg, class Cfg>
+static int launch_gl(int bit, const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats) {
+    if ((glds_mask() & bit) && p.vec4 && p.Cin % GLCfg::CK == 0 && p.Cout % GLCfg::MT == 0) return launch_cfg<GLCfg>(p, s, scratch, scratch_floats);
+    return launch_cfg<Cfg>(p, s, scratch, scratch_floats);
+}
+
 template <class C>
 static int64_t num_workgroups(int Cout, int T, int H, int W) {
     return ceil_div(W, C::COLS * 32) * ceil_div(H, C::ROWS) * T * ceil_div(Cout, C::MT);
@@ -858,10 +955,10 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K3Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
             else cfg = 3;
         }
-        if (cfg == 2 && prefer_flat<K3FlatMed56, K3Med>(p, tile_cfg, bf)) return launch_cfg<K3FlatMed56>(p, s, scratch, scratch_floats);
-        if (cfg == 3 && prefer_flat<K3FlatSmall56, K3Small>(p, tile_cfg, bf)) return launch_cfg<K3FlatSmall56>(p, s, scratch, scratch_floats);
-        if (cfg == 2 && prefer_flat<K3FlatMed, K3Med>(p, tile_cfg, bf)) return launch_cfg<K3FlatMed>(p, s, scratch, scratch_floats);
-        if (cfg == 3 && prefer_flat<K3FlatSmall, K3Small>(p, tile_cfg, bf)) return launch_cfg<K3FlatSmall>(p, s, scratch, scratch_floats);
+        if (cfg == 2 && prefer_flat<K3FlatMed56, K3Med>(p, tile_cfg, bf)) return launch_gl<K3FlatMed56GL, K3FlatMed56>(2, p, s, scratch, scratch_floats);
+        if (cfg == 3 && prefer_flat<K3FlatSmall56, K3Small>(p, tile_cfg, bf)) return launch_gl<K3FlatSmall56GL, K3FlatSmall56>(2, p, s, scratch, scratch_floats);
+        if (cfg == 2 && prefer_flat<K3FlatMed, K3Med>(p, tile_cfg, bf)) return launch_gl<K3FlatMedGL, K3FlatMed>(2, p, s, scratch, scratch_floats);
+        if (cfg == 3 && prefer_flat<K3FlatSmall, K3Small>(p, tile_cfg, bf)) return launch_gl<K3FlatSmallGL, K3FlatSmall>(2, p, s, scratch, scratch_floats);
         if (bf) {
             if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);   // (row balancing measured slower here)
             if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
@@ -870,14 +967,18 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         // the big tile runs double-buffered (measured 4.06 -> 3.66 ms on block_4x); STEMSEG_K3_DB=0 selects the single-buffer
         // form for A/B measurements
         static const bool use_db = [] { const char* e = getenv("STEMSEG_K3_DB"); return !(e && e[0] == '0'); }();
+        if (cfg == 1 && (glds_mask() & 1) && p.vec4 && p.Cin % 2 == 0 && p.Cout % 128 == 0) {
+            if (tile_cfg <= 0 || tile_cfg > 3) return launch_planned<K3BigGL, K3Med>(p, s, scratch, scratch_floats, 2, 2);
+            return launch_cfg<K3BigGL>(p, s, scratch, scratch_floats);
+        }
         if (cfg == 1 && use_db && p.vec4) {
             if (tile_cfg <= 0 || tile_cfg > 3) return launch_planned<K3BigDB, K3Med>(p, s, scratch, scratch_floats, 2, 2);
             return launch_cfg<K3BigDB>(p, s, scratch, scratch_floats);
         }
         if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<K3Big, K3Med>(p, s, scratch, scratch_floats, 2, 2);
         if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
-        if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats);
-        return launch_cfg<K3Small>(p, s, scratch, scratch_floats);
+        if (cfg == 2) return launch_gl<K3MedGL, K3Med>(2, p, s, scratch, scratch_floats);
+        return launch_gl<K3SmallGL, K3Small>(2, p, s, scratch, scratch_floats);
     }
     if (k2) {
         if (p.Cout <= 64) return bf ? launch_cfg<X2M64>(p, s, scratch, scratch_floats) : launch_cfg<K2M64>(p, s, scratch, scratch_floats);
@@ -888,20 +989,21 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= need) cfg = 2;
             else cfg = 3;
         }
-        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg, bf)) return launch_cfg<K2FlatBig56>(p, s, scratch, scratch_floats);
-        if (cfg >= 2 && prefer_flat<K2FlatMed56, K2Med>(p, tile_cfg, bf)) return launch_cfg<K2FlatMed56>(p, s, scratch, scratch_floats);
-        if (cfg == 1 && prefer_flat<K2FlatBig, K2Big>(p, tile_cfg, bf)) return launch_cfg<K2FlatBig>(p, s, scratch, scratch_floats);
-        if (cfg >= 2 && prefer_flat<K2FlatMed, K2Med>(p, tile_cfg, bf)) return launch_cfg<K2FlatMed>(p, s, scratch, scratch_floats);
+        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg, bf)) return launch_gl<K2FlatBig56GL, K2FlatBig56>(4, p, s, scratch, scratch_floats);
+        if (cfg >= 2 && prefer_flat<K2FlatMed56, K2Med>(p, tile_cfg, bf)) return launch_gl<K2FlatMed56GL, K2FlatMed56>(4, p, s, scratch, scratch_floats);
+        if (cfg == 1 && prefer_flat<K2FlatBig, K2Big>(p, tile_cfg, bf)) return launch_gl<K2FlatBigGL, K2FlatBig>(4, p, s, scratch, scratch_floats);
+        if (cfg >= 2 && prefer_flat<K2FlatMed, K2Med>(p, tile_cfg, bf)) return launch_gl<K2FlatMedGL, K2FlatMed>(4, p, s, scratch, scratch_floats);
         if (bf) {
             if (cfg == 1) return launch_cfg<X2Big>(p, s, scratch, scratch_floats);
             if (cfg == 2) return launch_cfg<X2Med>(p, s, scratch, scratch_floats);
             return launch_cfg<X2Small>(p, s, scratch, scratch_floats);
         }
+        const bool gl2 = (glds_mask() & 4) && p.vec4 && p.Cin % 4 == 0 && p.Cout % 128 == 0;
         if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= 512)
-            return launch_planned<K2Big, K2Med>(p, s, scratch, scratch_floats, 3, 3);
-        if (cfg == 1) return launch_cfg<K2Big>(p, s, scratch, scratch_floats);
-        if (cfg == 2) return launch_cfg<K2Med>(p, s, scratch, scratch_floats);
-        return launch_cfg<K2Small>(p, s, scratch, scratch_floats);
+            return gl2 ? launch_planned<K2BigGL, K2MedGL>(p, s, scratch, scratch_floats, 3, 3) : launch_planned<K2Big, K2Med>(p, s, scratch, scratch_floats, 3, 3);
+        if (cfg == 1) return launch_gl<K2BigGL, K2Big>(4, p, s, scratch, scratch_floats);
+        if (cfg == 2) return launch_gl<K2MedGL, K2Med>(4, p, s, scratch, scratch_floats);
+        return launch_gl<K2SmallGL, K2Small>(4, p, s, scratch, scratch_floats);
     }
     if (p.Cout <= 64) return bf ? launch_cfg<X1M64>(p, s, scratch, scratch_floats) : launch_cfg<K1M64>(p, s, scratch, scratch_floats);
     int cfg = tile_cfg;
