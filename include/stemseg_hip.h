@@ -109,6 +109,18 @@ int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const flo
                        int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
                        int64_t splitk_scratch_floats, const StemsegConvEpilogue* epilogue, void* stream);
 
+/* Convolution + the GroupNorm statistics of its output in ONE pass (embedding_decoder.py:21-23: Conv3d followed by
+ * GroupNorm): the conv's epilogue -- or, for split-K launches, its reduce kernel -- leaves per-tile fp64 partial sums in
+ * gn_scratch (>= stemseg_hip_conv3d_gn_scratch_doubles(Cout, groups) doubles) and one small launch combines them in fixed
+ * order (no atomics: bit-identical run to run) into stats[2g] = mean, stats[2g+1] = 1/sqrt(biased_var + eps), so the
+ * conv output is not read again for the statistics.  Plain bias epilogue only; groups of 4 or 8 channels take the fused
+ * path, any other group size runs stemseg_hip_conv3d + stemseg_hip_groupnorm_stats (dense `out` required then). */
+int64_t stemseg_hip_conv3d_gn_scratch_doubles(int32_t Cout, int32_t groups);
+int stemseg_hip_conv3d_gn(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
+                          int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch,
+                          int64_t splitk_scratch_floats, int32_t precision, int32_t groups, float eps,
+                          float* stats, double* gn_scratch, void* stream);
+
 /* GroupNorm statistics over a dense [C][S] tensor (S = T*H*W), `groups` contiguous channel groups:
  * stats[2g] = mean, stats[2g+1] = 1/sqrt(biased_var + eps).  scratch: >= groups*128 doubles. */
 int stemseg_hip_groupnorm_stats(const float* x, int32_t C, int64_t S, int32_t groups, float eps,

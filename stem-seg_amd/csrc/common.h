@@ -81,11 +81,24 @@ struct ConvEpilogue {            // fused into the conv epilogue (or the split-K
     int64_t res_cs = 0, res_ts = 0, res_ys = 0;
     int dec_H = 0, dec_W = 0;    // > 0: 1x1x1 conv launched on a flat [C][V] input; voxel v -> (v / (H*W), (v / W) % H, v % W)
     int precision = 0;           // 0: exact fp32 MFMA; 1: bf16x3 split (weights must be packed with ..._bf16x3)
+    // GroupNorm statistics of the output in the same pass (decoder stages): see launch_conv3d_gn
+    double* gn_part = nullptr;   // [Cout / gn_cpg][gn_cap][2] partial (sum, sum of squares) table
+    int gn_cpg = 0, gn_cap = 0;
+    int* gn_used = nullptr;      // host counter: slots filled by this conv's launches
 };
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0,
                   const ConvEpilogue* epi = nullptr);
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s);
+// conv + GroupNorm statistics of its output in one pass: the conv's epilogue (or its split-K reduce) leaves per-tile partial
+// sums in `gn_scratch` (>= gn_scratch_doubles(Cout, groups) doubles), one more tiny launch turns them into stats[2g] = mean,
+// stats[2g+1] = rstd.  Falls back to conv + launch_gn_stats when the group size is not 4 or 8 channels.
+constexpr int GN_SLOT_CAP = 4096;
+static inline int64_t gn_scratch_doubles(int Cout, int groups) { return (int64_t)groups * GN_SLOT_CAP * 2 > (int64_t)groups * 128 ? (int64_t)groups * GN_SLOT_CAP * 2 : (int64_t)groups * 128; }
+int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
+                     int tile_cfg, hipStream_t s, float* splitk_scratch, int64_t splitk_scratch_floats, const ConvEpilogue* epi, int groups,
+                     float eps, float* stats, double* gn_scratch);
+int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s);
 int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
                         const float* beta, int pool, const StemsegVolume& out, hipStream_t s);
 int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy, int sx, const StemsegVolume& out,

@@ -57,6 +57,11 @@ struct ConvKParams {
     int vec_epi;                 // 16-B epilogue through an LDS transpose (dense, aligned outputs only)
     int t_fastest;               // tile order: t-planes of one (x, y) tile are neighbours in launch order (3-D taps)
     int n_co;                    // output-channel tiles (Cout / MT), the fastest-running part of the workgroup index
+    // GroupNorm statistics of the output, taken in the epilogue (decoder stages): per (group, slot) partial sum / sum of squares
+    // in fp64, one slot per tile (or per reduce block under split-K), combined in fixed order by gn_finalize_slots_kernel
+    double* gn_part;             // [Cout / gn_cpg][gn_cap][2] or NULL
+    int gn_cpg, gn_cap, gn_slot0;
+    int* gn_used_host;           // host-side slot counter of the current conv (never dereferenced on the device)
 };
 
 // bf16x3 ("3xBF16") mode: every fp32 operand x is split as x = hi + lo (+ residual <= 2^-18 |x|) with hi, lo bf16, and
@@ -107,10 +112,13 @@ struct ConvCfg {
     static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
     static_assert(!FLAT || (!BF && (!DB || GL) && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: fp32 3x3 taps only");
     static_assert(!GL || (DB && !BF), "direct-to-LDS staging is the double-buffered fp32 form");
+    // workgroups per CU the register allocator must leave room for: the GL forms carry no staging registers, so the tiles whose
+    // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
+    static constexpr int MIN_WG = (GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2;
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKParams p) {
+__global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(const ConvKParams p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
     float* const in_lds = smem;
     float* const w_lds = smem + C::IN_FLOATS;
@@ -479,6 +487,74 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
 
     // ---- epilogue: C/D layout col = lane&31 (voxel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel) ----
     const int co_base = co0 + wm * (C::MI * 32);
+    if (p.gn_part) {
+        // GroupNorm statistics of this tile's (acc + bias): a group of 8 channels is the rows (r>>2 fixed) of both lane halves,
+        // a group of 4 channels the rows of one half -- fp32 over a lane's <= 4 * NI values, fp64 from there on: lanes (xor
+        // butterfly, fixed order), the WN waves that share the channels (LDS, fixed order), then ONE slot of the global
+        // [group][slot] table per tile.  No atomics anywhere: bit-identical run to run.
+        __syncthreads();                                       // the staged tiles are dead: their LDS is reused below
+        constexpr int GPW8 = C::MI * 4;                        // 8-channel groups per wave (x2 for 4-channel groups)
+        double* red = reinterpret_cast<double*>(smem + 4 * 32 * 36);          // behind the epilogue's transpose buffers
+        static_assert(4 * 32 * 36 + 2 * C::WM * C::WN * GPW8 * 2 * 2 <= C::LDS_FLOATS, "GN partial sums must fit the staging LDS");
+        const bool g4 = p.gn_cpg == 4;
+        bool ok[C::NI];
+#pragma unroll
+        for (int ni = 0; ni < C::NI; ++ni) {
+            const int sN = wn * C::NI + ni;
+            int y = y0 + sN / C::COLS, x = x0 + (sN % C::COLS) * 32 + l31;
+            if constexpr (C::FLAT) {
+                const int f = F0 + sN * 32 + l31, y1 = f / pitch, x1 = f - y1 * pitch;
+                y = y1 - 1;
+                x = (x1 >= 1) ? x1 - 1 : p.W;
+            }
+            ok[ni] = y < p.H && x < p.W;
+        }
+#pragma unroll
+        for (int mi = 0; mi < C::MI; ++mi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float fs = 0.f, fss = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int co = co_base + mi * 32 + rr + 8 * j + 4 * half;
+                    const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < C::NI; ++ni)
+                        if (ok[ni]) {
+                            const float v = acc[mi][ni][4 * j + rr] + bv;
+                            fs += v;
+                            fss += v * v;
+                        }
+                }
+                double ds = (double)fs, dss = (double)fss;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
+                if (!g4) { ds += __shfl_xor(ds, 32, 64); dss += __shfl_xor(dss, 32, 64); }
+                if (l31 == 0 && (g4 || half == 0)) {
+                    const int gl = g4 ? (mi * 4 + j) * 2 + half : mi * 4 + j;          // group within this wave's channel block
+                    const int gpw = g4 ? 2 * GPW8 : GPW8;
+                    double* d = red + ((size_t)(wm * gpw + gl) * C::WN + wn) * 2;
+                    d[0] = ds; d[1] = dss;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int gpw = g4 ? 2 * GPW8 : GPW8, ngw = C::WM * gpw;           // groups of this workgroup's MT channels
+            if (tid < ngw) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int k = 0; k < C::WN; ++k) { a += red[((size_t)tid * C::WN + k) * 2]; b += red[((size_t)tid * C::WN + k) * 2 + 1]; }
+                const int gg = co0 / p.gn_cpg + tid;
+                if (gg * p.gn_cpg < p.Cout) {
+                    const int slot = p.gn_slot0 + (t * p.tiles_y + ty) * p.tiles_x + tx;
+                    double* o = p.gn_part + ((size_t)gg * p.gn_cap + slot) * 2;
+                    o[0] = a; o[1] = b;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (p.vec_epi && !C::FLAT) {
         // 16-B stores: each wave transposes its 32x32 accumulator tiles through LDS so that a lane owns 4 consecutive
         // voxels of one channel (the MFMA layout gives it 16 channels of ONE voxel -> 4-B stores, 4x the instructions)
@@ -494,7 +570,7 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void conv_igemm_kernel(const ConvKP
             // residual and bias of two 32-channel sub-tiles at a time are requested up front: otherwise each of the loads
             // below is waited for on its own, right where it is used, and the epilogue of a short-K conv becomes a chain of
             // HBM latencies
-            constexpr int MG = C::MI >= 2 ? 2 : 1;
+            constexpr int MG = (C::MI >= 2 && C::MIN_WG < 3) ? 2 : 1;      // (3 workgroups per CU: 168 VGPRs, one sub-tile at a time)
 #pragma unroll
             for (int m0 = 0; m0 < C::MI; m0 += MG) {
                 float4 rres[MG][4];
@@ -590,43 +666,66 @@ struct SplitReduceParams {
     int64_t out_cs, out_ts, out_ys, res_cs, res_ts, res_ys, slab;
     int C, H, W, ksplit, relu;     // (H, W): how to split the flat voxel index into (t, y, x)
     int64_t V;
-    unsigned n_items;              // threads needed: C * V / (4 or 1)
+    unsigned per_c;                // threads needed per channel: V / (4 or 1)
+    double* gn_part;               // GroupNorm partial sums of the reduced output (see ConvKParams), or NULL
+    int gn_cpg, gn_cap, gn_slot0;
 };
-// One thread per output float4 (VEC: W % 4 == 0 and 16-B aligned output / residual rows) or per output float; the index
-// is decomposed with 32-bit divisions once per thread.  Partial slabs are dense [C][T][H][W], so their reads are coalesced
-// 16-B loads in the VEC form.
+// grid = (blocks per channel, channels).  One thread per output float4 (VEC: W % 4 == 0 and 16-B aligned output / residual
+// rows) or per output float; 32-bit index math.  Partial slabs are dense [C][T][H][W], so their reads are coalesced 16-B
+// loads in the VEC form.  With gn_part every block also leaves the (sum, sum of squares) of the values it wrote in its own
+// slot (gn_slot0 + (c % cpg) * gridDim.x + blockIdx.x) of the channel's group -- fixed-order tree, no atomics.
 template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReduceParams p) {
     constexpr int VW = VEC ? 4 : 1;
     const unsigned wq = (unsigned)p.W / VW;
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
-    if (idx >= p.n_items) return;
-    const unsigned row = idx / wq, x = (idx - row * wq) * VW;
-    const unsigned th = (unsigned)(p.V / p.W);                 // T * H rows per channel
-    const unsigned c = row / th, r2 = row - c * th;
-    const unsigned t = r2 / (unsigned)p.H, y = r2 - t * (unsigned)p.H;
-    const int64_t i = (int64_t)row * p.W + x;
-    const int64_t o = (int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
-    if constexpr (VEC) {
-        float4 acc = *reinterpret_cast<const float4*>(p.partial + i);
-        for (int z = 1; z < p.ksplit; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(p.partial + (int64_t)z * p.slab + i);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const unsigned c = blockIdx.y;
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;        // item within the channel
+    const bool active = j < p.per_c;
+    float s1 = 0.f, s2 = 0.f;
+    if (active) {
+        const unsigned r2 = j / wq, x = (j - r2 * wq) * VW;    // r2 = t * H + y
+        const unsigned t = r2 / (unsigned)p.H, y = r2 - t * (unsigned)p.H;
+        const int64_t i = (int64_t)c * p.V + (int64_t)r2 * p.W + x;
+        const int64_t o = (int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
+        if constexpr (VEC) {
+            float4 acc = *reinterpret_cast<const float4*>(p.partial + i);
+            for (int z = 1; z < p.ksplit; ++z) {
+                const float4 v = *reinterpret_cast<const float4*>(p.partial + (int64_t)z * p.slab + i);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (p.bias) { const float b = p.bias[c]; acc.x += b; acc.y += b; acc.z += b; acc.w += b; }
+            if (p.res) {
+                const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
+                acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+            }
+            if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+            *reinterpret_cast<float4*>(p.out + o) = acc;
+            s1 = (acc.x + acc.y) + (acc.z + acc.w);
+            s2 = (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
+        } else {
+            float acc = p.partial[i];
+            for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
+            if (p.bias) acc += p.bias[c];
+            if (p.res) acc += p.res[(int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x];
+            if (p.relu) acc = fmaxf(acc, 0.f);
+            p.out[o] = acc;
+            s1 = acc;
+            s2 = acc * acc;
         }
-        if (p.bias) { const float b = p.bias[c]; acc.x += b; acc.y += b; acc.z += b; acc.w += b; }
-        if (p.res) {
-            const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
-            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+    if (p.gn_part) {                                           // (uniform)
+        __shared__ double red[2][4];
+        double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d1; red[1][threadIdx.x >> 6] = d2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int g = (int)c / p.gn_cpg, slot = p.gn_slot0 + ((int)c % p.gn_cpg) * (int)gridDim.x + (int)blockIdx.x;
+            double* o = p.gn_part + ((size_t)g * p.gn_cap + slot) * 2;
+            o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         }
-        if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        *reinterpret_cast<float4*>(p.out + o) = acc;
-    } else {
-        float acc = p.partial[i];
-        for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
-        if (p.bias) acc += p.bias[c];
-        if (p.res) acc += p.res[(int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x];
-        if (p.relu) acc = fmaxf(acc, 0.f);
-        p.out[o] = acc;
     }
 }
 
@@ -724,6 +823,9 @@ using K2FlatBigGL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 8, false, false, true, 112, 
 using K2FlatMedGL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 4, false, false, true, 112, true>;
 using K2FlatBig56GL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 8, false, false, true, 56, true>;
 using K2FlatMed56GL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 4, false, false, true, 56, true>;
+using K1BigGL = ConvCfg<1, 1, 1, 16, 4, 2, 1, 4, 8, false, false, true, 0, true>;     // (STEMSEG_GLDS bit 8)
+using K1SmallGL = ConvCfg<1, 1, 1, 16, 2, 2, 2, 2, 4, false, false, true, 0, true>;
+using K1M64GL = ConvCfg<1, 1, 1, 16, 2, 2, 1, 4, 8, false, false, true, 0, true>;
 
 // bf16x3 twins of the tile shapes (register prefetch only where the wider fragments still fit 256 VGPRs)
 using X3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, true>;
@@ -741,7 +843,7 @@ using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 // MFMA peak)
 constexpr double CU_FLOPS_F32 = 0.46e12;
 #ifndef STEMSEG_GLDS_DEFAULT
-#define STEMSEG_GLDS_DEFAULT 0
+#define STEMSEG_GLDS_DEFAULT 1
 #endif
 
 template <class C>
@@ -767,6 +869,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys; rp.res_cs = p.res_cs; rp.res_ts = p.res_ts; rp.res_ys = p.res_ys;
         rp.slab = slab; rp.C = p.Cout; rp.V = (int64_t)p.T * p.H * p.W; rp.ksplit = ksplit; rp.relu = p.relu;
         rp.H = p.dec_W > 0 ? p.dec_H : p.H; rp.W = p.dec_W > 0 ? p.dec_W : p.W;
+        rp.gn_part = nullptr; rp.gn_cpg = rp.gn_cap = rp.gn_slot0 = 0;
         // partial slabs are dense in the launch's own tile coordinates; the whole epilogue moves to the reduce kernel
         p.out = scratch; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.dec_H = p.dec_W = 0;
         p.out_cs = (int64_t)p.T * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
@@ -774,6 +877,17 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         p.vec_epi = !C::FLAT && (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0);
     } else p.out_split_stride = 0;
     p.n_co = (int)ceil_div(p.Cout, C::MT);
+    const int64_t red_items = slab / p.Cout / (rp_vec ? 4 : 1);      // reduce threads per channel
+    const unsigned red_bx = (unsigned)ceil_div(red_items, 256);
+    if (p.gn_part) {                                     // slots of this launch in the [group][slot] table (see ConvKParams)
+        const int slot0 = *p.gn_used_host;
+        const int64_t slots = ksplit > 1 ? (int64_t)p.gn_cpg * red_bx : (int64_t)p.tiles_x * p.tiles_y * p.T;
+        SS_CHECK_ARG(slot0 + slots <= p.gn_cap, "conv3d: GroupNorm partial table too small (%lld slots needed, %d available)",
+                     (long long)(slot0 + slots), p.gn_cap);
+        if (ksplit > 1) { rp.gn_part = p.gn_part; rp.gn_cpg = p.gn_cpg; rp.gn_cap = p.gn_cap; rp.gn_slot0 = slot0; p.gn_part = nullptr; }
+        else p.gn_slot0 = slot0;
+        *p.gn_used_host = slot0 + (int)slots;
+    }
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), 1, (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
     constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
@@ -781,11 +895,10 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
     if (ksplit > 1) {
-        const int64_t items = slab / (rp_vec ? 4 : 1);
-        SS_CHECK_ARG(items < (1ll << 32) - 256, "conv3d: split-K output too large (%lld elements)", (long long)slab);
-        rp.n_items = (unsigned)items;
-        if (rp_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, s, rp);
-        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, s, rp);
+        SS_CHECK_ARG(red_items < (1ll << 32) - 256 && p.Cout <= 65535, "conv3d: split-K output too large (%lld elements)", (long long)slab);
+        rp.per_c = (unsigned)red_items;
+        if (rp_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(red_bx, (unsigned)p.Cout), dim3(256), 0, s, rp);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(red_bx, (unsigned)p.Cout), dim3(256), 0, s, rp);
     }
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
@@ -935,6 +1048,11 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.res = epi ? epi->res : nullptr;
     p.res_cs = epi ? epi->res_cs : 0; p.res_ts = epi ? epi->res_ts : 0; p.res_ys = epi ? epi->res_ys : 0;
     p.dec_H = flat ? epi->dec_H : 0; p.dec_W = flat ? epi->dec_W : 0;
+    p.gn_part = epi ? epi->gn_part : nullptr;
+    p.gn_cpg = epi ? epi->gn_cpg : 0; p.gn_cap = epi ? epi->gn_cap : 0; p.gn_slot0 = 0;
+    p.gn_used_host = epi ? epi->gn_used : nullptr;
+    SS_CHECK_ARG(!p.gn_part || ((p.gn_cpg == 4 || p.gn_cpg == 8) && p.gn_used_host && p.Cout % p.gn_cpg == 0 && !(epi->relu || epi->res)),
+                 "conv3d: fused GroupNorm statistics need groups of 4 or 8 channels and a plain (bias-only) epilogue");
     auto al16 = [](const void* ptr, int64_t cs, int64_t ts, int64_t ys, int T, int H) {
         return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && (cs % 4 == 0) && (T == 1 || ts % 4 == 0) && (H == 1 || ys % 4 == 0);
     };
@@ -1005,7 +1123,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         if (cfg == 2) return launch_gl<K2MedGL, K2Med>(4, p, s, scratch, scratch_floats);
         return launch_gl<K2SmallGL, K2Small>(4, p, s, scratch, scratch_floats);
     }
-    if (p.Cout <= 64) return bf ? launch_cfg<X1M64>(p, s, scratch, scratch_floats) : launch_cfg<K1M64>(p, s, scratch, scratch_floats);
+    if (p.Cout <= 64) return bf ? launch_cfg<X1M64>(p, s, scratch, scratch_floats) : launch_gl<K1M64GL, K1M64>(8, p, s, scratch, scratch_floats);
     int cfg = tile_cfg;
     if (cfg <= 0 || cfg > 2) {
         cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
@@ -1021,17 +1139,58 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     }
     // big un-decoded 1x1 launches: same round-based cut as the 3x3 convs, along the flat voxel row
     const bool plan1 = !flat && (tile_cfg <= 0 || tile_cfg > 2) && scratch != nullptr;
+    const bool gl1 = (glds_mask() & 8) && p.vec4 && p.Cin % 16 == 0 && p.Cout % 128 == 0;
     if (cfg == 1) {
-        if (plan1 && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512)
+        if (plan1 && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) {
+            if (gl1) return launch_rows<K1BigGL>(p, s, scratch, scratch_floats, plan_rows<K1BigGL>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
             return launch_rows<K1Big>(p, s, scratch, scratch_floats, plan_rows<K1Big>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
-        return launch_cfg<K1Big>(p, s, scratch, scratch_floats);
+        }
+        return launch_gl<K1BigGL, K1Big>(8, p, s, scratch, scratch_floats);
     }
-    if (plan1 && num_workgroups<K1Small>(p.Cout, p.T, p.H, p.W) >= 1024)
+    if (plan1 && num_workgroups<K1Small>(p.Cout, p.T, p.H, p.W) >= 1024) {
+        if (gl1) return launch_rows<K1SmallGL>(p, s, scratch, scratch_floats, plan_rows<K1SmallGL>(p, true, scratch_floats, CU_FLOPS_F32, 5, 0.85));
         return launch_rows<K1Small>(p, s, scratch, scratch_floats, plan_rows<K1Small>(p, true, scratch_floats, CU_FLOPS_F32, 5, 0.85));
-    return launch_cfg<K1Small>(p, s, scratch, scratch_floats);
+    }
+    return launch_gl<K1SmallGL, K1Small>(8, p, s, scratch, scratch_floats);
+}
+
+int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
+                     int tile_cfg, hipStream_t s, float* splitk_scratch, int64_t splitk_scratch_floats, const ConvEpilogue* epi, int groups,
+                     float eps, float* stats, double* gn_scratch) {
+    SS_CHECK_ARG(stats && gn_scratch && groups > 0 && out.C % groups == 0, "conv3d_gn: bad GroupNorm arguments");
+    const int cpg = out.C / groups;
+    const int64_t S = (int64_t)out.T * out.H * out.W;
+    static const bool off = [] { const char* e = getenv("STEMSEG_GN_EPILOGUE"); return e && e[0] == '0'; }();
+    const bool dense = out.t_stride == (int64_t)out.H * out.W && out.y_stride == out.W && out.c_stride == S;
+    if (off || (cpg != 4 && cpg != 8) || (epi && (epi->relu || epi->res || epi->dec_W > 0))) {
+        SS_CHECK_ARG(dense, "conv3d_gn: the separate statistics pass needs a dense output");
+        const int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, epi);
+        return rc ? rc : launch_gn_stats(out.ptr, out.C, S, groups, eps, stats, gn_scratch, s);
+    }
+    ConvEpilogue e = epi ? *epi : ConvEpilogue();
+    int used = 0;
+    e.gn_part = gn_scratch; e.gn_cpg = cpg; e.gn_cap = GN_SLOT_CAP; e.gn_used = &used;
+    const int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, &e);
+    if (rc) return rc;
+    return launch_gn_finalize_slots(gn_scratch, groups, GN_SLOT_CAP, used, (double)cpg * (double)S, eps, stats, s);
 }
 
 }  // namespace stemseg
+
+extern "C" int64_t stemseg_hip_conv3d_gn_scratch_doubles(int32_t Cout, int32_t groups) {
+    return (Cout > 0 && groups > 0) ? stemseg::gn_scratch_doubles(Cout, groups) : 0;
+}
+
+extern "C" int stemseg_hip_conv3d_gn(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
+                                     int32_t kt, int32_t kh, int32_t kw, int32_t tile_cfg, float* splitk_scratch, int64_t splitk_scratch_floats,
+                                     int32_t precision, int32_t groups, float eps, float* stats, double* gn_scratch, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(in && out, "conv3d_gn: null volume");
+    ConvEpilogue e;
+    e.precision = precision;
+    return launch_conv3d_gn(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream), splitk_scratch, splitk_scratch_floats, &e, groups,
+                            eps, stats, gn_scratch);
+}
 
 extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream) {
     using namespace stemseg;

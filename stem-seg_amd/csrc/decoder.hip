@@ -114,7 +114,7 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     p.X4 = take((int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
     for (int i = 0; i < 4; ++i) {
         p.stats[i] = take(2 * 64);
-        p.gn_scratch[i] = take(2 * 64 * 128);   // doubles: groups(<=64) * GN_SPLIT(64) * 2
+        p.gn_scratch[i] = take(2 * gn_scratch_doubles(64 * 8, 64));   // doubles (2 floats each): groups (<= 64) x GN_SLOT_CAP x 2
     }
     p.total = off;
     SS_CHECK_ARG(p.G <= 64, "decoder: gn_groups > 64");
@@ -163,9 +163,8 @@ static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b,
     StemsegVolume d = dense_volume(D, Cout, T, H, W);
     ConvEpilogue e;
     e.precision = precision;
-    int rc = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e);
-    if (rc) return rc;
-    rc = launch_gn_stats(D, Cout, (int64_t)T * H * W, G, eps, stats, scratch, s);
+    // the conv's epilogue (or its split-K reduce) leaves the GroupNorm partial sums: its output is not read again for them
+    int rc = launch_conv3d_gn(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e, G, eps, stats, scratch);
     if (rc) return rc;
     return launch_gn_relu_pool(D, Cout, T, H, W, G, stats, gw, gb, pool, dst, s);
 }

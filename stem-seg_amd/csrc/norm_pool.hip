@@ -81,6 +81,30 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
     }
 }
 
+// one workgroup per group: fixed-order combine of the `used` per-tile partials the conv epilogue / split-K reduce left in
+// part[g][slot] (thread k takes slots k, k + 256, ...; then a fixed tree) -> mean, rstd.  Deterministic, no atomics.
+__global__ __launch_bounds__(256) void gn_finalize_slots_kernel(const double* __restrict__ part, int cap, int used, double group_elems,
+                                                                float eps, float* __restrict__ stats) {
+    const int g = blockIdx.x;
+    const double* pg = part + (size_t)g * cap * 2;
+    double s = 0.0, ss = 0.0;
+    for (int k = threadIdx.x; k < used; k += 256) { s += pg[2 * k]; ss += pg[2 * k + 1]; }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double mean = s / group_elems;
+        double var = ss / group_elems - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        stats[2 * g + 0] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 struct GnApplyParams {
     const float* x;
     const float* stats;
@@ -199,6 +223,15 @@ int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, flo
     hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SPLIT, groups), dim3(256), 0, s, x, ge, scratch);
     SS_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups), dim3(64), 0, s, (const double*)scratch, (double)ge, eps, stats);
+    profile_end(ev, s);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s) {
+    SS_CHECK_ARG(part && stats && groups > 0 && used > 0 && used <= cap, "gn_finalize_slots: bad arguments (used %d of %d)", used, cap);
+    void* ev = profile_begin(41, 16.0 * groups * used, s);
+    hipLaunchKernelGGL(gn_finalize_slots_kernel, dim3(groups), dim3(256), 0, s, part, cap, used, group_elems, eps, stats);
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;

@@ -84,6 +84,8 @@ SIGNATURES = {
     "stemseg_hip_packed_weight_bytes_bf16x3": (C.c_int64, [_I32, _I32, _I32]),
     "stemseg_hip_pack_conv_weight_bf16x3": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
+    "stemseg_hip_conv3d_gn_scratch_doubles": (C.c_int64, [_I32, _I32]),
+    "stemseg_hip_conv3d_gn": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
     "stemseg_hip_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "stemseg_hip_encoder_init_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, _P]),
     "stemseg_hip_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), _P, C.POINTER(Volume), _P, C.c_size_t, _P]),
@@ -262,6 +264,18 @@ def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None, epilog
         e.precision = PRECISIONS[epilogue.get("precision", "f32")]
     check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), kt, kh, kw, tile_cfg,
                                    ptr(splitk_scratch), n, C.byref(e) if e is not None else None, stream()))
+
+
+def conv3d_gn(vin, packed_w, bias, vout, k, groups, eps=1e-5, tile_cfg=0, splitk_scratch=None, precision="f32"):
+    """Convolution + GroupNorm statistics of its output in one pass -> stats float32 [2 * groups] (mean, rstd per group)."""
+    n = 0 if splitk_scratch is None else splitk_scratch.numel()
+    kt, kh, kw = (k, k, k) if isinstance(k, int) else k
+    dev = packed_w.device
+    stats = torch.empty(2 * groups, dtype=torch.float32, device=dev)
+    scratch = torch.empty(lib().stemseg_hip_conv3d_gn_scratch_doubles(vout.C, groups), dtype=torch.float64, device=dev)
+    check(lib().stemseg_hip_conv3d_gn(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), kt, kh, kw, tile_cfg, ptr(splitk_scratch), n,
+                                      PRECISIONS[precision], groups, eps, ptr(stats), ptr(scratch), stream()))
+    return stats
 
 
 def groupnorm_stats(x, groups, eps=1e-5):

@@ -276,6 +276,39 @@ def test_groupnorm_stats(hip, shape):
     assert report("gn rstd", stats[:, 1], 1 / np.sqrt(xg.var(1) + 1e-5)) <= 1e-5
 
 
+@pytest.mark.parametrize("case", [(64, 128, 2, 9, 40, 0, False), (64, 256, 4, 15, 27, 0, False), (32, 128, 8, 24, 64, 0, True), (32, 256, 2, 30, 54, 0, True),
+                                  (16, 128, 3, 17, 70, 1, False), (16, 128, 3, 17, 70, 2, True), (16, 256, 2, 9, 37, 3, True), (16, 64, 2, 6, 9, 0, False),
+                                  (256, 128, 8, 120, 216, 0, True)])
+def test_conv3d_with_groupnorm_statistics_in_the_epilogue(hip, case):
+    """Conv3d + the GroupNorm(32) statistics of its output in one pass (epilogue partial sums / split-K reduce partial sums +
+    fixed-order finalize) vs the conv followed by the separate statistics pass: same conv output bit for bit, statistics
+    to fp32 round-off, and bit-identical from run to run.  Cases: group sizes 4 and 8 (fused) and 2 (fallback), every 3x3x3
+    tile shape incl. flat tiles, split-K, and the planner's row cut on the full block_4x shape."""
+    Cin, Cout, T, H, W, cfg, with_scratch = case
+    x = _rand((Cin, T, H, W), 21)
+    w = _rand((Cout, Cin, 3, 3, 3), 22, 1.0 / np.sqrt(Cin * 27))
+    b = _rand((Cout,), 23)
+    buf, g = hip.alloc_padded(Cin, T, H, W)
+    hip.copy_to_volume(dev(x), 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
+    pw = hip.pack_conv_weight(dev(w))
+    scratch = torch.empty(2 * Cout * T * H * W, device="cuda") if with_scratch else None
+    vin = hip.padded_halo_view(buf, g, Cin, T, H, W)
+    ref_out = torch.empty(Cout, T, H, W, device="cuda")
+    hip.conv3d(vin, pw, dev(b), hip.dense_volume(ref_out), 3, cfg, scratch)
+    ref_stats = hip.groupnorm_stats(ref_out, 32).cpu().numpy()
+    out = torch.empty(Cout, T, H, W, device="cuda")
+    stats = hip.conv3d_gn(vin, pw, dev(b), hip.dense_volume(out), 3, 32, tile_cfg=cfg, splitk_scratch=scratch)
+    assert torch.equal(out, ref_out)
+    got = stats.cpu().numpy()
+    assert report("fused GN mean %s" % (case,), got[0::2], ref_stats[0::2]) <= 2e-6
+    assert report("fused GN rstd %s (rel)" % (case,), got[1::2] / ref_stats[1::2], np.ones(32)) <= 2e-6
+    again = hip.conv3d_gn(vin, pw, dev(b), hip.dense_volume(out), 3, 32, tile_cfg=cfg, splitk_scratch=scratch)
+    assert torch.equal(again, stats)
+    xo = ref_out.cpu().numpy().astype(np.float64).reshape(32, -1)
+    assert report("fused GN mean vs fp64", got[0::2], xo.mean(1)) <= 1e-5
+    assert report("fused GN rstd vs fp64", got[1::2], 1 / np.sqrt(xo.var(1) + 1e-5)) <= 1e-5
+
+
 @pytest.mark.parametrize("pool", [0, 1])
 @pytest.mark.parametrize("shape", [(64, 8, 6, 9), (128, 4, 15, 27), (32, 5, 3, 33), (32, 3, 4, 4)])
 def test_gn_relu_pool(hip, pool, shape):
@@ -914,7 +947,8 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
-def test_config0_vs_reference_cpu_path(hip, golden):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_config0_vs_reference_cpu_path(hip, golden, precision):
     """BASELINE configs[0] -- one synthetic 8 x 256 x 448 clip, random-init ResNet-50 -- through the whole HIP path (uint8 frames
     -> pre-processing -> encoder -> decoders -> fg mask -> gather -> clustering -> chainer) against what the REFERENCE itself
     computed on CPU for the same frames and weights (tests/golden/config0.npz): maps <= 1e-3, foreground mask and instance
@@ -934,6 +968,8 @@ def test_config0_vs_reference_cpu_path(hip, golden):
         msd = model._model.state_dict()
         model._model.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])).reshape(msd[k].shape) for k in msd})
         model = model.cuda()
+        model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
+        exact = precision == "f32"
         tg = TrackGenerator(model, "davis", seediness_thresh=thr, frame_overlap=4)
         embeddings, fg, _ = tg.do_inference([f for f in frames])
         e = embeddings[0]
@@ -952,13 +988,16 @@ def test_config0_vs_reference_cpu_path(hip, golden):
         agree = float((ref_lab[both] == got_lab[both]).mean())
         print("[parity] config0 vs reference: fg %d vs %d (%d pixels differ), %d instances vs %d, labels identical on %.4f of the common fg"
               % (got_fg.sum(), ref_fg.sum(), (got_fg != ref_fg).sum(), len(meta[0]["instance_labels"]), len(g["instance_labels"]), agree))
-        assert (got_fg != ref_fg).sum() <= 20 and agree >= 0.999
+        print("[bf16x3-labels] config0 %s: fg differs in %d pixels, label agreement %.5f, instance list %s"
+              % (precision, (got_fg != ref_fg).sum(), agree, "identical" if meta[0]["instance_labels"] == g["instance_labels"].tolist() else "DIFFERENT"))
+        assert (got_fg != ref_fg).sum() <= (20 if exact else 60) and agree >= (0.999 if exact else 0.99)
         assert meta[0]["instance_labels"] == g["instance_labels"].tolist()
     finally:
         config.load_preset("defaults")
 
 
-def test_ytvis_flow_vs_reference(hip, golden):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_ytvis_flow_vs_reference(hip, golden, precision):
     """BASELINE configs[2] flow (reduced size) vs the REFERENCE's own CPU result (tests/golden/model_ytvis.npz): YouTube-VIS preset
     -- 7-channel embedding head with in-head seediness, 40+1-channel semseg head (inter [256]*4, wide head on the MFMA conv),
     --resize_embeddings: semseg logits x4, averaged over two overlapping clips, fg = sigmoid > 0.5, class argmax; the chainer
@@ -978,6 +1017,8 @@ def test_ytvis_flow_vs_reference(hip, golden):
         new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 6.0
         model._model.load_state_dict(new)
         model = model.cuda()
+        model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
+        exact = precision == "f32"
         frames = synth.synth_frames(12, 96, 128, seed=81)
         tg = TrackGenerator(model, "ytvis", resize_scale=4.0, frame_overlap=4)
         out = model([f for f in frames], g["subseqs"].tolist())
@@ -1003,7 +1044,8 @@ def test_ytvis_flow_vs_reference(hip, golden):
         # (the fixture keeps the seediness sigmoid out of saturation: a plateau of exact 1.0 values, once resized x4, leaves the
         #  round's arg-max to last-bit differences between any two fp32 resamplers -- measured 3.6 % label differences with a x30
         #  gain, against the reference AND against the CPU oracle alike -- and a different, equally good seed moves the boundary)
-        assert (got_fg != ref_fg).mean() < 1e-3 and agree >= 0.999
+        print("[bf16x3-labels] ytvis %s: fg differs in %d pixels, label agreement %.5f" % (precision, (got_fg != ref_fg).sum(), agree))
+        assert (got_fg != ref_fg).mean() < 1e-3 and agree >= (0.999 if exact else 0.99)
         for i in range(2):
             assert meta[i]["instance_labels"] == g["c%d_instance_labels" % i].tolist()
         # the ORACLE chain on the SAME head outputs (CPU x4 trilinear resize, CPU clustering and stitching) must agree too
@@ -1017,12 +1059,13 @@ def test_ytvis_flow_vs_reference(hip, golden):
         (rtrack, rcounts, _), _, _, _, _ = ref_chain.process(fg.cpu(), dicts)
         same = float(np.mean([float((a.cpu() == b).float().mean()) for a, b in zip(track, rtrack) if b.numel()]))
         print("[parity] ytvis flow vs oracle chain on the same head outputs: %.5f of labels identical" % same)
-        assert same >= 0.999
+        assert same >= 0.999        # (same head outputs on both sides: holds in either precision)
     finally:
         config.load_preset("defaults")
 
 
-def test_kitti_flow_vs_reference(hip, golden):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_kitti_flow_vs_reference(hip, golden, precision):
     """KITTI-MOTS preset ('xyt' embeddings: the time coordinate is an embedding dimension, no free dims; in-head seediness; 3+1
     channel semseg head through the fused heads kernel) at a reduced wide-aspect size, 14 frames as three overlapping clips, vs
     the REFERENCE's own CPU result (tests/golden/model_kitti.npz): semseg fg / class probabilities, embeddings, stitched tracks."""
@@ -1041,6 +1084,8 @@ def test_kitti_flow_vs_reference(hip, golden):
         new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 6.0
         model._model.load_state_dict(new)
         model = model.cuda()
+        model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
+        exact = precision == "f32"
         frames = synth.synth_frames(14, 60, 190, seed=91)
         tg = TrackGenerator(model, "kittimots", frame_overlap=4)
         out = model([f for f in frames], g["subseqs"].tolist())
@@ -1060,8 +1105,9 @@ def test_kitti_flow_vs_reference(hip, golden):
         agree = float((ref_lab[both] == got_lab[both]).mean())
         print("[parity] kitti flow vs reference: fg %d vs %d (%d pixels differ), labels identical on %.4f of the common fg, tracks %s"
               % (got_fg.sum(), ref_fg.sum(), (got_fg != ref_fg).sum(), agree, sorted(counts.items())[:8]))
-        assert (got_fg != ref_fg).mean() < 1e-3 and agree >= 0.999
-        assert sorted(counts.items()) == [tuple(r) for r in g["pt_counts"].tolist()] or (got_fg != ref_fg).any()
+        print("[bf16x3-labels] kitti %s: fg differs in %d pixels, label agreement %.5f" % (precision, (got_fg != ref_fg).sum(), agree))
+        assert (got_fg != ref_fg).mean() < 1e-3 and agree >= (0.999 if exact else 0.99)
+        assert not exact or sorted(counts.items()) == [tuple(r) for r in g["pt_counts"].tolist()] or (got_fg != ref_fg).any()
         for i in range(3):
             assert meta[i]["instance_labels"] == g["c%d_instance_labels" % i].tolist()
     finally:
