@@ -36,6 +36,13 @@ namespace stemseg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// small direct-to-LDS tiles (<= 4 accumulator blocks per wave, LDS <= 35 KB): workgroups per CU the register allocator leaves
+// room for (4 -> 128 VGPRs)
+#ifndef STEMSEG_MIN_WG4
+#define STEMSEG_MIN_WG4 4
+#endif
+constexpr int MIN_WG4 = STEMSEG_MIN_WG4;
+
 struct ConvKParams {
     const float* in;
     int64_t in_cs, in_ts, in_ys, in_limit;
@@ -114,7 +121,7 @@ struct ConvCfg {
     static_assert(!GL || (DB && !BF), "direct-to-LDS staging is the double-buffered fp32 form");
     // workgroups per CU the register allocator must leave room for: the GL forms carry no staging registers, so the tiles whose
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
-    static constexpr int MIN_WG = (GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2;
+    static constexpr int MIN_WG = (GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2);
 };
 
 template <class C>
@@ -843,7 +850,7 @@ using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 // MFMA peak)
 constexpr double CU_FLOPS_F32 = 0.46e12;
 #ifndef STEMSEG_GLDS_DEFAULT
-#define STEMSEG_GLDS_DEFAULT 1
+#define STEMSEG_GLDS_DEFAULT 13
 #endif
 
 template <class C>

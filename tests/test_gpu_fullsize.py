@@ -106,6 +106,39 @@ def test_config1_davis_r101_clip_480x864_vs_oracle(hip):
         config.load_preset("defaults")
 
 
+def test_config1_davis_reference_resize_704x1248_vs_oracle(hip):
+    """The reference-faithful DAVIS resize (davis_1.yaml: MIN_DIM 736 / MAX_DIM 1248 -> 480x854 frames become 701x1248, padded
+    704x1248; SURVEY 8(d) 'secondary' shape): h4 x w4 = 176 x 312, 439 k voxels per map.  R-50 weights (the shape is what is
+    under test); encoder + both decoders + clustering vs the oracle."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import compute_resize_params_2, pad_to_multiple_of_32
+    from stemseg_amd.pipeline import ClipPipeline
+    try:
+        nw, nh, _ = compute_resize_params_2((854, 480), 736, 1248)
+        H, W = pad_to_multiple_of_32(nh, nw)
+        assert (nh, nw, H, W) == (701, 1248, 704, 1248)
+        model, sd = _model("davis", "R-50-FPN", 21, {"seediness_head.conv_out.weight": 30.0}, 736, 1248)
+        pipe = ClipPipeline(model)
+        frames = _frames(8, H, W, nw, seed=12)
+        frames[:, :, nh:] = 0
+        out = pipe.step(frames.cuda())
+        torch.cuda.synchronize()
+        t0 = time.time()
+        ref = opipe.embed_and_cluster_clip(frames, sd, "R-50-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+        print("[fullsize] oracle 704x1248 clip took %.1f s" % (time.time() - t0))
+        assert tuple(out["emb"].shape) == (4, 8, 176, 312)
+        assert _maxerr("davis 704x1248 emb", out["emb"].cpu().numpy(), ref["emb"].numpy()) <= 1e-3
+        assert _maxerr("davis 704x1248 seediness", out["seed"].cpu().numpy(), ref["seed"].numpy()) <= 1e-3
+        assert _maxerr("davis 704x1248 bandwidth (rel)", (out["bw"].cpu() / ref["bw"]).numpy(), np.ones(ref["bw"].shape)) <= 1e-3
+        o2 = pipe.cluster(ref["emb"].cuda().contiguous(), ref["bw"].cuda().contiguous(), ref["seed"].cuda().contiguous())
+        n2 = int(o2["frame_offsets"].cpu()[-1])
+        bad = int((o2["labels"][:n2].cpu().numpy() != ref["labels"]).sum()) if n2 == ref["labels"].shape[0] else -1
+        print("[fullsize] davis 704x1248: %d fg points, K %d, %d labels differ" % (n2, len(ref["meta"]["instance_labels"]), bad))
+        assert n2 == ref["labels"].shape[0] and 0 <= bad <= max(2, n2 // 2000)
+    finally:
+        config.load_preset("defaults")
+
+
 # ------------------------------------------------------------------------------------------------ configs[4]
 def test_config4_kitti_clip_608x1952_vs_oracle(hip):
     """One KITTI-MOTS-preset clip at the --max_dim 1948 size: 375x1242 frames -> 588x1948 -> padded 608x1952 (h4 x w4 =

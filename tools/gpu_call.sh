@@ -6,7 +6,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 R=${ROUND:-r02}
 if [[ -z "${SKIP_TESTS:-}" ]]; then
 timeout 1200 python -m pytest tests -m gpu -q -s --timeout 600 -p no:cacheprovider --durations=8 ${TESTS:-} > gpurun_out/tests.log 2>&1; echo "tests exit $?"; grep -E "passed|failed|error" gpurun_out/tests.log | tail -2 | cut -c1-200
-grep -E "^\[fullsize\]|^FAILED|^ERROR" gpurun_out/tests.log | cut -c1-220
+grep -E "^\[fullsize\]|^\[bf16x3-labels\]|^FAILED|^ERROR" gpurun_out/tests.log | cut -c1-220
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/smoke.log | cut -c1-200
 fi
 timeout 400 python bench.py > gpurun_out/bench_final.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench_final.log > gpurun_out/bench_final.json; cut -c1-160 gpurun_out/bench_final.json

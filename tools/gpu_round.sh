@@ -32,4 +32,6 @@ if [[ $what == pmc ]]; then
     (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/tools/pmc_conv.py 3 ${PMC_CFG:-0}) > gpurun_out/pmc_$tag.log 2>&1
     echo "pmc $tag exit $?"; tail -2 gpurun_out/pmc_$tag.log
   done
+  python tools/pmc_summary.py ${ROUND:-r02} 3 | tail -12
+  rm -rf gpurun_out/pmc_*/ gpucore.*
 fi
