@@ -810,6 +810,12 @@ using K3FlatMed = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 112>;  
 using K3FlatSmall = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 112>; // 128 co x 64
 // (pitch <= 56: 16x maps -- the staged run is tile + 2 * PMAX + 8 floats per channel plane, so a tighter PMAX stages less)
 using K2FlatBig56 = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, false, false, 56>;
+// 224-position twins (7 segments: 4 waves x 32 channels, each across all 7): chosen when they divide the launch into fewer
+// rounds of the chip than the 256-position tile (a 16x plane of 32 x 56 positions = exactly 8 such tiles; 32 frames x 2
+// channel tiles = 512 workgroups = two per CU, where the 256-position tile gives 448 = 1.75 per CU -> two uneven rounds)
+using K2Flat7_56 = ConvCfg<1, 3, 3, 8, 1, 7, 4, 1, 7, true, false, false, 56>;
+using K1N7 = ConvCfg<1, 1, 1, 32, 1, 7, 4, 1, 7, true>;                              // 128 co x 224 voxels
+using K1N7GL = ConvCfg<1, 1, 1, 16, 1, 7, 4, 1, 7, false, false, true, 0, true>;
 using K2FlatMed56 = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, false, false, 56>;
 using K3FlatMed56 = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 56>;
 using K3FlatSmall56 = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 56>;
@@ -850,7 +856,7 @@ using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 // MFMA peak)
 constexpr double CU_FLOPS_F32 = 0.46e12;
 #ifndef STEMSEG_GLDS_DEFAULT
-#define STEMSEG_GLDS_DEFAULT 13
+#define STEMSEG_GLDS_DEFAULT 9
 #endif
 
 template <class C>
@@ -1014,6 +1020,18 @@ static bool prefer_flat(const ConvKParams& p, int tile_cfg, bool bf) {
     return tile_efficiency<Flat>(p) > 1.08 * tile_efficiency<Tile2D>(p);
 }
 
+// rounds of the chip x work per workgroup: the time of an MFMA-bound launch whose workgroups all take equally long
+template <class C>
+static double rounds_cost(const ConvKParams& p) {
+    const int64_t tiles = C::FLAT ? ceil_div((int64_t)p.H * p.in_ys, C::NT) : ceil_div(p.W, C::COLS * 32) * ceil_div(p.H, C::ROWS);
+    const int64_t wgs = tiles * p.T * ceil_div(p.Cout, C::MT);
+    return (double)ceil_div(wgs, 256) * C::NT * C::MT;
+}
+static bool tile224_on() {
+    static const bool on = [] { const char* e = getenv("STEMSEG_TILE224"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int glds_mask() {
     static const int m = [] { const char* e = getenv("STEMSEG_GLDS"); return e ? atoi(e) : STEMSEG_GLDS_DEFAULT; }();
     return m;
@@ -1114,7 +1132,12 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= need) cfg = 2;
             else cfg = 3;
         }
-        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg, bf)) return launch_gl<K2FlatBig56GL, K2FlatBig56>(4, p, s, scratch, scratch_floats);
+        if (tile_cfg == 4 && !bf && p.vec4 && p.dec_W == 0 && p.in_ys <= 56 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys)   // (tests / sweeps)
+            return launch_cfg<K2Flat7_56>(p, s, scratch, scratch_floats);
+        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg, bf)) {
+            if (tile224_on() && rounds_cost<K2FlatBig56>(p) > 1.5 * K2FlatBig56::NT * K2FlatBig56::MT && rounds_cost<K2Flat7_56>(p) < 0.97 * rounds_cost<K2FlatBig56>(p)) return launch_cfg<K2Flat7_56>(p, s, scratch, scratch_floats);
+            return launch_gl<K2FlatBig56GL, K2FlatBig56>(4, p, s, scratch, scratch_floats);
+        }
         if (cfg >= 2 && prefer_flat<K2FlatMed56, K2Med>(p, tile_cfg, bf)) return launch_gl<K2FlatMed56GL, K2FlatMed56>(4, p, s, scratch, scratch_floats);
         if (cfg == 1 && prefer_flat<K2FlatBig, K2Big>(p, tile_cfg, bf)) return launch_gl<K2FlatBigGL, K2FlatBig>(4, p, s, scratch, scratch_floats);
         if (cfg >= 2 && prefer_flat<K2FlatMed, K2Med>(p, tile_cfg, bf)) return launch_gl<K2FlatMedGL, K2FlatMed>(4, p, s, scratch, scratch_floats);
@@ -1144,6 +1167,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         if (cfg == 1) return launch_cfg<X1Big>(p, s, scratch, scratch_floats);
         return launch_cfg<X1Small>(p, s, scratch, scratch_floats);
     }
+    if (tile_cfg == 4) return launch_gl<K1N7GL, K1N7>(8, p, s, scratch, scratch_floats);                                      // (tests / sweeps)
     // big un-decoded 1x1 launches: same round-based cut as the 3x3 convs, along the flat voxel row
     const bool plan1 = !flat && (tile_cfg <= 0 || tile_cfg > 2) && scratch != nullptr;
     const bool gl1 = (glds_mask() & 8) && p.vec4 && p.Cin % 16 == 0 && p.Cout % 128 == 0;
@@ -1152,6 +1176,8 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             if (gl1) return launch_rows<K1BigGL>(p, s, scratch, scratch_floats, plan_rows<K1BigGL>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
             return launch_rows<K1Big>(p, s, scratch, scratch_floats, plan_rows<K1Big>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
         }
+        if (tile224_on() && (tile_cfg <= 0 || tile_cfg > 2) && rounds_cost<K1Big>(p) > 1.5 * K1Big::NT * K1Big::MT && rounds_cost<K1N7>(p) < 0.97 * rounds_cost<K1Big>(p))
+            return launch_gl<K1N7GL, K1N7>(8, p, s, scratch, scratch_floats);
         return launch_gl<K1BigGL, K1Big>(8, p, s, scratch, scratch_floats);
     }
     if (plan1 && num_workgroups<K1Small>(p.Cout, p.T, p.H, p.W) >= 1024) {

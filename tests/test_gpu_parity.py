@@ -207,6 +207,35 @@ def test_conv1x1_flat_decode_residual_relu(hip, shape):
         assert float(halo.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [("k1", 256, 256, 2, 30, 54), ("k1", 40, 128, 1, 7, 33), ("k1", 1024, 256, 4, 30, 54), ("k2", 256, 256, 4, 30, 54), ("k2", 64, 128, 2, 9, 50)])
+def test_conv_224_wide_tiles(hip, case):
+    """The 7-segment (224-position) tiles the launcher picks when they divide a launch into fewer rounds of the chip -- forced
+    here with tile_cfg = 4: 1x1 (direct-to-LDS form, and the register-staged form when Cin % 16 != 0) with residual + ReLU, and the
+    flat 1x3x3 tile on zero-haloed planes of pitch 56; with and without split-K."""
+    kind, Cin, Cout, T, H, W = case
+    b = _rand((Cout,), 33)
+    if kind == "k1":
+        V = T * H * W
+        x, w, r = _rand((Cin, V), 31), _rand((Cout, Cin, 1, 1), 32, 1.0 / np.sqrt(Cin)), _rand((Cout, V), 34)
+        ref = F.relu(torch.from_numpy(w.reshape(Cout, Cin)) @ torch.from_numpy(x) + torch.from_numpy(b)[:, None] + torch.from_numpy(r)).numpy()
+        xd, rd, wd = dev(x), dev(r), hip.pack_conv_weight(dev(w))
+        for sk in (None, torch.empty(8 * Cout * V, device="cuda")):
+            out = torch.full((Cout, V), float("nan"), device="cuda")
+            hip.conv3d(hip.flat_volume(xd), wd, dev(b), hip.flat_volume(out), 1, 4, sk, dict(relu=1, residual=rd, res_strides=(V, 0, 0)))
+            assert report("conv1x1 224-tile %s splitk=%s" % (case, sk is not None), out.cpu().numpy(), ref) <= 2e-4
+    else:
+        x, w = _rand((Cin, T, H, W), 31), _rand((Cout, Cin, 3, 3), 32, 1.0 / np.sqrt(Cin * 9))
+        ref = F.relu(F.conv2d(torch.from_numpy(x).permute(1, 0, 2, 3), torch.from_numpy(w), torch.from_numpy(b), padding=1)).permute(1, 0, 2, 3).numpy()
+        pitch = (W + 2 + 3) // 4 * 4
+        buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
+        buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
+        vin = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel())
+        for sk in (None, torch.empty(8 * Cout * T * H * W, device="cuda")):
+            out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+            hip.conv3d(vin, hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(out), (1, 3, 3), 4, sk, dict(relu=1))
+            assert report("conv2d 224-tile %s splitk=%s" % (case, sk is not None), out.cpu().numpy(), ref) <= 2e-4
+
+
 @pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
 def test_encoder_vs_golden(hip, golden, btype):
     """HIP encoder (stem, bottlenecks with fused epilogues, FPN) vs the reference's outputs (golden) and the oracle."""
