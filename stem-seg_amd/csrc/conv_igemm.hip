@@ -27,7 +27,11 @@
 //   BF    bf16x3 split on v_mfma_f32_32x32x16_bf16, fp32 accumulate             (opt-in precision mode)
 // plus split-K with a deterministic slab reduce, an XCD-aware (and, for 3-D taps, t-fastest) tile order, and a launch
 // planner that cuts big launches into whole rows + split-K rows so that their workgroups fill whole rounds of the chip.
-// A/B switches (environment, read once): STEMSEG_K3_DB, STEMSEG_FLAT, STEMSEG_PLANNER, STEMSEG_T_FASTEST (= 0 to disable).
+//   GL    with DB: the next chunk goes global -> LDS directly (global_load_lds_dwordx4), no staging registers -> 3-4 workgroups per CU
+//         for the 1x1 tiles (default for the big 3x3x3 tile and every 1x1 tile: STEMSEG_GLDS bit mask, default 9)
+// and the GroupNorm statistics of the output (decoder stages) as per-tile fp64 partial sums left by the epilogue.
+// A/B switches (environment, read once; bench.py records them): STEMSEG_K3_DB, STEMSEG_FLAT, STEMSEG_PLANNER, STEMSEG_T_FASTEST,
+// STEMSEG_GN_EPILOGUE (= 0 to disable), STEMSEG_GLDS (bit mask: 1 big 3x3x3, 2 other 3x3x3, 4 1x3x3, 8 1x1), STEMSEG_TILE224 (= 1 to enable).
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -1028,7 +1032,9 @@ static double rounds_cost(const ConvKParams& p) {
     return (double)ceil_div(wgs, 256) * C::NT * C::MT;
 }
 static bool tile224_on() {
-    static const bool on = [] { const char* e = getenv("STEMSEG_TILE224"); return !(e && e[0] == '0'); }();
+    // measured (round 2): 42.99 / 43.09 clips/s with, 43.60 / 43.40 without -- the rounds saved are eaten by the narrower wave
+    // tile (one A fragment per 7 MFMAs instead of 4 per 8) and the other lanes' kernels already fill uneven rounds: off
+    static const bool on = [] { const char* e = getenv("STEMSEG_TILE224"); return e && e[0] == '1'; }();
     return on;
 }
 

@@ -169,7 +169,7 @@ def profile_enable(on):
 
 
 # profiler tags: convolutions by tile class (work = FLOP) and the streaming kernels (work = algorithmic bytes)
-PROFILE_CONV_TAGS = {"conv3x3x3": (8, 4, 2), "conv1x3x3": (28, 24, 22), "conv1x1x1": (18, 14, 16, 12)}
+PROFILE_CONV_TAGS = {"conv3x3x3": (8, 4, 2), "conv1x3x3": (28, 27, 24, 22), "conv1x1x1": (18, 17, 14, 16, 12)}
 PROFILE_HBM_TAGS = {40: "upsample_trilinear", 41: "gn_stats (partial + finalize)", 42: "gn_relu (apply)", 43: "gn_relu_pool (apply + AvgPool3d)",
                     44: "heads", 45: "fg_gather (count + scan + scatter)", 46: "cluster (all rounds + final)", 47: "stem_conv7x7",
                     48: "maxpool3x3s2", 49: "subsample2", 50: "upsample2x_add (FPN top-down)"}
