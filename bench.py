@@ -197,7 +197,8 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
                                    "clustering + Hungarian stitching" % (F, overlap, n_clips, world, BACKBONE),
                        "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "eager" if args.no_graph else "hipGraph replay",
                        "switches": library_switches()},
-            "exchange": {"collective": "all_gather (RCCL)" if world > 1 else "none (one rank)", "bytes_received_per_rank": stats["allgather_bytes"],
+            "exchange": {"collective": ("all_gather (%s)" % ("RCCL" if os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl" else
+                                                             os.environ["STEMSEG_BENCH_BACKEND"] + ": functional check, ranks share a GPU")) if world > 1 else "none (one rank)", "bytes_received_per_rank": stats["allgather_bytes"],
                          "ms_median": round(sorted(ag_ms)[len(ag_ms) // 2], 3) if ag_ms else 0.0, "inside_timed_region": True},
             "result": {"frames": len(track), "fg_points": int(sum(counts.values())), "highest_track_id": int(max(list(counts) + [0])),
                        "label_checksum_crc32": int(crc), "note": "the checksum must be identical for every --gpus N"}}))
@@ -250,8 +251,16 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # STEMSEG_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
+        # the exchange goes through the host) -- never a performance number; the line's config says so
+        backend = os.environ.get("STEMSEG_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 

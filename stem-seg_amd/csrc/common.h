@@ -93,7 +93,7 @@ int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, flo
 // conv + GroupNorm statistics of its output in one pass: the conv's epilogue (or its split-K reduce) leaves per-tile partial
 // sums in `gn_scratch` (>= gn_scratch_doubles(Cout, groups) doubles), one more tiny launch turns them into stats[2g] = mean,
 // stats[2g+1] = rstd.  Falls back to conv + launch_gn_stats when the group size is not 4 or 8 channels.
-constexpr int GN_SLOT_CAP = 4096;
+constexpr int GN_SLOT_CAP = 32768;      // slots per group (x 16 B x groups = 33.5 MB at 64 groups); larger launches take the separate pass
 static inline int64_t gn_scratch_doubles(int Cout, int groups) { return (int64_t)groups * GN_SLOT_CAP * 2 > (int64_t)groups * 128 ? (int64_t)groups * GN_SLOT_CAP * 2 : (int64_t)groups * 128; }
 int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
                      int tile_cfg, hipStream_t s, float* splitk_scratch, int64_t splitk_scratch_floats, const ConvEpilogue* epi, int groups,

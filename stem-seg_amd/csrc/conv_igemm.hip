@@ -1201,7 +1201,9 @@ int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float
     const int64_t S = (int64_t)out.T * out.H * out.W;
     static const bool off = [] { const char* e = getenv("STEMSEG_GN_EPILOGUE"); return e && e[0] == '0'; }();
     const bool dense = out.t_stride == (int64_t)out.H * out.W && out.y_stride == out.W && out.c_stride == S;
-    if (off || (cpg != 4 && cpg != 8) || (epi && (epi->relu || epi->res || epi->dec_W > 0))) {
+    // upper bound of the slots any tile choice can need: smallest 2-D tile (2 rows x 32 columns) + a fully split-K launch
+    const int64_t slot_bound = ceil_div(out.W, 32) * ceil_div(out.H, 2) * out.T + (int64_t)cpg * ceil_div(S, 256);
+    if (off || (cpg != 4 && cpg != 8) || slot_bound > GN_SLOT_CAP || (epi && (epi->relu || epi->res || epi->dec_W > 0))) {
         SS_CHECK_ARG(dense, "conv3d_gn: the separate statistics pass needs a dense output");
         const int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, epi);
         return rc ? rc : launch_gn_stats(out.ptr, out.C, S, groups, eps, stats, gn_scratch, s);

@@ -15,7 +15,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 
 
 def counters(tag):
-    dbs = glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s" % tag, "**", "*.db"), recursive=True)
+    dbs = glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_%s*" % tag, "**", "*.db"), recursive=True)
     if not dbs:
         return {}
     con = sqlite3.connect(dbs[0])
@@ -30,7 +30,8 @@ def counters(tag):
 
 
 fetch, write = counters("FETCH_SIZE").get("FETCH_SIZE", {}), counters("WRITE_SIZE").get("WRITE_SIZE", {})
-sq = counters("SQ_WAVES_SQ_BUSY_CYCLES_SQ_VALU_MFMA_BUSY_CY")
+sq = counters("SQ_WAVES")
+sq.update(counters("SQ_LDS_BANK"))
 lines = ["# rocprofv3 --pmc passes on tools/pmc_conv.py (block_4x conv of BASELINE configs[1]: Cin 256 -> Cout 128 over [8,120,216]), %d convs per pass" % reps]
 res = {}
 if fetch and write:
@@ -44,7 +45,15 @@ if fetch and write:
            "note": "GB per block_4x conv (all its kernel launches incl. the split-K reduce of the planner's cut), FETCH_SIZE x2 + WRITE_SIZE "
                    "from separate rocprofv3 --pmc passes, profiles/%s_pmc_conv3d_block4x.txt" % rnd}
 for cname, d in sorted(sq.items()):
-    lines.append("%-28s %s" % (cname, ", ".join("%s %.4g" % (k, v[0] / reps) for k, v in d.items())))
+    lines.append("%-28s %s   (per conv, summed over XCDs / SIMDs)" % (cname, ", ".join("%s %.4g" % (k, v[0] / reps) for k, v in d.items())))
+if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "GRBM_GUI_ACTIVE" in sq:
+    busy = sum(v[0] for v in sq["SQ_VALU_MFMA_BUSY_CYCLES"].values()) / 1024.0        # per SIMD (256 CUs x 4)
+    act = sum(v[0] for v in sq["GRBM_GUI_ACTIVE"].values()) / 8.0                      # per XCD
+    lines.append("MFMA-pipe utilisation         %.1f %%  (busy cycles per SIMD / active cycles per XCD, all kernels of the conv)" % (100.0 * busy / act))
+if "SQ_WAIT_ANY" in sq and "SQ_WAVE_CYCLES" in sq:
+    wc = sum(v[0] for v in sq["SQ_WAVE_CYCLES"].values())
+    lines.append("wave time parked (s_waitcnt / barrier)  %.1f %%, issue-stalled %.1f %%, issuing %.1f %%" % tuple(
+        100.0 * sum(v[0] for v in sq[k].values()) / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")))
 lines += [l.rstrip() for l in open(os.path.join(ROOT, "gpurun_out", "pmc_FETCH_SIZE.log")).read().splitlines() if l.startswith("conv3d_k3")][:1] \
     if os.path.exists(os.path.join(ROOT, "gpurun_out", "pmc_FETCH_SIZE.log")) else []
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
