@@ -254,6 +254,11 @@ int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEnc
  * then (sum / count) > thr.  accumulate: acc = (first ? 0 : acc) + plane, n floats. */
 int stemseg_hip_seediness_accumulate(float* acc, const float* plane, int64_t n, int32_t first, void* stream);
 int stemseg_hip_fg_mask(const float* acc, float count, float thr, uint8_t* mask, int64_t n, void* stream);
+/* The same for every frame of a sequence in one launch: acc [F][HW] holds the per-frame sums (e.g. accumulated with
+ * stemseg_hip_semseg_accumulate on the 1-channel seediness maps, clip after clip), counts [F] (device) the number of clips
+ * that contain each frame; mask[f][p] = acc[f][p] / counts[f] > thr, 0 where counts[f] == 0 (inference/main.py:93-103). */
+int stemseg_hip_fg_mask_frames(const float* acc, const float* counts, float thr, uint8_t* mask, int32_t F, int64_t HW,
+                               void* stream);
 
 /* online_chainer.py:11-22 + :258-281 : compact the foreground voxels of a clip.
  * emb [E][V], bw [Ev][V], seed [V] dense with V = T*HW, fg uint8 [V].  Point order = flat voxel order

@@ -272,6 +272,15 @@ __global__ void fg_mask_kernel(const float* acc, float count, float thr, unsigne
         mask[i] = (__fdiv_rn(acc[i], count) > thr) ? 1 : 0;
 }
 
+// all frames of a sequence at once: mask[f][p] = acc[f][p] / counts[f] > thr (counts[f] = clips that contain frame f; 0 -> background)
+__global__ void fg_mask_frames_kernel(const float* acc, const float* counts, float thr, unsigned char* mask, int F, long long HW) {
+    const long long n = (long long)F * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float c = counts[i / HW];
+        mask[i] = (c > 0.f && __fdiv_rn(acc[i], c) > thr) ? 1 : 0;
+    }
+}
+
 // ---- fg gather: count -> scan -> scatter ------------------------------------------------------------
 constexpr int GA_BLOCK = 1024;   // voxels per block (256 threads x 4)
 
@@ -445,6 +454,15 @@ extern "C" int stemseg_hip_fg_mask(const float* acc, float count, float thr, uin
     SS_CHECK_ARG(acc && mask && n >= 0 && count > 0.f, "fg_mask: bad arguments");
     if (n == 0) return STEMSEG_OK;
     hipLaunchKernelGGL(fg_mask_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, as_stream(stream), acc, count, thr, mask, (long long)n);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_fg_mask_frames(const float* acc, const float* counts, float thr, uint8_t* mask, int32_t F, int64_t HW, void* stream) {
+    SS_CHECK_ARG(acc && counts && mask && F >= 0 && HW >= 0, "fg_mask_frames: bad arguments");
+    if (F == 0 || HW == 0) return STEMSEG_OK;
+    hipLaunchKernelGGL(fg_mask_frames_kernel, dim3(grid_for((int64_t)F * HW, 256, 4096)), dim3(256), 0, as_stream(stream), acc, counts, thr, mask, F,
+                       (long long)HW);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }

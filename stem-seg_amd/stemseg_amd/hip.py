@@ -100,6 +100,7 @@ SIGNATURES = {
     "stemseg_hip_decoder_join": (C.c_int, [_I32, _P]),
     "stemseg_hip_seediness_accumulate": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "stemseg_hip_fg_mask": (C.c_int, [_P, _F, _F, _P, _I64, _P]),
+    "stemseg_hip_fg_mask_frames": (C.c_int, [_P, _P, _F, _P, _I32, _I64, _P]),
     "stemseg_hip_fg_gather": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "stemseg_hip_cluster_workspace_bytes": (C.c_size_t, [_I64]),
     "stemseg_hip_cluster": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, C.POINTER(ClusterParams), _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -326,6 +327,15 @@ def seediness_accumulate(acc, plane, first):
 def fg_mask(acc, count, thr):
     mask = torch.empty(acc.shape, dtype=torch.uint8, device=acc.device)
     check(lib().stemseg_hip_fg_mask(ptr(acc, torch.float32), float(count), float(thr), ptr(mask), acc.numel(), stream()))
+    return mask
+
+
+def fg_mask_frames(acc, counts, thr):
+    """acc float32 [F,h,w] (per-frame sums), counts float32 [F] on the device -> uint8 [F,h,w]: acc / counts > thr."""
+    Fn = acc.shape[0]
+    mask = torch.empty(acc.shape, dtype=torch.uint8, device=acc.device)
+    check(lib().stemseg_hip_fg_mask_frames(ptr(acc, torch.float32), ptr(counts, torch.float32), float(thr), ptr(mask), Fn,
+                                           acc[0].numel() if Fn else 0, stream()))
     return mask
 
 

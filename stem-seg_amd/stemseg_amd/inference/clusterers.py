@@ -7,8 +7,8 @@ constructor (inference/main.py:84-91), same call
 ``average_time``.  The <= 20 rounds of the reference's Python loop become max_instances + 2 kernel launches with a
 single host read-back (K and the instance list) at the end.
 """
+import time
 from collections import defaultdict
-from time import time as current_time
 
 import torch
 
@@ -16,43 +16,53 @@ from .. import hip
 
 
 class ClustererBase(object):
+    """Callable with a per-input-size wall-clock log -- the surface ``inference/main.py`` and the chainer use
+    (clusterers.py:7-31): ``clusterer(embeddings, ...)``, ``reset_time_log()``, ``average_time``, ``name``."""
+
+    _name = "clusterer"
+
     def __init__(self):
-        self._time_log = defaultdict(list)
+        self.reset_time_log()
+
+    def reset_time_log(self):
+        self._time_log = defaultdict(list)              # number of points -> [seconds per call]
 
     def __call__(self, embeddings, *args, **kwargs):
-        assert embeddings.dtype == torch.float32
-        t0 = current_time()
-        output = self._process(embeddings, *args, **kwargs)
-        self._time_log[embeddings.shape[0]].append(current_time() - t0)
-        return output
+        if embeddings.dtype != torch.float32:
+            raise AssertionError("embeddings must be float32, got %s" % embeddings.dtype)
+        started = time.time()
+        result = self._process(embeddings, *args, **kwargs)
+        self._time_log[int(embeddings.shape[0])].append(time.time() - started)
+        return result
 
     def _process(self, embeddings, *args, **kwargs):
         raise NotImplementedError("Must be implemented by derived class")
 
-    def reset_time_log(self):
-        self._time_log = defaultdict(list)
-
     @property
     def average_time(self):
-        all_times = sum(list(self._time_log.values()), [])
-        return sum(all_times) / float(len(all_times))
+        calls = [t for ts in self._time_log.values() for t in ts]
+        return sum(calls) / float(len(calls))
 
-    name = property(fget=lambda self: self._name)
+    @property
+    def name(self):
+        return self._name
 
 
 class SequentialClustering(ClustererBase):
+    _name = "SequentialClustering"
+
     def __init__(self, primary_prob_thresh, secondary_prob_thresh, min_seediness_prob, n_free_dims, free_dim_stds, device,
                  max_instances=20):
+        """Same arguments as the reference (clusterers.py:35-50; built at inference/main.py:84-91).  ``device`` is where inputs
+        that arrive on the host are moved for clustering."""
         super().__init__()
+        if n_free_dims and len(free_dim_stds) < n_free_dims:
+            raise AssertionError("%d free dims but only %d stds" % (n_free_dims, len(free_dim_stds)))
         self.thresholding_mode = "probability"
-        self.primary_prob_thresh = primary_prob_thresh
-        self.secondary_prob_thresh = secondary_prob_thresh
-        self.min_seediness_prob = min_seediness_prob
-        self.max_instances = max_instances
-        self.n_free_dims = n_free_dims
-        self.free_dim_stds = list(free_dim_stds)
+        self.primary_prob_thresh, self.secondary_prob_thresh = primary_prob_thresh, secondary_prob_thresh
+        self.min_seediness_prob, self.max_instances = min_seediness_prob, max_instances
+        self.n_free_dims, self.free_dim_stds = n_free_dims, list(free_dim_stds)
         self.device = device
-        assert len(self.free_dim_stds) >= n_free_dims or n_free_dims == 0
 
     def _params(self):
         return hip.make_cluster_params(self.primary_prob_thresh, self.secondary_prob_thresh, self.min_seediness_prob,

@@ -36,22 +36,24 @@ def get_subsequence_frames(seq_len, subseq_len, dataset_name, frame_overlap=-1):
 @torch.no_grad()
 def fg_masks_from_seediness(embedding_maps, threshold, device=None):
     """Mean seediness over the clips containing each frame, > threshold -> uint8 [n_frames, h, w] on the device
-    (inference/main.py:93-103).  Accumulation order = clip order, exactly like the reference's ``+=``."""
+    (inference/main.py:93-103).  One accumulate launch per clip (its T planes go to their frames' sums; clip order = the
+    reference's ``+=`` order) and ONE mask launch for the whole sequence."""
     hip.require_gpu()
-    acc, cnt = {}, {}
+    frames_all = sorted({t for entry in embedding_maps for t in entry[0]})
+    index = {t: i for i, t in enumerate(frames_all)}
+    acc, counts = None, [0.0] * len(frames_all)
     for entry in embedding_maps:
-        frames, seed = entry[0], entry[3]
-        seed = (seed if seed.is_cuda else seed.to(device if device is not None else "cuda")).contiguous()
-        for i, t in enumerate(frames):
-            plane = seed[0, i].contiguous()
-            if t not in acc:
-                acc[t] = torch.empty_like(plane)
-                hip.seediness_accumulate(acc[t], plane, True)
-                cnt[t] = 1.0
-            else:
-                hip.seediness_accumulate(acc[t], plane, False)
-                cnt[t] += 1.0
-    return torch.stack([hip.fg_mask(acc[t], cnt[t], threshold) for t in sorted(acc)], 0)
+        frames, seed = list(entry[0]), entry[3]
+        seed = (seed if seed.is_cuda else seed.to(device if device is not None else "cuda")).contiguous().float()
+        if acc is None:
+            acc = torch.zeros((len(frames_all), 1) + tuple(seed.shape[-2:]), dtype=torch.float32, device=seed.device)
+        assert len(set(frames)) == len(frames) and seed.shape[1] == len(frames)
+        hip.semseg_accumulate(acc, seed, [index[t] for t in frames])
+        for t in frames:
+            counts[index[t]] += 1.0
+    if acc is None:
+        return torch.zeros(0, dtype=torch.uint8)
+    return hip.fg_mask_frames(acc[:, 0], torch.tensor(counts, dtype=torch.float32).to(acc.device), threshold)
 
 
 class TrackGenerator(object):

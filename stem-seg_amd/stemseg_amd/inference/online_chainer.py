@@ -77,6 +77,7 @@ class HipChainerOps(object):
     device they arrive on (the model's); host tensors go to ``device`` (TrackGenerator's ``clustering_device``)."""
 
     def __init__(self, device=None):
+        self._offs_pinned = {}
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.index is None and torch.cuda.is_available():
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -99,8 +100,33 @@ class HipChainerOps(object):
         return labels, meta_dev, masks
 
     def read(self, pts, meta_dev):
-        offs = pts["offs"].cpu().tolist()                 # synchronises
-        return offs, hip.read_cluster_meta(meta_dev)
+        """Frame offsets + clustering record with ONE host synchronisation (both copies are enqueued, the record's read waits)."""
+        key = (pts["offs"].device.index, pts["offs"].numel())
+        buf = self._offs_pinned.get(key)
+        if buf is None:
+            buf = self._offs_pinned[key] = torch.empty(pts["offs"].numel(), dtype=torch.int64, pin_memory=True)
+        buf.copy_(pts["offs"], non_blocking=True)
+        meta = hip.read_cluster_meta(meta_dev)            # synchronises the stream
+        return buf.tolist(), meta
+
+    def label_sets(self, groups, cap):
+        """groups: lists of (device, int64) label arrays -> for each group the ascending ids > 0 that occur, with ONE read-back
+        for all of them (the reference's unique() per group, online_chainer.py:304-308, and the highest id of :43-49)."""
+        rows = []
+        dev = next((l.device for g in groups for l in g), self.device)
+        for g in groups:
+            ls = [l.contiguous() for l in g if l.numel() > 0]
+            if ls:
+                present, mx = hip.label_presence(ls, cap)
+                rows.append(torch.cat([present.to(torch.int64), mx]))
+            else:
+                rows.append(torch.zeros(cap + 1, dtype=torch.int64, device=dev))
+        host = torch.stack(rows).cpu()                    # the one read-back
+        out = []
+        for r in host:
+            assert int(r[-1]) <= cap, "label %d beyond the stated bound %d" % (int(r[-1]) - 1, cap)
+            out.append([i for i in torch.nonzero(r[:-1]).flatten().tolist() if i > 0])
+        return out
 
     def present_ids(self, labels_list, cap=None):
         """Ascending ids > 0 that occur in the (device, int64) label arrays -- the reference's ``unique()`` minus the outlier
@@ -124,8 +150,10 @@ class HipChainerOps(object):
             if ids:
                 t[torch.as_tensor(ids, dtype=torch.int64) + 1] = torch.arange(len(ids), dtype=torch.int32)
             return t.to(la.device)
-        inter, ca, cb = hip.overlap_counts(la.contiguous(), lb.contiguous(), lut(ids_a), lut(ids_b), len(ids_a), len(ids_b))
-        return inter.cpu().numpy(), ca.cpu().numpy(), cb.cpu().numpy()
+        Ka, Kb = len(ids_a), len(ids_b)
+        inter, ca, cb = hip.overlap_counts(la.contiguous(), lb.contiguous(), lut(ids_a), lut(ids_b), Ka, Kb)
+        host = torch.cat([inter.reshape(-1), ca, cb]).cpu().numpy()      # one read-back
+        return host[:Ka * Kb].reshape(Ka, Kb), host[Ka * Kb:Ka * Kb + Ka], host[Ka * Kb + Ka:]
 
     def relabel(self, labels, mapping):
         """mapping: dict old -> new.  In place."""
@@ -203,8 +231,10 @@ class OnlineChainer(object):
             if return_fg_embeddings:
                 fg_embeddings.append(pts["emb"][:offs[-1]].cpu())
 
+            id_bound = next_track_label + self.clusterer.max_instances        # every label of this clip is below it
             if i == 0:
-                next_track_label = track.add_labels(frames, labels_per_frame, max_label=ops.max_label(labels_per_frame))
+                (ids_new,) = ops.label_sets([labels_per_frame], id_bound)
+                next_track_label = track.add_labels(frames, labels_per_frame, max_label=self._max_of(ids_new, labels_per_frame))
                 subseq_meta.append(meta_info)
                 prev_frames = frames
                 subseq["embeddings"] = subseq["bandwidths"] = subseq["seediness"] = None
@@ -213,18 +243,24 @@ class OnlineChainer(object):
             overlap = sorted(set(frames).intersection(prev_frames))        # previous clip only (:201-202)
             existing = track.get_labels(overlap)
             current = [labels_per_frame[j] for j, t in enumerate(frames) if t in overlap]
-            associations = self.associate_clusters(existing, current, next_track_label + self.clusterer.max_instances)[0]
+            new_js = [j for j, t in enumerate(frames) if t not in overlap]
+            new_labels = [labels_per_frame[j] for j in new_js]
+            # one read-back: ids on the overlap frames (existing / current) and ids of the frames this clip adds
+            ids_1, ids_2, ids_new = ops.label_sets([existing, current, new_labels], id_bound)
+            associations = self._associate_ids(torch.cat(list(existing)), torch.cat(list(current)), ids_1, ids_2)[0] if ids_1 or ids_2 \
+                else []
             mapping = {cur: assoc for assoc, cur in associations}
-            new_frames, new_labels = [], []
-            for j, t in enumerate(frames):
-                if t in overlap:
-                    continue
-                if mapping:
-                    ops.relabel(labels_per_frame[j], mapping)
-                new_frames.append(t)
-                new_labels.append(labels_per_frame[j])
-            if new_frames:
-                next_track_label = track.add_labels(new_frames, new_labels, max_label=ops.max_label(new_labels))
+            if mapping and new_js:
+                # the added frames' labels are consecutive slices of the clip's label array: one launch per run of frames
+                run_start = prev = new_js[0]
+                for j in new_js[1:] + [None]:
+                    if j is None or j != prev + 1:
+                        ops.relabel(pts["labels"][offs[run_start]:offs[prev + 1]], mapping)
+                        run_start = j
+                    prev = j
+            if new_js:
+                mapped = [mapping.get(k, k) for k in ids_new]
+                next_track_label = track.add_labels([frames[j] for j in new_js], new_labels, max_label=self._max_of(mapped, new_labels))
             for assoc, cur in associations:
                 meta_info['instance_labels'][meta_info['instance_labels'].index(cur)] = assoc
             subseq_meta.append(meta_info)
@@ -247,8 +283,17 @@ class OnlineChainer(object):
         n = offs[-1]
         info = self.clusterer.meta_to_dict(meta, embeddings.shape[0], label_start, masks, None, n)
         assert labels.numel() >= n
+        pts["labels"] = labels
         per_frame = [labels[offs[j]:offs[j + 1]] for j in range(len(offs) - 1)]
         return per_frame, pts, info
+
+    @staticmethod
+    def _max_of(ids, labels_list):
+        """highest id among the labels being added, from the ids known to occur: -1 when there are points but only outliers,
+        None when there is no point at all (TrackContainer.add_labels, online_chainer.py:43-49)."""
+        if ids:
+            return max(ids)
+        return -1 if any(l.numel() > 0 for l in labels_list) else None
 
     def associate_clusters(self, labels_1, labels_2, id_bound=None):
         """Hungarian matching on 1 - IoU over the overlap frames (online_chainer.py:291-343).  Every returned pair is
@@ -261,8 +306,10 @@ class OnlineChainer(object):
             return [], set(), set(), np.zeros(0, np.float32), (np.zeros((0, 0), np.float32), [], [])
         # only the ids that occur on the overlap frames enter the statistics (the reference's unique(), :304-308): the table
         # is K1 x K2 <= a few hundred cells however large the track ids have grown
-        ids_1 = self.ops.present_ids([la], id_bound)
-        ids_2 = self.ops.present_ids([lb], id_bound)
+        return self._associate_ids(la, lb, self.ops.present_ids([la], id_bound), self.ops.present_ids([lb], id_bound))
+
+    def _associate_ids(self, la, lb, ids_1, ids_2):
+        assert la.shape == lb.shape, "Shape mismatch: {}, {}".format(la.shape, lb.shape)
         assert not set(ids_1).intersection(ids_2), "Labels overlap: {}, {}".format(ids_1, ids_2)
         inter, ca, cb = self.ops.overlap_counts(la, lb, ids_1, ids_2)
         I = inter.astype(np.float32).reshape(len(ids_1), len(ids_2))

@@ -55,6 +55,9 @@ class OracleChainerOps(object):
         assert cap is None or ids.size == 0 or ids.max() < cap
         return [int(i) for i in ids if i > 0]
 
+    def label_sets(self, groups, cap):
+        return [self.present_ids([l for l in g if l.numel() > 0], cap) if any(l.numel() > 0 for l in g) else [] for g in groups]
+
     def overlap_counts(self, la, lb, ids_a, ids_b):
         la, lb = la.numpy(), lb.numpy()
         inter = np.array([[np.sum((la == a) & (lb == b)) for b in ids_b] for a in ids_a], np.int64).reshape(len(ids_a), len(ids_b))
