@@ -148,19 +148,17 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
     frames = torch.cat([make_clip(5000 + i, device) for i in range(n_src)], 0)[:F].contiguous()      # same frames on every rank
     clips, _ = get_subsequence_frames(F, T, "davis", overlap)
     pipe.model.overlap_decoders = False
-    if args.no_graph:
-        def embed(fr):
-            return pipe.embed(frames[torch.as_tensor(fr, device=device)])
-    else:
-        g = pipe.capture_embed(frames[:T].contiguous())
+    eh = pipe.model._model.embedding_head
+    split = (eh.embedding_size, eh.variance_channels)
 
-        def embed(fr):
-            return g.run(frames[torch.as_tensor(fr, device=device)])
+    def embed_many(my_clips):                         # up to 4 clips per encoder pass, full batches as graph replays on two lanes
+        return pipe.embed_many(frames, my_clips, batch=max(1, args.clips_per_step), lanes=2, use_graph=not args.no_graph)
     chainer = pipe.tg.chainer
     stats, ag_ms, res = {}, [], None
 
     def one():
-        return run_sequence_sharded(F, embed, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats)
+        return run_sequence_sharded(F, None, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats,
+                                    embed_many_fn=embed_many, channel_split=split)
 
     def sync():
         torch.cuda.synchronize()
@@ -195,7 +193,7 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
             "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt round-robin "
                                    "to %d rank(s), %s, both decoders; all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + "
                                    "clustering + Hungarian stitching" % (F, overlap, n_clips, world, BACKBONE),
-                       "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "eager" if args.no_graph else "hipGraph replay",
+                       "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "%d clips per encoder pass, %s" % (max(1, args.clips_per_step), "eager" if args.no_graph else "full batches as hipGraph replays on 2 lanes"),
                        "switches": library_switches()},
             "exchange": {"collective": ("all_gather (%s)" % ("RCCL" if os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl" else
                                                              os.environ["STEMSEG_BENCH_BACKEND"] + ": functional check, ranks share a GPU")) if world > 1 else "none (one rank)", "bytes_received_per_rank": stats["allgather_bytes"],

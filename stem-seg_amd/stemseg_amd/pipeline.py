@@ -61,11 +61,52 @@ class ClipPipeline(object):
         return outs
 
     @torch.no_grad()
-    def capture_embed(self, example_frames, lane=0):
-        """hipGraph of ``embed`` alone (encoder + decoders + heads of one clip): for drivers that cluster later, e.g. the sharded
-        sequence path, where clustering waits for the cross-clip foreground mask.  ``run`` returns static (emb, bw, seed)
-        tensors that the next replay overwrites."""
-        return GraphedStep(self, example_frames, False, None, lane, embed_only=True)
+    def capture_embed(self, example_frames, n_clips=None, lane=0):
+        """hipGraph of the embedding alone (encoder + decoders + heads): for drivers that cluster later, e.g. the sharded
+        sequence path, where clustering waits for the cross-clip foreground mask.  ``n_clips``: that many clips stacked along the
+        frame axis share the encoder pass (``run`` then returns a list).  The outputs are static (emb, bw, seed) tensors that
+        the next replay overwrites."""
+        return GraphedStep(self, example_frames, False, n_clips, lane, embed_only=True)
+
+    @torch.no_grad()
+    def embed_many(self, frames, clips, batch=4, lanes=2, use_graph=True):
+        """Embeds the clips ``clips`` (lists of frame indices into ``frames`` [F,3,H,W], all of one length) ``batch`` at a time
+        through one encoder pass each, full batches as hipGraph replays alternating over ``lanes`` streams, the remainder
+        eagerly.  Returns per clip a [E+Ev+1, T, h4, w4] block (emb | bw | seed stacked) that the caller owns."""
+        dev = frames.device
+        out = [None] * len(clips)
+        groups = [list(range(i, min(i + batch, len(clips)))) for i in range(0, len(clips), batch)]
+        full = [g for g in groups if len(g) == batch] if use_graph and batch > 1 else []
+        if full:
+            key = (batch, len(clips[0]), tuple(frames.shape[1:]), lanes)
+            cache = self.__dict__.setdefault("_embed_graphs", {})
+            if key not in cache:
+                ex = frames[torch.as_tensor(sum([clips[c] for c in full[0]], []), device=dev)].contiguous()
+                cache[key] = [self.capture_embed(ex, n_clips=batch, lane=10 + k) for k in range(max(1, lanes))]
+            gs = cache[key]
+            pending = [None] * len(gs)
+
+            def collect(k):
+                if pending[k] is not None:
+                    gs[k].wait()
+                    for c, (emb, bw, seed) in zip(pending[k], gs[k].out):
+                        out[c] = torch.cat([emb, bw, seed], 0)
+                    pending[k] = None
+            for n, g in enumerate(full):
+                k = n % len(gs)
+                collect(k)                                   # the lane's previous outputs, before the replay overwrites them
+                gs[k].run_async(frames[torch.as_tensor(sum([clips[c] for c in g], []), device=dev)])
+                pending[k] = g
+            for k in range(len(gs)):
+                collect(k)
+        for g in groups:
+            if g in full:
+                continue
+            idx = torch.as_tensor(sum([clips[c] for c in g], []), device=dev)
+            res = self.model.embed_frames_batch(frames[idx].contiguous(), len(g)) if len(g) > 1 else [self.model.embed_frames(frames[idx].contiguous())]
+            for c, (emb, bw, seed) in zip(g, res):
+                out[c] = torch.cat([emb, bw, seed], 0)
+        return out
 
     def capture(self, example_frames, overlap=False, n_clips=None, lane=0):
         """Capture ``step`` for clips of ``example_frames``' shape into ONE hipGraph (~330 kernel nodes on a single stream:
@@ -86,7 +127,7 @@ class GraphedStep(object):
         pipe.model.set_lane(lane)
         fn = pipe.step if n_clips is None else (lambda x: pipe.step_batch(x, n_clips))     # n_clips: ``run`` returns a list
         if embed_only:
-            fn = pipe.embed
+            fn = pipe.embed if n_clips is None else (lambda x: pipe.model.embed_frames_batch(x.contiguous(), n_clips))
         prev = pipe.model.overlap_decoders
         pipe.model.overlap_decoders = bool(overlap)       # True = capture the fork/join branch streams too (experimental)
         try:
@@ -134,8 +175,10 @@ def shard_clips(n_clips, rank, world_size):
 
 @torch.no_grad()
 def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
-                         fg_mask_fn=None, group=None, stats=None):
-    """embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w], seed [1,T,h,w]) on this rank's device.
+                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None):
+    """embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w], seed [1,T,h,w]) on this rank's device; or
+    embed_many_fn(list of this rank's clips) -> list of stacked [E+Ev+1,T,h,w] blocks (e.g. ClipPipeline.embed_many: several clips
+    per encoder pass) together with channel_split = (E, Ev).
     Returns OnlineChainer.process(...) output, identical on every rank.  ``stats`` (dict, optional) receives the exchange's
     size and duration: ``allgather_bytes`` (payload received per rank), ``allgather_ms`` (device time of the collective on
     this rank), ``n_clips``, ``clips_this_rank``."""
@@ -149,7 +192,13 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     per_rank = (len(clips) + world - 1) // world
     packed = None
     E = Ev = None
-    for slot, ci in enumerate(mine):
+    if embed_many_fn is not None and mine:
+        E, Ev = channel_split
+        blocks = embed_many_fn([clips[ci] for ci in mine])
+        packed = torch.zeros((per_rank,) + tuple(blocks[0].shape), dtype=blocks[0].dtype, device=blocks[0].device)
+        for slot, blk in enumerate(blocks):
+            packed[slot] = blk
+    for slot, ci in enumerate(mine if embed_many_fn is None else []):
         emb, bw, seed = embed_clip_fn(clips[ci])
         if packed is None:
             E, Ev = emb.shape[0], bw.shape[0]

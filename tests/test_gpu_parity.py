@@ -1214,6 +1214,35 @@ def test_sequence_end_to_end_tracks_and_masks(hip):
         config.load_preset("defaults")
 
 
+def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
+    """ClipPipeline.embed_many (the sharded sequence driver's embedding: several clips per encoder pass, full batches as hipGraph
+    replays alternating over two lanes, the remainder eagerly) returns, clip for clip, what embedding each clip on its own gives
+    (<= 1e-5: the batched encoder pass uses other launch shapes), in the caller's clip order, and identically when repeated."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset("davis")
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        model = InferenceModel()
+        names = [(k, v.shape) for k, v in model._model.state_dict().items()]
+        sd = synth.synth_state_dict(names, 3)
+        model._model.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(model._model.state_dict()[k].shape) for k, v in sd.items()})
+        pipe = ClipPipeline(model)
+        frames = (torch.from_numpy(synth.synth_frames(24, 64, 96, seed=3).astype(np.float32)).permute(0, 3, 1, 2) - 110.0).cuda().contiguous()
+        clips = [list(range(s, s + 8)) for s in (0, 4, 8, 12, 16)]
+        ref = [torch.cat(pipe.embed(frames[c].contiguous()), 0).clone() for c in clips]
+        got = pipe.embed_many(frames, clips, batch=2, lanes=2)
+        again = pipe.embed_many(frames, clips, batch=2, lanes=2)
+        eager = pipe.embed_many(frames, clips, batch=2, lanes=2, use_graph=False)
+        torch.cuda.synchronize()
+        for i in range(len(clips)):
+            assert report("embed_many clip %d vs per-clip" % i, got[i].cpu().numpy(), ref[i].cpu().numpy()) <= 1e-5
+            assert torch.equal(got[i], again[i]) and torch.equal(got[i], eager[i])
+    finally:
+        config.load_preset("defaults")
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("size", [(96, 160), (256, 448)])
 def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
