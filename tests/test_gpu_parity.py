@@ -1237,7 +1237,9 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
         eager = pipe.embed_many(frames, clips, batch=2, lanes=2, use_graph=False)
         torch.cuda.synchronize()
         for i in range(len(clips)):
-            assert report("embed_many clip %d vs per-clip" % i, got[i].cpu().numpy(), ref[i].cpu().numpy()) <= 1e-5
+            g_, r_ = got[i].cpu().numpy(), ref[i].cpu().numpy()
+            scale = np.maximum(1.0, np.abs(r_))                      # (bandwidth channels are exp(.) * 10: compare relatively)
+            assert report("embed_many clip %d vs per-clip (rel)" % i, g_ / scale, r_ / scale) <= 1e-5
             assert torch.equal(got[i], again[i]) and torch.equal(got[i], eager[i])
     finally:
         config.load_preset("defaults")
