@@ -14,9 +14,9 @@ are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line 
 
     python bench.py --sequence [--frames 64|36]      # BASELINE configs[3]: ONE long sequence sharded over the ranks
 
---sequence: a step = the whole sequence through ``pipeline.run_sequence_sharded`` -- clips dealt round-robin to the ranks
-(64 frames / overlap 4 -> 15 clips; 36 frames -> exactly 8, one per GPU at N = 8), every rank embeds its clips (hipGraph
-replay of encoder + decoders + heads), ONE all-gather (RCCL over xGMI) of the head outputs INSIDE the timed region, then the
+--sequence: a step = the whole sequence through ``pipeline.run_sequence_sharded`` -- clips dealt to the ranks in contiguous blocks
+(64 frames / overlap 4 -> 15 clips; 36 frames -> exactly 8, one per GPU at N = 8), every rank embeds its block of clips (up to 4
+per encoder pass; frames shared by neighbouring clips pass the trunk once; full batches as hipGraph replays), ONE all-gather (RCCL over xGMI) of the head outputs INSIDE the timed region, then the
 replicated chain (cross-clip fg mask, clustering, Hungarian stitching).  value = clips / s of the whole job (strong scaling:
 the sequence is fixed); the line also carries the all-gather's bytes / time and a checksum of the stitched track labels that
 must be the same at every N.  The default mode and this one share the model, weights and kernels.
@@ -190,7 +190,7 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
             "value": round(n_clips * args.steps / dt, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt round-robin "
+            "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt in contiguous blocks "
                                    "to %d rank(s), %s, both decoders; all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + "
                                    "clustering + Hungarian stitching" % (F, overlap, n_clips, world, BACKBONE),
                        "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "%d clips per encoder pass, %s" % (max(1, args.clips_per_step), "eager" if args.no_graph else "full batches as hipGraph replays on 2 lanes"),
@@ -233,7 +233,7 @@ def main():
                     help="captured steps in flight on one GPU, each with its own workspaces and stream (graph mode): the kernels of "
                          "one step fill the tail rounds and memory-bound phases of the other")
     ap.add_argument("--sequence", action="store_true",
-                    help="BASELINE configs[3]: one long sequence, clips sharded round-robin over the ranks, RCCL all-gather of the head "
+                    help="BASELINE configs[3]: one long sequence, clips sharded over the ranks in contiguous blocks, RCCL all-gather of the head "
                          "outputs inside the timed region, replicated stitching (see the module docstring)")
     ap.add_argument("--frames", type=int, default=64, help="--sequence: frames of the sequence (64 -> 15 clips at overlap 4; 36 -> 8)")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 1
+#define STEMSEG_HIP_ABI_VERSION 2
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -224,6 +224,12 @@ typedef struct StemsegEncoderDesc {
     int32_t n_clips;             /* >= 1: the T frames are n_clips consecutive clips of T / n_clips frames; each clip's four maps
                                     go to their own output volumes (frames are independent in the encoder, so several clips
                                     share one pass: layer3 / layer4 launches grow from 0.4 to n_clips x 0.4 waves of the chip) */
+    int32_t clip_frames;         /* 0: T / n_clips.  > 0 with clip_stride > 0: the clips are OVERLAPPING windows of clip_frames
+                                    frames every clip_stride frames of the pass ((n_clips - 1) * clip_stride + clip_frames == T),
+                                    the way inference/main.py:23-49 cuts a sequence: a frame shared by two clips goes through
+                                    the trunk once (the reference's cross-clip feature cache, inference_model.py:83-108) and
+                                    only the per-clip FPN output convs run once per clip */
+    int32_t clip_stride;
 } StemsegEncoderDesc;
 
 typedef struct StemsegEncoderWeights {
@@ -241,7 +247,7 @@ typedef struct StemsegEncoderWeights {
 size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* desc);
 int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
 /* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[4 * c + k], c < n_clips, k = 0..3: the four FPN maps (4x, 8x, 16x,
- * 32x) of clip c as volumes [256][T / n_clips][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed
+ * 32x) of clip c as volumes [256][clip frames][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed
  * inputs (then no copy is needed). */
 int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEncoderWeights* weights, const float* frames,
                                 const StemsegVolume* out, void* workspace, size_t ws_bytes, void* stream);

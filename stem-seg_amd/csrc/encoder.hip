@@ -177,7 +177,13 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     SS_CHECK_ARG(d, "encoder: null descriptor");
     SS_CHECK_ARG(d->struct_bytes == (int32_t)sizeof(StemsegEncoderDesc), "encoder: descriptor size mismatch (%d vs %d): ABI skew",
                  d->struct_bytes, (int)sizeof(StemsegEncoderDesc));
-    SS_CHECK_ARG(d->n_clips >= 1 && d->T % d->n_clips == 0, "encoder: T=%d is not n_clips=%d whole clips", d->T, d->n_clips);
+    SS_CHECK_ARG(d->n_clips >= 1 && d->clip_frames >= 0 && d->clip_stride >= 0, "encoder: bad clip layout");
+    if (d->clip_frames > 0) {
+        SS_CHECK_ARG(d->clip_stride > 0 && (d->n_clips - 1) * d->clip_stride + d->clip_frames == d->T,
+                     "encoder: %d windows of %d frames every %d frames do not cover T=%d", d->n_clips, d->clip_frames, d->clip_stride, d->T);
+    } else {
+        SS_CHECK_ARG(d->T % d->n_clips == 0, "encoder: T=%d is not n_clips=%d whole clips", d->T, d->n_clips);
+    }
     SS_CHECK_ARG(d->T >= 1 && d->H >= 32 && d->W >= 32 && d->H % 32 == 0 && d->W % 32 == 0, "encoder: T=%d H=%d W=%d (H, W multiples of 32)", d->T, d->H, d->W);
     p.T = d->T; p.H = d->H; p.W = d->W;
     p.total_blocks = 0;
@@ -248,8 +254,9 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
     for (int i = 0; i < 4; ++i) {
         for (int c = 0; c < desc->n_clips; ++c) {
             const StemsegVolume& o = out[4 * c + i];
-            SS_CHECK_ARG(o.ptr && o.C == desc->out_channels && o.T == p.T / desc->n_clips && o.H == p.h[i] && o.W == p.w[i],
-                         "encoder_forward: output volume %d of clip %d must be [%d][%d][%d][%d]", i, c, desc->out_channels, p.T / desc->n_clips, p.h[i], p.w[i]);
+            const int Tc_ = desc->clip_frames > 0 ? desc->clip_frames : p.T / desc->n_clips;
+            SS_CHECK_ARG(o.ptr && o.C == desc->out_channels && o.T == Tc_ && o.H == p.h[i] && o.W == p.w[i],
+                         "encoder_forward: output volume %d of clip %d must be [%d][%d][%d][%d]", i, c, desc->out_channels, Tc_, p.h[i], p.w[i]);
         }
         SS_CHECK_ARG(wts->fpn_inner_w[i] && wts->fpn_inner_b[i] && wts->fpn_layer_w[i] && wts->fpn_layer_b[i], "encoder_forward: null FPN weights %d", i);
     }
@@ -337,11 +344,12 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             SS_LAUNCH_CHECK();
         }
         // the output conv runs once per clip: each clip's map goes to its own (usually zero-haloed) consumer volume
-        const int Tc = T / desc->n_clips;
+        const int Tc = desc->clip_frames > 0 ? desc->clip_frames : T / desc->n_clips;
+        const int Ts = desc->clip_frames > 0 ? desc->clip_stride : Tc;          // first frame of clip c within the pass: c * Ts
         for (int c = 0; c < desc->n_clips; ++c) {
             StemsegVolume in = halo2d_view(ws + p.L[k], 256, T, h, w);
-            in.ptr += (int64_t)c * Tc * in.t_stride;
-            in.limit -= (int64_t)c * Tc * in.t_stride;
+            in.ptr += (int64_t)c * Ts * in.t_stride;
+            in.limit -= (int64_t)c * Ts * in.t_stride;
             in.T = Tc;
             rc = launch_conv3d(in, wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[4 * c + k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &el);
             if (rc) return rc;

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstemseg_hip.so")
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Volume(C.Structure):
@@ -47,7 +47,8 @@ class ConvEpilogue(C.Structure):
 
 class EncoderDesc(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("blocks", C.c_int32 * 4), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("out_channels", C.c_int32), ("precision", C.c_int32), ("n_clips", C.c_int32)]
+                ("out_channels", C.c_int32), ("precision", C.c_int32), ("n_clips", C.c_int32), ("clip_frames", C.c_int32),
+                ("clip_stride", C.c_int32)]
 
 
 _BLK = C.c_void_p * MAX_ENCODER_BLOCKS

@@ -169,27 +169,34 @@ class ResNetFPN(nn.Module):
         self._packed, self._sig = (w, keep), sig
         return self._packed
 
-    def _desc(self, T, H, W, n_clips=1):
+    def _desc(self, T, H, W, n_clips=1, clip_frames=0, clip_stride=0):
         d = hip.EncoderDesc()
         d.struct_bytes = C.sizeof(hip.EncoderDesc)
         for i, n in enumerate(self.stage_blocks):
             d.blocks[i] = n
         d.T, d.H, d.W, d.out_channels = T, H, W, self.out_channels
         d.precision = hip.PRECISIONS[self.precision]
-        d.n_clips = n_clips
+        d.n_clips, d.clip_frames, d.clip_stride = n_clips, clip_frames, clip_stride
         return d
 
     @torch.no_grad()
-    def run_backbone_into(self, frames, out_volumes):
+    def run_backbone_into(self, frames, out_volumes, window=None):
         """frames: float32 [T,3,H,W] on the device; out_volumes: 4 ``hip.Volume`` (4x, 8x, 16x, 32x), each
         [256][T][H/s][W/s] -- e.g. the interiors of the decoders' zero-haloed inputs.  With 4 * n volumes the T frames are n
-        consecutive clips of T / n frames sharing one encoder pass; volumes 4c .. 4c+3 receive clip c."""
+        consecutive clips of T / n frames sharing one encoder pass; volumes 4c .. 4c+3 receive clip c.  ``window`` =
+        (clip_frames, clip_stride): the n clips are overlapping windows of the pass (shared frames go through the trunk once)."""
         hip.require_gpu()
         frames = frames.contiguous().float()
         T, _, H, W = frames.shape
         w, _keep = self._pack()
-        assert len(out_volumes) % 4 == 0 and T % (len(out_volumes) // 4) == 0
-        d = self._desc(T, H, W, len(out_volumes) // 4)
+        n = len(out_volumes) // 4
+        assert len(out_volumes) % 4 == 0
+        if window is None:
+            assert T % n == 0
+            d = self._desc(T, H, W, n)
+        else:
+            assert (n - 1) * window[1] + window[0] == T, "windows do not cover the pass"
+            d = self._desc(T, H, W, n, int(window[0]), int(window[1]))
         key = (T, H, W, frames.device.index, self.lane)
         ws = self._ws.get(key)
         if ws is None:

@@ -177,6 +177,26 @@ class InferenceModel(nn.Module):
         return [self._run_heads(pads[c], T, H, W, dev) for c in range(n_clips)]
 
     @torch.no_grad()
+    def embed_frames_windows(self, frames, n_clips, clip_frames, clip_stride):
+        """``n_clips`` OVERLAPPING clips in one encoder pass: frames float32 [(n_clips - 1) * clip_stride + clip_frames, 3, H, W]
+        (a run of consecutive sequence frames), clip c = frames [c * clip_stride, c * clip_stride + clip_frames) -- the windows
+        inference/main.py:23-49 cuts.  A frame shared by two clips goes through the encoder trunk once (what the reference's
+        cross-clip feature cache does, inference_model.py:83-108); only the per-clip FPN output convs and everything after
+        run per clip.  -> list of (emb, bw, seed)."""
+        hip.require_gpu()
+        m = self._model
+        NT, _, H, W = frames.shape
+        assert NT == (n_clips - 1) * clip_stride + clip_frames
+        T, dev, Cn = clip_frames, frames.device, m.backbone.out_channels
+        pads = [self._padded_feature_buffers(T, H, W, dev, slot=c) for c in range(n_clips)]
+        vols = []
+        for c in range(n_clips):
+            v = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads[c], (32, 16, 8, 4))}
+            vols += [v[s] for s in (4, 8, 16, 32)]
+        m.backbone.run_backbone_into(frames, vols, window=(clip_frames, clip_stride))
+        return [self._run_heads(pads[c], T, H, W, dev) for c in range(n_clips)]
+
+    @torch.no_grad()
     def _run_heads(self, pads, T, H, W, dev):
         m = self._model
         feats = ([b for b, _ in pads], (T, H // 4, W // 4))

@@ -3,8 +3,8 @@
 * ``ClipPipeline.step`` is BASELINE.json's unit of work: one T-frame clip through encoder -> two 3-D decoders ->
   fused heads -> fg mask -> fg gather -> sequential clustering, all enqueued on one HIP stream with no host
   synchronisation (N, K and the instance list stay on the device until the caller reads them).
-* ``run_sequence_sharded`` is the one-process-per-GPU form for long sequences: clips are dealt round-robin to
-  ranks, every rank embeds its own clips, ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests)
+* ``run_sequence_sharded`` is the one-process-per-GPU form for long sequences: every rank takes a contiguous block of
+  the clips and embeds it (frames shared by neighbouring clips of the block pass the encoder trunk once), ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests)
   exchanges the per-clip head outputs (<= 5.8 MB per clip at 480p), and the cheap chain (fg mask from the
   cross-clip mean seediness, clustering, Hungarian stitching: < 1 % of the work) is replicated so every rank
   ends with the single-process result bit for bit.
@@ -69,20 +69,37 @@ class ClipPipeline(object):
         return GraphedStep(self, example_frames, False, n_clips, lane, embed_only=True)
 
     @torch.no_grad()
-    def embed_many(self, frames, clips, batch=4, lanes=2, use_graph=True):
+    def embed_many(self, frames, clips, batch=4, lanes=2, use_graph=True, share_overlap=True):
         """Embeds the clips ``clips`` (lists of frame indices into ``frames`` [F,3,H,W], all of one length) ``batch`` at a time
         through one encoder pass each, full batches as hipGraph replays alternating over ``lanes`` streams, the remainder
-        eagerly.  Returns per clip a [E+Ev+1, T, h4, w4] block (emb | bw | seed stacked) that the caller owns."""
+        eagerly.  When the clips are consecutive windows of the sequence (constant stride, as get_subsequence_frames cuts them)
+        and ``share_overlap``, a pass covers the windows' UNION of frames: shared frames go through the encoder trunk once.
+        Returns per clip a [E+Ev+1, T, h4, w4] block (emb | bw | seed stacked) that the caller owns."""
         dev = frames.device
         out = [None] * len(clips)
+        T = len(clips[0])
+        stride = clips[1][0] - clips[0][0] if len(clips) > 1 else T
+        windows = bool(share_overlap) and 0 < stride < T and all(
+            list(c) == list(range(clips[0][0] + i * stride, clips[0][0] + i * stride + T)) for i, c in enumerate(clips))
         groups = [list(range(i, min(i + batch, len(clips)))) for i in range(0, len(clips), batch)]
+
+        def pass_frames(g):                                 # frame indices of one encoder pass
+            if windows:
+                return list(range(clips[g[0]][0], clips[g[-1]][-1] + 1))
+            return sum([list(clips[c]) for c in g], [])
+
+        def embed_pass(x, n):
+            if windows and n > 1:
+                return self.model.embed_frames_windows(x, n, T, stride)
+            return self.model.embed_frames_batch(x, n) if n > 1 else [self.model.embed_frames(x)]
         full = [g for g in groups if len(g) == batch] if use_graph and batch > 1 else []
         if full:
-            key = (batch, len(clips[0]), tuple(frames.shape[1:]), lanes)
+            key = (batch, T, stride if windows else 0, tuple(frames.shape[1:]), lanes)
             cache = self.__dict__.setdefault("_embed_graphs", {})
             if key not in cache:
-                ex = frames[torch.as_tensor(sum([clips[c] for c in full[0]], []), device=dev)].contiguous()
-                cache[key] = [self.capture_embed(ex, n_clips=batch, lane=10 + k) for k in range(max(1, lanes))]
+                ex = frames[torch.as_tensor(pass_frames(full[0]), device=dev)].contiguous()
+                cache[key] = [GraphedStep(self, ex, False, batch, 10 + k, embed_fn=lambda x: embed_pass(x.contiguous(), batch))
+                              for k in range(max(1, lanes))]
             gs = cache[key]
             pending = [None] * len(gs)
 
@@ -95,15 +112,14 @@ class ClipPipeline(object):
             for n, g in enumerate(full):
                 k = n % len(gs)
                 collect(k)                                   # the lane's previous outputs, before the replay overwrites them
-                gs[k].run_async(frames[torch.as_tensor(sum([clips[c] for c in g], []), device=dev)])
+                gs[k].run_async(frames[torch.as_tensor(pass_frames(g), device=dev)])
                 pending[k] = g
             for k in range(len(gs)):
                 collect(k)
         for g in groups:
             if g in full:
                 continue
-            idx = torch.as_tensor(sum([clips[c] for c in g], []), device=dev)
-            res = self.model.embed_frames_batch(frames[idx].contiguous(), len(g)) if len(g) > 1 else [self.model.embed_frames(frames[idx].contiguous())]
+            res = embed_pass(frames[torch.as_tensor(pass_frames(g), device=dev)].contiguous(), len(g))
             for c, (emb, bw, seed) in zip(g, res):
                 out[c] = torch.cat([emb, bw, seed], 0)
         return out
@@ -120,7 +136,7 @@ class ClipPipeline(object):
 
 
 class GraphedStep(object):
-    def __init__(self, pipe, example_frames, overlap=False, n_clips=None, lane=0, embed_only=False):
+    def __init__(self, pipe, example_frames, overlap=False, n_clips=None, lane=0, embed_only=False, embed_fn=None):
         self.pipe = pipe
         self.lane = lane
         self.stream = torch.cuda.Stream(device=example_frames.device)       # replays of this lane are ordered on this stream
@@ -128,6 +144,8 @@ class GraphedStep(object):
         fn = pipe.step if n_clips is None else (lambda x: pipe.step_batch(x, n_clips))     # n_clips: ``run`` returns a list
         if embed_only:
             fn = pipe.embed if n_clips is None else (lambda x: pipe.model.embed_frames_batch(x.contiguous(), n_clips))
+        if embed_fn is not None:
+            fn = embed_fn
         prev = pipe.model.overlap_decoders
         pipe.model.overlap_decoders = bool(overlap)       # True = capture the fork/join branch streams too (experimental)
         try:
@@ -169,8 +187,20 @@ class GraphedStep(object):
 
 # ------------------------------------------------------------------------------------------------ multi-GPU
 def shard_clips(n_clips, rank, world_size):
-    """Round-robin deal: clip i -> rank i % world_size."""
-    return [i for i in range(n_clips) if i % world_size == rank]
+    """Balanced CONTIGUOUS blocks (sizes differ by at most one): a rank's clips are consecutive windows of the sequence, so the
+    frames two of them share go through that rank's encoder trunk once (ClipPipeline.embed_many)."""
+    q, rem = divmod(n_clips, world_size)
+    start = rank * q + min(rank, rem)
+    return list(range(start, start + q + (1 if rank < rem else 0)))
+
+
+def clip_owner(ci, n_clips, world_size):
+    """-> (rank, slot within the rank's block) of clip ``ci`` under shard_clips."""
+    q, rem = divmod(n_clips, world_size)
+    edge = rem * (q + 1)
+    if ci < edge:
+        return ci // (q + 1), ci % (q + 1)
+    return rem + (ci - edge) // max(q, 1), (ci - edge) % max(q, 1)
 
 
 @torch.no_grad()
@@ -237,7 +267,8 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
         stats.update(allgather_ms=ag_ms, allgather_bytes=ag_bytes, n_clips=len(clips), clips_this_rank=len(mine), world=world)
     entries = []
     for ci, frames in enumerate(clips):
-        blk = gathered[ci % world][ci // world]
+        owner, slot = clip_owner(ci, len(clips), world)
+        blk = gathered[owner][slot]
         uniq = sorted(set(frames))
         if len(uniq) != len(frames):
             sel = torch.as_tensor([max(j for j, v in enumerate(frames) if v == t) for t in uniq], device=blk.device)

@@ -65,7 +65,13 @@ def test_sharded_sequence_two_ranks_gloo(tag):
     assert sum(r[2] for r in res) == n_clips
 
 
-def test_shard_clips_round_robin():
-    from stemseg_amd.pipeline import shard_clips
-    assert shard_clips(15, 0, 8) == [0, 8] and shard_clips(15, 7, 8) == [7] and shard_clips(3, 5, 8) == []
-    assert sorted(sum((shard_clips(29, r, 8) for r in range(8)), [])) == list(range(29))
+def test_shard_clips_contiguous_blocks():
+    """Each rank takes a contiguous, balanced block (neighbouring clips share frames: one trunk pass per shared frame)."""
+    from stemseg_amd.pipeline import clip_owner, shard_clips
+    assert shard_clips(15, 0, 8) == [0, 1] and shard_clips(15, 6, 8) == [12, 13] and shard_clips(15, 7, 8) == [14]
+    assert shard_clips(8, 3, 8) == [3] and shard_clips(3, 5, 8) == [] and shard_clips(3, 2, 8) == [2]
+    for n in (1, 5, 8, 9, 15, 16, 29):
+        for w in (1, 2, 3, 8):
+            blocks = [shard_clips(n, r, w) for r in range(w)]
+            assert sum(blocks, []) == list(range(n)) and max(map(len, blocks)) - min(map(len, blocks)) <= 1
+            assert all(clip_owner(ci, n, w) == (r, k) for r, b in enumerate(blocks) for k, ci in enumerate(b))

@@ -1232,11 +1232,16 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
         frames = (torch.from_numpy(synth.synth_frames(24, 64, 96, seed=3).astype(np.float32)).permute(0, 3, 1, 2) - 110.0).cuda().contiguous()
         clips = [list(range(s, s + 8)) for s in (0, 4, 8, 12, 16)]
         ref = [torch.cat(pipe.embed(frames[c].contiguous()), 0).clone() for c in clips]
-        got = pipe.embed_many(frames, clips, batch=2, lanes=2)
+        got = pipe.embed_many(frames, clips, batch=2, lanes=2)                       # overlapping windows: shared frames encoded once
         again = pipe.embed_many(frames, clips, batch=2, lanes=2)
         eager = pipe.embed_many(frames, clips, batch=2, lanes=2, use_graph=False)
+        stacked = pipe.embed_many(frames, clips, batch=2, lanes=2, share_overlap=False)     # every clip's frames stacked per pass
+        three = pipe.embed_many(frames, clips, batch=3, lanes=1)                     # 3 windows per pass (20 frames) + 2 eagerly
         torch.cuda.synchronize()
         for i in range(len(clips)):
+            for other in (stacked, three):
+                sc = np.maximum(1.0, np.abs(ref[i].cpu().numpy()))
+                assert float(np.abs((other[i] - ref[i]).cpu().numpy() / sc).max()) <= 1e-5
             g_, r_ = got[i].cpu().numpy(), ref[i].cpu().numpy()
             scale = np.maximum(1.0, np.abs(r_))                      # (bandwidth channels are exp(.) * 10: compare relatively)
             assert report("embed_many clip %d vs per-clip (rel)" % i, g_ / scale, r_ / scale) <= 1e-5
