@@ -226,7 +226,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the step (use under rocprofv3)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)      # (the default; kept for old command lines)
-    ap.add_argument("--clips-per-step", type=int, default=4,
+    ap.add_argument("--clips-per-step", type=int, default=None,
                     help="clips that share one encoder pass per step (frames are independent in the encoder; stacking clips fills "
                          "its small-map launches); decoders, fg gather and clustering run per clip.  1 = one clip per step")
     ap.add_argument("--lanes", type=int, default=3,
@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
     args.graph = not args.no_graph
+    if args.clips_per_step is None:          # default: 4 independent clips per encoder pass; --sequence: 8 overlapping windows (36 frames)
+        args.clips_per_step = 8 if args.sequence else 4
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
