@@ -128,6 +128,43 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
     }
 }
 
+// 16-B forms (W % 8 == 0, aligned planes): one thread = 4 consecutive outputs of one row; 32-bit index arithmetic (n_items =
+// output rows over all planes x float4 pieces per row).
+__global__ __launch_bounds__(256) void maxpool3x3s2_vec4_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, unsigned n_items) {
+    const int Ho = H / 2, Wo = W / 2;
+    const unsigned wq = Wo / 4, idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_items) return;
+    const unsigned row = idx / wq;                         // plane * Ho + y
+    const int j = (int)(idx - row * wq);
+    const unsigned pl = row / (unsigned)Ho, y = row - pl * (unsigned)Ho;
+    const float* p = in + (size_t)pl * H * W;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = 2 * (int)y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const float* r = p + (size_t)yy * W + 8 * j;       // inputs 8j-1 .. 8j+7 feed outputs 4j .. 4j+3
+        const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
+        const float left = j > 0 ? r[-1] : -INFINITY;
+        m[0] = fmaxf(m[0], fmaxf(left, fmaxf(a.x, a.y)));
+        m[1] = fmaxf(m[1], fmaxf(a.y, fmaxf(a.z, a.w)));
+        m[2] = fmaxf(m[2], fmaxf(a.w, fmaxf(b.x, b.y)));
+        m[3] = fmaxf(m[3], fmaxf(b.y, fmaxf(b.z, b.w)));
+    }
+    *reinterpret_cast<float4*>(out + (size_t)row * Wo + 4 * j) = make_float4(m[0], m[1], m[2], m[3]);
+}
+__global__ __launch_bounds__(256) void subsample2_vec4_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W, unsigned n_items) {
+    const int Ho = H / 2, Wo = W / 2;
+    const unsigned wq = Wo / 4, idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_items) return;
+    const unsigned row = idx / wq;
+    const int j = (int)(idx - row * wq);
+    const unsigned pl = row / (unsigned)Ho, y = row - pl * (unsigned)Ho;
+    const float* r = in + (size_t)pl * H * W + (size_t)(2 * y) * W + 8 * j;
+    const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
+    *reinterpret_cast<float4*>(out + (size_t)row * Wo + 4 * j) = make_float4(a.x, a.z, b.x, b.z);
+}
+
 // out[pl][y][x] = in[pl][2y][2x]   (shared input of a stride-2 block's conv1 and projection shortcut)
 __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int H, int W) {
     const int Ho = H / 2, Wo = W / 2;
@@ -276,7 +313,12 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         profile_end(ev, s);
         SS_LAUNCH_CHECK();
         ev = profile_begin(48, 4.0 * 64.0 * T * ((double)Ho * Wo + (double)p.V[0] / T), s);
-        hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid1d(64 * p.V[0])), dim3(256), 0, s, (const float*)(ws + p.S0), ws + p.X1, (int64_t)64 * T, Ho, Wo);
+        const int64_t mp_items = (int64_t)64 * T * (Ho / 2) * (Wo / 8);
+        if (Wo % 8 == 0 && mp_items < (1ll << 31))
+            hipLaunchKernelGGL(maxpool3x3s2_vec4_kernel, dim3((unsigned)ceil_div(mp_items, 256)), dim3(256), 0, s, (const float*)(ws + p.S0), ws + p.X1, Ho,
+                               Wo, (unsigned)mp_items);
+        else
+            hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid1d(64 * p.V[0])), dim3(256), 0, s, (const float*)(ws + p.S0), ws + p.X1, (int64_t)64 * T, Ho, Wo);
         profile_end(ev, s);
         SS_LAUNCH_CHECK();
     }
@@ -294,7 +336,12 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             float* xin = x;
             if (stride2) {
                 void* ev = profile_begin(49, 4.0 * 2.0 * (double)cin * V, s);       // (the kept quarter is read, sector granularity aside)
-                hipLaunchKernelGGL(subsample2_kernel, dim3(grid1d((int64_t)cin * V)), dim3(256), 0, s, (const float*)x, ws + p.XS, (int64_t)cin * T, 2 * h, 2 * w);
+                const int64_t ss_items = (int64_t)cin * T * h * (w / 4);
+                if (w % 4 == 0 && ss_items < (1ll << 31))
+                    hipLaunchKernelGGL(subsample2_vec4_kernel, dim3((unsigned)ceil_div(ss_items, 256)), dim3(256), 0, s, (const float*)x, ws + p.XS, 2 * h,
+                                       2 * w, (unsigned)ss_items);
+                else
+                    hipLaunchKernelGGL(subsample2_kernel, dim3(grid1d((int64_t)cin * V)), dim3(256), 0, s, (const float*)x, ws + p.XS, (int64_t)cin * T, 2 * h, 2 * w);
                 profile_end(ev, s);
                 SS_LAUNCH_CHECK();
                 xin = ws + p.XS;
