@@ -1175,7 +1175,10 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     }
     if (tile_cfg == 4) return launch_gl<K1N7GL, K1N7>(8, p, s, scratch, scratch_floats);                                      // (tests / sweeps)
     // big un-decoded 1x1 launches: same round-based cut as the 3x3 convs, along the flat voxel row
-    const bool plan1 = !flat && (tile_cfg <= 0 || tile_cfg > 2) && scratch != nullptr;
+    // ... but only where the conv is matrix-core bound: the cut trades slab traffic for MFMA rounds, and a short-K expansion
+    // (64 -> 256, 128 -> 512 + residual: ~14-25 FLOP per byte of its own tensors) is bound by exactly that traffic
+    const double flop_per_byte = 2.0 * p.Cin * p.Cout / (4.0 * (p.Cin + p.Cout * (p.res ? 2.0 : 1.0)));
+    const bool plan1 = !flat && (tile_cfg <= 0 || tile_cfg > 2) && scratch != nullptr && flop_per_byte >= 40.0;
     const bool gl1 = (glds_mask() & 8) && p.vec4 && p.Cin % 16 == 0 && p.Cout % 128 == 0;
     if (cfg == 1) {
         if (plan1 && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) {
