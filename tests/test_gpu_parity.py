@@ -421,7 +421,7 @@ def _emb_head(mode, E, tanh, seed_out, T, wseed):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("T", [8, 16, 4])
+@pytest.mark.parametrize("T", [8, 16, 4, 2, 24])
 def test_embedding_decoder_vs_golden_and_oracle(hip, golden, T):
     g = golden("decoder_T%d" % T)
     for name in [k for k in g.files if k.startswith("emb_") and "__" not in k]:
@@ -442,7 +442,7 @@ def test_embedding_decoder_vs_golden_and_oracle(hip, golden, T):
         assert np.array_equal(out2[:nE], out[:nE])
 
 
-@pytest.mark.parametrize("T", [8, 16, 4])
+@pytest.mark.parametrize("T", [8, 16, 4, 2, 24])
 def test_seediness_decoder_vs_golden(hip, golden, T):
     from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
     g = golden("decoder_T%d" % T)

@@ -17,7 +17,7 @@ def _dec_sd(prefix, seed, **kw):
     return synth.synth_state_dict(odec.decoder_param_shapes(prefix, **kw), seed)
 
 
-@pytest.mark.parametrize("T", [8, 16, 4])
+@pytest.mark.parametrize("T", [8, 16, 4, 2, 24])
 def test_embedding_decoder(golden, T):
     g = golden("decoder_T%d" % T)
     names = [k for k in g.files if k.startswith("emb_") and "__" not in k]
@@ -32,7 +32,7 @@ def test_embedding_decoder(golden, T):
         assert np.abs(out - g[name]).max() <= TOL, name
 
 
-@pytest.mark.parametrize("T", [8, 16, 4])
+@pytest.mark.parametrize("T", [8, 16, 4, 2, 24])
 def test_seediness_decoder(golden, T):
     g = golden("decoder_T%d" % T)
     _, h32, w32, ws, _, _ = g["seediness__meta"].tolist()

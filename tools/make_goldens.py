@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "chainer_long", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "dec_T2", "dec_T24", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "chainer_long", "misc"]
 
 
 def _save(name, **arrays):
