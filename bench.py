@@ -204,7 +204,7 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
 
 def library_switches():
     """The A/B switches the library reads from the environment (csrc/conv_igemm.hip), as set for this run."""
-    return {k: os.environ.get(k, "default") for k in ("STEMSEG_K3_DB", "STEMSEG_FLAT", "STEMSEG_PLANNER", "STEMSEG_T_FASTEST", "STEMSEG_GLDS", "STEMSEG_GN_EPILOGUE", "STEMSEG_TILE224")}
+    return {k: os.environ.get(k, "default") for k in ("STEMSEG_K3_DB", "STEMSEG_FLAT", "STEMSEG_PLANNER", "STEMSEG_T_FASTEST", "STEMSEG_GLDS", "STEMSEG_GN_EPILOGUE", "STEMSEG_TILE224", "STEMSEG_AUTOSPLIT")}
 
 
 def mark(msg):

@@ -875,6 +875,20 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     const int64_t slab = (int64_t)p.Cout * p.T * p.H * p.W;
     int ksplit = 1;
     while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= 640 && slab * ksplit * 2 <= scratch_floats) ksplit *= 2;
+    // uneven rounds (STEMSEG_AUTOSPLIT=1, off by default until measured): a launch of a few hundred long-running 3x3(x3)
+    // workgroups -- 424 on 256 CUs = two rounds for 1.66 rounds of work -- splits K by the k in {2, 3, 4} whose
+    // ceil(workgroups * k / 256) / k rounds, plus the slab round trip at ~4 TB/s, beat the plain launch by > 7 %
+    static const bool autosplit = [] { const char* e = getenv("STEMSEG_AUTOSPLIT"); return e && e[0] == '1'; }();
+    if (autosplit && force_ksplit == 0 && ksplit == 1 && scratch && C::TAPS > 1 && wgs > 256 && wgs <= 1024) {
+        const double t_wg = 2.0 * C::MT * C::NT * (double)p.Cin * C::TAPS / CU_FLOPS_F32;        // one workgroup alone on a CU
+        double best = (double)ceil_div(wgs, 256) * t_wg;
+        const double plain = best;
+        for (int k = 2; k <= 4; ++k) {
+            if (k * 4 > nchunks || (int64_t)k * slab > scratch_floats) continue;
+            const double t = (double)ceil_div(wgs * k, 256) * t_wg / k + 2.0 * k * slab * 4.0 / 4.0e12 + 6e-6;
+            if (t < 0.93 * plain && t < best) { best = t; ksplit = k; }
+        }
+    }
     if (force_ksplit > 0) ksplit = (scratch && (int64_t)force_ksplit * slab <= scratch_floats) ? std::min(force_ksplit, nchunks) : 1;
     p.chunks_per_split = (int)ceil_div(nchunks, ksplit);
     ksplit = (int)ceil_div(nchunks, p.chunks_per_split);

@@ -99,7 +99,7 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     // tail (launch_rows_balanced), 2 slabs' worth covers any (rows, k) the cost model picks
     p.Sfloats[0] = 16 * (int64_t)p.c32 * p.T * p.h[0] * p.w[0];
     p.Sfloats[1] = 4 * (int64_t)p.c16 * p.T * p.h[1] * p.w[1];
-    p.Sfloats[2] = 2 * (int64_t)p.c8 * p.T * p.h[2] * p.w[2];
+    p.Sfloats[2] = 4 * (int64_t)p.c8 * p.T * p.h[2] * p.w[2];
     p.Sfloats[3] = 2 * (int64_t)p.c4 * p.T * p.h[3] * p.w[3];
     for (int i = 0; i < 4; ++i) p.S[i] = p.Sfloats[i] ? take(p.Sfloats[i]) : 0;
     p.P32b = take(PaddedGeom(p.c32, p.Ta1, p.h[0], p.w[0]).total);
