@@ -104,6 +104,7 @@ int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, 
 int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy, int sx, const StemsegVolume& out,
                     hipStream_t s);
 int launch_copy_to_volume(const float* in, int layout, const StemsegVolume& out, hipStream_t s);
+int launch_copy_strided(const float* in, int64_t in_c_stride, int64_t in_t_stride, const StemsegVolume& out, hipStream_t s);
 struct HeadSpec {
     int n_out;
     int act[STEMSEG_MAX_EMB_DIMS * 2];

@@ -178,6 +178,20 @@ int launch_copy_to_volume(const float* in, int layout, const StemsegVolume& out,
     return STEMSEG_OK;
 }
 
+// same kernel, source given by its (channel, t) strides: a window of frames of a larger dense [C][T_all][H][W] tensor
+int launch_copy_strided(const float* in, int64_t in_c_stride, int64_t in_t_stride, const StemsegVolume& out, hipStream_t s) {
+    SS_CHECK_ARG(in && out.ptr, "copy_strided: null pointer");
+    CopyParams p;
+    p.in = in; p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
+    p.C = out.C; p.T = out.T; p.H = out.H; p.W = out.W;
+    p.in_c = in_c_stride; p.in_t = in_t_stride;
+    const int64_t total = (int64_t)out.C * out.T * out.H * out.W;
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(copy_to_volume_kernel, dim3(blocks), dim3(256), 0, s, p);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
 }  // namespace stemseg
 
 extern "C" int stemseg_hip_upsample_trilinear(const float* in, int32_t C, int32_t T, int32_t H, int32_t W, int32_t st, int32_t sy,

@@ -197,7 +197,7 @@ class ResNetFPN(nn.Module):
         else:
             assert (n - 1) * window[1] + window[0] == T, "windows do not cover the pass"
             d = self._desc(T, H, W, n, int(window[0]), int(window[1]))
-        key = (T, H, W, frames.device.index, self.lane)
+        key = (T, H, W, frames.device.index, self.lane, None if window is None else (n, int(window[0]), int(window[1])))
         ws = self._ws.get(key)
         if ws is None:
             nbytes = hip.lib().stemseg_hip_encoder_workspace_bytes(C.byref(d))
