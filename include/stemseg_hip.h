@@ -227,8 +227,8 @@ typedef struct StemsegEncoderDesc {
     int32_t clip_frames;         /* 0: T / n_clips.  > 0 with clip_stride > 0: the clips are OVERLAPPING windows of clip_frames
                                     frames every clip_stride frames of the pass ((n_clips - 1) * clip_stride + clip_frames == T),
                                     the way inference/main.py:23-49 cuts a sequence: a frame shared by two clips goes through
-                                    the trunk once (the reference's cross-clip feature cache, inference_model.py:83-108) and
-                                    only the per-clip FPN output convs run once per clip */
+                                    the encoder once (the reference's cross-clip feature cache, inference_model.py:83-108) and
+                                    each clip's window of the FPN maps is copied to its output volumes */
     int32_t clip_stride;
 } StemsegEncoderDesc;
 
