@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 2
+#define STEMSEG_HIP_ABI_VERSION 3
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -328,6 +328,36 @@ int stemseg_hip_label_presence(const int64_t* labels, int64_t n, uint8_t* presen
 
 /* in-place relabel: labels[i] = map[labels[i] + 1] for labels[i] + 1 in [0, map_len) (online_chainer.py:219-229) */
 int stemseg_hip_relabel(int64_t* labels, int64_t n, const int64_t* map, int32_t map_len, void* stream);
+
+/* ---- clip-parallel stitching: what a rank needs when the clips of ONE sequence are clustered on different GPUs
+ * (the chain itself is online_chainer.py:193-236).  A clip clustered with label_start = 1 leaves ONE BYTE per
+ * voxel -- 0 background, 1..K the clip-local instance (labels are i + label_start, clusterers.py:121), 255 the outlier label
+ * -1 -- and only those planes are exchanged.  "bin" below maps a code to a table index: 0..B-2 as is, 255 -> B-1,
+ * B = max_instances + 2. ---- */
+
+/* masks_to_coord_list alone (online_chainer.py:11-22): voxel_index [N] + frame_offsets [T+1] of stemseg_hip_fg_gather, without
+ * the head outputs.  scratch as for stemseg_hip_fg_gather. */
+int stemseg_hip_fg_compact(const uint8_t* fg, int32_t T, int64_t HW, int32_t* voxel_index, int64_t* frame_offsets, void* scratch,
+                           void* stream);
+
+/* codes[0..V) = 0, then codes[voxel_index[i]] = labels[i] - label_start + 1 (255 for labels[i] < 0), i < N; N from
+ * n_points_dev (device, e.g. frame_offsets + T) or n_max when NULL. */
+int stemseg_hip_labels_to_codes(const int64_t* labels, const int32_t* voxel_index, const int64_t* n_points_dev, int64_t n_max,
+                                int64_t label_start, uint8_t* codes, int64_t V, void* stream);
+
+/* online_chainer.py:291-343's statistics for every (clip, frame) of a sequence in ONE launch.  codes: [planes][HW];
+ * item k compares plane_a[k] (the frame as labelled by the clip that contributed it to the track container; -1: none, every
+ * voxel counts under a = 0) with plane_b[k] (the same frame as labelled by the current clip) over the voxels that are
+ * foreground in plane_b: tables[k][a][b] (int32, zeroed by the call) = #voxels with bin(code_a) = a, bin(code_b) = b.
+ * plane_a / plane_b: DEVICE int32 [n_items]. */
+int stemseg_hip_pair_tables(const uint8_t* codes, const int32_t* plane_a, const int32_t* plane_b, int32_t n_items, int64_t HW,
+                            int32_t B, int32_t* tables, void* stream);
+
+/* The relabel of online_chainer.py:219-224 as a gather: for item k = (src_begin, count, vbase, plane, out_begin) (DEVICE int64
+ * [n_items][5]): out[out_begin + q] = lut[k][bin(codes[plane][voxel_index[src_begin + q] - vbase])], q < count.
+ * lut: DEVICE int64 [n_items][B] (final track id per clip-local code).  max_count = max over items of count. */
+int stemseg_hip_codes_to_labels(const uint8_t* codes, const int32_t* voxel_index, const int64_t* items, int32_t n_items,
+                                int64_t max_count, const int64_t* lut, int64_t HW, int32_t B, int64_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Semantic-segmentation side (datasets with MODEL.USE_SEMSEG_HEAD: youtube_vis.yaml, kitti_mots_*.yaml).

@@ -436,6 +436,96 @@ __global__ void relabel_kernel(long long* labels, long long n, const long long* 
     }
 }
 
+
+// ---- clip-parallel stitching (pipeline.run_sequence_sharded) ---------------------------------------
+// Every rank clusters ITS clips with label_start = 1 (clusterers.py:121: labels are i + label_start, so the global id is an
+// offset applied later), leaves the result as one byte per voxel -- 0 = background, 1..K = local instance, 255 = outlier --
+// and only those planes travel.  The chain of online_chainer.py:193-236 then needs, per clip and frame, the K1 x K2 table of
+// (label of the clip that first contributed the frame, label of this clip) pairs: one launch for the whole sequence.
+
+// compaction of a foreground mask alone: voxel_index + frame_offsets of stemseg_hip_fg_gather without the head outputs
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const unsigned char* __restrict__ fg, long long V, long long HW, int T,
+                                                              const long long* __restrict__ block_offsets, int* vox, long long* frame_offsets) {
+    __shared__ int wave_tot[4][4];
+    const long long base = (long long)blockIdx.x * GA_BLOCK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long blk_off = block_offsets[blockIdx.x];
+    bool f[4];
+    int rank_in_wave[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long v = base + k * 256 + threadIdx.x;
+        f[k] = (v < V) && fg[v];
+        const unsigned long long b = __ballot(f[k]);
+        rank_in_wave[k] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[k][w] = __popcll(b);
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int before = run;
+        for (int ww = 0; ww < 4; ++ww) {
+            if (ww < w) before += wave_tot[k][ww];
+            run += wave_tot[k][ww];
+        }
+        const long long v = base + k * 256 + threadIdx.x;
+        const long long dst = blk_off + before + rank_in_wave[k];
+        if (v < V && (v % HW) == 0) frame_offsets[v / HW] = dst;
+        if (f[k]) vox[dst] = (int)v;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) frame_offsets[T] = block_offsets[gridDim.x];
+}
+
+__global__ void labels_to_codes_kernel(const long long* __restrict__ labels, const int* __restrict__ vox, const long long* n_dev,
+                                       long long n_max, long long label_start, unsigned char* codes) {
+    long long N = n_dev ? *n_dev : n_max;
+    N = N < n_max ? N : n_max;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = labels[i];
+        const long long c = l - label_start + 1;
+        codes[vox[i]] = (l < 0) ? 255 : (unsigned char)(c < 1 ? 254 : (c > 254 ? 254 : c));      // (254: out of range, never produced)
+    }
+}
+
+__device__ __forceinline__ int code_bin(unsigned int c, int B) { return c == 255u ? B - 1 : (c < (unsigned)(B - 1) ? (int)c : B - 1); }
+
+// tables[item][a][b] = #voxels v with bin(codes[plane_a[item]][v]) == a and bin(codes[plane_b[item]][v]) == b, over the voxels where
+// plane_b is foreground (code != 0); plane_a == -1: a = 0 for every voxel.  grid = (chunks, items); LDS histogram, integer atomics.
+__global__ __launch_bounds__(256) void pair_tables_kernel(const unsigned char* __restrict__ codes, const int* __restrict__ plane_a,
+                                                          const int* __restrict__ plane_b, long long HW, int B, unsigned int* tables) {
+    extern __shared__ unsigned int hist[];
+    const int item = blockIdx.y;
+    const int pa = plane_a[item], pb = plane_b[item];
+    for (int k = threadIdx.x; k < B * B; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const unsigned char* cb = codes + (long long)pb * HW;
+    const unsigned char* ca = pa >= 0 ? codes + (long long)pa * HW : nullptr;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < HW; v += (long long)gridDim.x * blockDim.x) {
+        const unsigned int b = cb[v];
+        if (!b) continue;
+        const unsigned int a = ca ? ca[v] : 0u;
+        atomicAdd(&hist[code_bin(a, B) * B + code_bin(b, B)], 1u);
+    }
+    __syncthreads();
+    unsigned int* out = tables + (long long)item * B * B;
+    for (int k = threadIdx.x; k < B * B; k += blockDim.x)
+        if (hist[k]) atomicAdd(&out[k], hist[k]);
+}
+
+// out[item.out_begin + q] = lut[item][bin(codes[item.plane][vox[item.src_begin + q] - item.vbase])], q < item.count
+// items: int64 [n_items][5] = (src_begin, count, vbase, plane, out_begin).  grid = (chunks, items)
+__global__ __launch_bounds__(256) void codes_to_labels_kernel(const unsigned char* __restrict__ codes, const int* __restrict__ vox,
+                                                              const long long* __restrict__ items, const long long* __restrict__ lut,
+                                                              long long HW, int B, long long* out) {
+    const long long* it = items + (long long)blockIdx.y * 5;
+    const long long src = it[0], cnt = it[1], vbase = it[2], plane = it[3], dst = it[4];
+    const long long* l = lut + (long long)blockIdx.y * B;
+    const unsigned char* c = codes + plane * HW;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < cnt; q += (long long)gridDim.x * blockDim.x)
+        out[dst + q] = l[code_bin(c[vox[src + q] - vbase], B)];
+}
+
 static int grid_for(long long n, int threads, int cap) { return (int)std::max<long long>(1, std::min<long long>(ceil_div(n, threads), cap)); }
 
 }  // namespace stemseg
@@ -592,6 +682,64 @@ extern "C" int stemseg_hip_relabel(int64_t* labels, int64_t n, const int64_t* ma
     SS_CHECK_ARG(labels && map, "relabel: null pointer");
     hipLaunchKernelGGL(relabel_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<long long*>(labels), (long long)n, reinterpret_cast<const long long*>(map), map_len);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_fg_compact(const uint8_t* fg, int32_t T, int64_t HW, int32_t* voxel_index, int64_t* frame_offsets, void* scratch,
+                                      void* stream) {
+    SS_CHECK_ARG(fg && voxel_index && frame_offsets && scratch && T >= 1 && HW >= 1, "fg_compact: bad arguments");
+    const long long V = (long long)T * HW;
+    SS_CHECK_ARG(V < (1ll << 31), "fg_compact: more than 2^31 voxels");
+    const int nb = (int)ceil_div(V, GA_BLOCK);
+    int* counts = reinterpret_cast<int*>(scratch);
+    long long* offsets = reinterpret_cast<long long*>(reinterpret_cast<char*>(scratch) + round_up((int64_t)nb * 4, 8));
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(gather_count_kernel, dim3(nb), dim3(256), 0, s, fg, V, counts);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)counts, offsets, nb);
+    SS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb), dim3(256), 0, s, fg, V, (long long)HW, T, (const long long*)offsets, voxel_index,
+                       reinterpret_cast<long long*>(frame_offsets));
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_labels_to_codes(const int64_t* labels, const int32_t* voxel_index, const int64_t* n_points_dev, int64_t n_max,
+                                           int64_t label_start, uint8_t* codes, int64_t V, void* stream) {
+    SS_CHECK_ARG(codes && V >= 0 && n_max >= 0 && n_max <= V, "labels_to_codes: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (V) SS_HIP(hipMemsetAsync(codes, 0, (size_t)V, s));
+    if (n_max == 0) return STEMSEG_OK;
+    SS_CHECK_ARG(labels && voxel_index, "labels_to_codes: null pointer");
+    hipLaunchKernelGGL(labels_to_codes_kernel, dim3(grid_for(n_max, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const long long*>(labels),
+                       voxel_index, reinterpret_cast<const long long*>(n_points_dev), (long long)n_max, (long long)label_start, codes);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_pair_tables(const uint8_t* codes, const int32_t* plane_a, const int32_t* plane_b, int32_t n_items, int64_t HW,
+                                       int32_t B, int32_t* tables, void* stream) {
+    SS_CHECK_ARG(n_items >= 0 && HW >= 0 && B >= 3 && B <= STEMSEG_MAX_INSTANCES + 2, "pair_tables: bad arguments (B = max_instances + 2)");
+    if (n_items == 0) return STEMSEG_OK;
+    SS_CHECK_ARG(codes && plane_a && plane_b && tables, "pair_tables: null pointer");
+    hipStream_t s = as_stream(stream);
+    SS_HIP(hipMemsetAsync(tables, 0, sizeof(int32_t) * (size_t)n_items * B * B, s));
+    if (HW == 0) return STEMSEG_OK;
+    hipLaunchKernelGGL(pair_tables_kernel, dim3(grid_for(HW, 256 * 8, 64), (unsigned)n_items), dim3(256), sizeof(unsigned int) * B * B, s, codes,
+                       plane_a, plane_b, (long long)HW, B, reinterpret_cast<unsigned int*>(tables));
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_codes_to_labels(const uint8_t* codes, const int32_t* voxel_index, const int64_t* items, int32_t n_items,
+                                           int64_t max_count, const int64_t* lut, int64_t HW, int32_t B, int64_t* out, void* stream) {
+    SS_CHECK_ARG(n_items >= 0 && max_count >= 0 && HW >= 0 && B >= 3 && B <= STEMSEG_MAX_INSTANCES + 2, "codes_to_labels: bad arguments");
+    if (n_items == 0 || max_count == 0) return STEMSEG_OK;
+    SS_CHECK_ARG(codes && voxel_index && items && lut && out, "codes_to_labels: null pointer");
+    hipLaunchKernelGGL(codes_to_labels_kernel, dim3(grid_for(max_count, 256 * 4, 256), (unsigned)n_items), dim3(256), 0, as_stream(stream), codes,
+                       voxel_index, reinterpret_cast<const long long*>(items), reinterpret_cast<const long long*>(lut), (long long)HW, B,
+                       reinterpret_cast<long long*>(out));
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }

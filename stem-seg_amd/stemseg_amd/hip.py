@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstemseg_hip.so")
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Volume(C.Structure):
@@ -108,6 +108,10 @@ SIGNATURES = {
     "stemseg_hip_overlap_counts": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "stemseg_hip_label_presence": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _P]),
     "stemseg_hip_relabel": (C.c_int, [_P, _I64, _P, _I32, _P]),
+    "stemseg_hip_fg_compact": (C.c_int, [_P, _I32, _I64, _P, _P, _P, _P]),
+    "stemseg_hip_labels_to_codes": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64, _P]),
+    "stemseg_hip_pair_tables": (C.c_int, [_P, _P, _P, _I32, _I64, _I32, _P, _P]),
+    "stemseg_hip_codes_to_labels": (C.c_int, [_P, _P, _P, _I32, _I64, _P, _I64, _I32, _P, _P]),
     "stemseg_hip_semseg_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I64, C.POINTER(C.c_int32), _I32, _P]),
     "stemseg_hip_semseg_masks": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _P, _P, _P]),
     "stemseg_hip_preprocess_frames": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float), _I32, _I32, _P, _P]),
@@ -431,6 +435,47 @@ def label_presence(labels_list, cap):
 
 def relabel(labels, mapping):
     check(lib().stemseg_hip_relabel(ptr(labels, torch.int64), labels.numel(), ptr(mapping, torch.int64), mapping.numel(), stream()))
+
+
+# ---- clip-parallel stitching (pipeline.run_sequence_sharded) ------------------------------------------------
+def fg_compact(fg):
+    """fg uint8 [T,H,W] -> (voxel_index int32 [V] (first N valid), frame_offsets int64 [T+1]) on the device, no sync."""
+    T = fg.shape[0]
+    HW = fg[0].numel()
+    V = T * HW
+    vox = torch.empty(V, dtype=torch.int32, device=fg.device)
+    offs = torch.empty(T + 1, dtype=torch.int64, device=fg.device)
+    scratch = torch.empty(16 * (V // 1024 + 4), dtype=torch.uint8, device=fg.device)
+    check(lib().stemseg_hip_fg_compact(ptr(fg, torch.uint8), T, HW, ptr(vox), ptr(offs), ptr(scratch), stream()))
+    return vox, offs
+
+
+def labels_to_codes(labels, vox, n_points_dev, label_start, codes_out):
+    """codes_out uint8 [V] (a contiguous view, e.g. one clip's [T,h,w] block of the exchange buffer) := 0, then
+    codes_out[vox[i]] = labels[i] - label_start + 1 (255: outlier) for the first N points."""
+    check(lib().stemseg_hip_labels_to_codes(ptr(labels, torch.int64) if labels.numel() else None, ptr(vox, torch.int32) if vox.numel() else None,
+                                            ptr(n_points_dev), min(labels.numel(), codes_out.numel()), int(label_start),
+                                            ptr(codes_out, torch.uint8), codes_out.numel(), stream()))
+    return codes_out
+
+
+def pair_tables(codes, plane_a, plane_b, B):
+    """codes uint8 [P, HW]; plane_a / plane_b int32 [n] on the device -> int32 [n, B, B] on the device (no sync)."""
+    n = plane_a.numel()
+    HW = codes.shape[1]
+    tables = torch.empty(n, B, B, dtype=torch.int32, device=codes.device)
+    check(lib().stemseg_hip_pair_tables(ptr(codes, torch.uint8), ptr(plane_a, torch.int32), ptr(plane_b, torch.int32), n, HW, B,
+                                        ptr(tables), stream()))
+    return tables
+
+
+def codes_to_labels(codes, vox, items, lut, max_count, n_out):
+    """items int64 [n,5] = (src_begin, count, vbase, plane, out_begin), lut int64 [n,B] (both on the device) -> int64 [n_out]."""
+    n, B = lut.shape
+    out = torch.empty(n_out, dtype=torch.int64, device=codes.device)
+    check(lib().stemseg_hip_codes_to_labels(ptr(codes, torch.uint8), ptr(vox, torch.int32), ptr(items, torch.int64), n, int(max_count),
+                                            ptr(lut, torch.int64), codes.shape[1], B, ptr(out), stream()))
+    return out
 
 
 def semseg_accumulate(acc, clip_logits, frame_index):

@@ -172,6 +172,52 @@ class HipChainerOps(object):
         m = int(mx.item()) - 1
         return m if m >= 0 else -1            # all outliers: the reference's lab.max() is -1, max(0, -1) keeps 0
 
+    # ---- clip-parallel stitching (pipeline.run_sequence_sharded): clip-local label codes, pair tables, LUT gather --------
+    META_BYTES = None
+
+    def compact(self, fg):
+        """fg uint8 [F,h,w] -> (voxel_index int32 [V], frame_offsets int64 [F+1]) on the device (masks_to_coord_list of the
+        whole sequence in one compaction; no sync)."""
+        return hip.fg_compact(fg.contiguous())
+
+    def codes_from_labels(self, pts, labels, label_start, out):
+        """One byte per voxel of the clip (0 background, 1..K clip-local instance, 255 outlier) into ``out`` (uint8, contiguous)."""
+        hip.labels_to_codes(labels, pts["vox"], pts["offs"][pts["T"]:], label_start, out)
+
+    def meta_bytes(self):
+        import ctypes
+        return ctypes.sizeof(hip.ClusterMeta)
+
+    def pack_meta(self, meta_dev):
+        return meta_dev                                   # the device record itself (uint8 [sizeof(StemsegClusterMeta)])
+
+    def unpack_meta(self, raw):
+        return hip.ClusterMeta.from_buffer_copy(bytes(raw))
+
+    def pair_tables(self, codes, plane_a, plane_b, B):
+        dev = codes.device
+        return hip.pair_tables(codes, torch.as_tensor(plane_a, dtype=torch.int32).to(dev, non_blocking=True),
+                               torch.as_tensor(plane_b, dtype=torch.int32).to(dev, non_blocking=True), B)
+
+    def read_back(self, *tensors):
+        """Device tensors -> numpy arrays with ONE host synchronisation (pinned staging buffers, reused per shape)."""
+        bufs = []
+        for k, t in enumerate(tensors):
+            key = ("rb", k, t.device.index, t.dtype, tuple(t.shape))
+            buf = self._offs_pinned.get(key)
+            if buf is None:
+                buf = self._offs_pinned[key] = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+            buf.copy_(t, non_blocking=True)
+            bufs.append(buf)
+        if tensors:
+            torch.cuda.current_stream(tensors[0].device).synchronize()
+        return [b.numpy().copy() for b in bufs]
+
+    def labels_from_codes(self, codes, vox, items, lut, max_count, n_out):
+        dev = codes.device
+        return hip.codes_to_labels(codes, vox, torch.as_tensor(items, dtype=torch.int64).to(dev, non_blocking=True),
+                                   torch.as_tensor(lut, dtype=torch.int64).to(dev, non_blocking=True), max_count, n_out)
+
 
 def _int_scale(scale):
     s = int(round(float(scale)))
@@ -179,6 +225,110 @@ def _int_scale(scale):
         raise NotImplementedError("embedding resize factor %r: the HIP trilinear kernel takes positive integer scales (the "
                                   "reference only ever passes 1.0 or 4.0, inference/main.py:209-213)" % (scale,))
     return s
+
+
+def association_from_counts(inter, ca, cb, ids_1, ids_2):
+    """The Hungarian step of online_chainer.py:310-343 on the label-pair statistics: IoU costs in float32 exactly as the
+    reference forms them (``1. - iou.item()`` stored into a float32 matrix, :327), every returned pair accepted."""
+    I = np.asarray(inter).astype(np.float32).reshape(len(ids_1), len(ids_2))
+    A = np.asarray(ca).astype(np.float32)[:, None]
+    B = np.asarray(cb).astype(np.float32)[None, :]
+    U = (A + B - I).astype(np.float32)
+    iou = (I / U).astype(np.float32) if I.size else np.zeros_like(I)
+    costs = (1. - iou.astype(np.float64)).astype(np.float32)
+    recall = (I / A).astype(np.float32) if I.size else np.zeros_like(I)
+    idx1, idx2 = linear_sum_assignment(costs)
+    associations, un1, un2 = [], set(ids_1), set(ids_2)
+    for i1, i2 in zip(idx1, idx2):
+        associations.append((ids_1[i1], ids_2[i2]))
+        un1.remove(ids_1[i1])
+        un2.remove(ids_2[i2])
+    return associations, un1, un2, costs[idx1, idx2], (recall, ids_1, ids_2)
+
+
+def frame_sources(clip_frames):
+    """Which (clip, slot) contributes each frame to the track container: clip 0 all of its frames, clip i the frames it does not
+    share with clip i - 1 (online_chainer.py:196-229).  -> ({frame: (clip, slot)}, per clip the slots on the overlap with the
+    previous clip, per clip the slots it adds)."""
+    src, ov_js, new_js = {}, [], []
+    prev = None
+    for i, frames in enumerate(clip_frames):
+        shared = set(frames).intersection(prev) if prev is not None else set()
+        ov_js.append([j for j, t in enumerate(frames) if t in shared])
+        new_js.append([j for j, t in enumerate(frames) if t not in shared])
+        for j in new_js[-1]:
+            assert frames[j] not in src, "frame %d would be added twice" % frames[j]
+            src[frames[j]] = (i, j)
+        for j in ov_js[-1]:
+            assert frames[j] in src
+        prev = frames
+    return src, ov_js, new_js
+
+
+def stitch_from_tables(clip_frames, tables, item_of, Ks, B):
+    """The serial chain of OnlineChainer.process (online_chainer.py:193-236) on label-pair TABLES instead of label arrays --
+    what is left on every rank when the clips were clustered elsewhere with label_start = 1.
+
+    clip_frames: per clip its (distinct) frame numbers; tables: int [n_items, B, B], tables[item_of[(i, j)]][a][b] = voxels of
+    clip i's slot j whose code in the SOURCE plane of that frame (frame_sources) bins to a and whose code in clip i's own plane
+    bins to b (a = 0 when the frame has no source yet; bins: 1..B-2 clip-local instances, B-1 the outlier label);
+    Ks: instances per clip.  -> dict(lut_track, lut_sub: {(i, j): int64 [B] final label per bin}, label_start, instance_labels
+    per clip, next_track_label, src / new_js of frame_sources)."""
+    src, ov_js, new_js = frame_sources(clip_frames)
+    nb = B - 2
+    next_label, highest = 1, 0
+    lut_track, lut_sub, starts, inst = {}, {}, [], []
+    for i, frames in enumerate(clip_frames):
+        start = next_label
+        starts.append(start)
+        base = np.full(B, -1, np.int64)
+        base[0] = 0
+        base[1:B - 1] = start + np.arange(nb, dtype=np.int64)
+        labels_i = [start + k for k in range(int(Ks[i]))]
+        mapping = {}
+        if ov_js[i]:
+            tabs = np.stack([tables[item_of[(i, j)]] for j in ov_js[i]]).astype(np.int64)             # [J, B, B]
+            fin = np.stack([lut_track[src[frames[j]]] for j in ov_js[i]])                             # [J, B] final id per source bin
+            rows = tabs[:, 1:B - 1, :]                                                                 # source instances only
+            row_ids = fin[:, 1:B - 1].reshape(-1)
+            row_cnt = rows.sum(2).reshape(-1)
+            keep = row_cnt > 0
+            ids_1, inv = np.unique(row_ids[keep], return_inverse=True)
+            inter_rows = np.zeros((len(ids_1), nb), np.int64)
+            np.add.at(inter_rows, inv, rows[:, :, 1:B - 1].reshape(-1, nb)[keep])
+            ca = np.zeros(len(ids_1), np.int64)
+            np.add.at(ca, inv, row_cnt[keep])
+            col_cnt = tabs.sum((0, 1))[1:B - 1]                                                        # over ALL source bins
+            cols = np.flatnonzero(col_cnt > 0)
+            ids_1 = [int(v) for v in ids_1]
+            ids_2 = [int(base[1 + c]) for c in cols]
+            if ids_1 or ids_2:
+                assert not set(ids_1).intersection(ids_2), "Labels overlap: {}, {}".format(ids_1, ids_2)
+                associations = association_from_counts(inter_rows[:, cols], ca, col_cnt[cols], ids_1, ids_2)[0]
+                mapping = {cur: assoc for assoc, cur in associations}
+        final = base.copy()
+        for cur, assoc in mapping.items():
+            final[cur - start + 1] = assoc
+        for j in ov_js[i]:
+            lut_sub[(i, j)] = base
+        for j in new_js[i]:
+            lut_sub[(i, j)] = final if mapping else base
+            lut_track[(i, j)] = lut_sub[(i, j)]
+        if new_js[i]:
+            cnt_new = np.sum([tables[item_of[(i, j)]].sum(0) for j in new_js[i]], 0).astype(np.int64)  # per bin of this clip
+            present = np.flatnonzero(cnt_new[1:B - 1] > 0)
+            if present.size:
+                max_label = int(lut_sub[(i, new_js[i][0])][1 + present].max())
+            else:
+                max_label = -1 if int(cnt_new.sum()) > 0 else None
+            if max_label is not None:
+                highest = max(highest, max_label)
+            next_label = highest + 1
+        for cur, assoc in mapping.items():
+            labels_i[labels_i.index(cur)] = assoc
+        inst.append(labels_i)
+    return dict(lut_track=lut_track, lut_sub=lut_sub, label_start=starts, instance_labels=inst, next_track_label=next_label,
+                src=src, new_js=new_js, ov_js=ov_js)
 
 
 class OnlineChainer(object):
@@ -312,17 +462,4 @@ class OnlineChainer(object):
         assert la.shape == lb.shape, "Shape mismatch: {}, {}".format(la.shape, lb.shape)
         assert not set(ids_1).intersection(ids_2), "Labels overlap: {}, {}".format(ids_1, ids_2)
         inter, ca, cb = self.ops.overlap_counts(la, lb, ids_1, ids_2)
-        I = inter.astype(np.float32).reshape(len(ids_1), len(ids_2))
-        A = ca.astype(np.float32)[:, None]
-        B = cb.astype(np.float32)[None, :]
-        U = (A + B - I).astype(np.float32)
-        iou = (I / U).astype(np.float32) if I.size else np.zeros_like(I)
-        costs = (1. - iou.astype(np.float64)).astype(np.float32)             # `1. - iou.item()` stored as float32 (:327)
-        recall = (I / A).astype(np.float32) if I.size else np.zeros_like(I)
-        idx1, idx2 = linear_sum_assignment(costs)
-        associations, un1, un2 = [], set(ids_1), set(ids_2)
-        for i1, i2 in zip(idx1, idx2):
-            associations.append((ids_1[i1], ids_2[i2]))
-            un1.remove(ids_1[i1])
-            un2.remove(ids_2[i2])
-        return associations, un1, un2, costs[idx1, idx2], (recall, ids_1, ids_2)
+        return association_from_counts(inter, ca, cb, ids_1, ids_2)

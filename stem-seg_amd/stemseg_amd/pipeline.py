@@ -205,8 +205,242 @@ def clip_owner(ci, n_clips, world_size):
 
 @torch.no_grad()
 def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
+                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None, outputs_on_cpu=True):
+    """One long sequence over the ranks of ``group``, partitioned as SURVEY.md 8(e) lays out:
+
+      1. every rank embeds ITS contiguous block of clips (``embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w],
+         seed [1,T,h,w])`` per clip, or ``embed_many_fn(list of clips) -> list of stacked [E+Ev+1,T,h,w] blocks`` with
+         ``channel_split = (E, Ev)``, e.g. ClipPipeline.embed_many: several overlapping windows per encoder pass);
+      2. all-gather #1: the SEEDINESS planes only (1 of the E+Ev+1 channels) -> the cross-clip mean-seediness foreground mask of
+         the whole sequence on every rank (inference/main.py:93-103), one launch;
+      3. every rank gathers + clusters its OWN clips with label_start = 1 (labels are i + label_start, clusterers.py:121, so the
+         global id is an offset applied later) and leaves one byte per voxel (0 background, 1..K instance, 255 outlier);
+      4. all-gather #2: those byte planes + the 4.4 KB clustering record per clip;
+      5. replicated and tiny: ONE launch builds the K1 x K2 label-pair tables of every (clip, overlap frame), one read-back, the
+         Hungarian chain with ``next_track_label = highest id + 1`` runs on the host over the tables
+         (online_chainer.stitch_from_tables = online_chainer.py:193-236, :291-343, :43-49), one launch turns codes into final labels.
+
+    Returns OnlineChainer.process(...)'s structure, identical on every rank and bit-identical to the single-process result
+    (tests/test_distributed_cpu.py: world 1 / 2 / 3 / 8 against the reference-generated goldens).  ``outputs_on_cpu=False`` leaves
+    the label tensors on the device (the reference's structure holds host tensors).  ``stats`` (dict, optional) receives the
+    exchanges' sizes and durations."""
+    import time
+    import numpy as np
+    import torch.distributed as dist
+    from .inference.online_chainer import stitch_from_tables
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    ops, clusterer = chainer.ops, chainer.clusterer
+    assert chainer.resize_scale == 1.0, "the sharded sequence path clusters at the heads' resolution (resize_scale 1.0)"
+    clips, _ = get_subsequence_frames(n_frames, cfg.INPUT.NUM_FRAMES, dataset_name, frame_overlap)
+    n_clips = len(clips)
+    mine = shard_clips(n_clips, rank, world)
+    per_rank = (n_clips + world - 1) // world
+    T = len(clips[0])
+    uniq = [sorted(set(c)) for c in clips]
+    sels = [None if len(u) == len(c) else [max(j for j, v in enumerate(c) if v == t) for t in u] for u, c in zip(uniq, clips)]
+
+    # ---- 1. embed this rank's clips ---------------------------------------------------------------------------------
+    blocks = []                                           # per own clip: (emb, bw, seed) with all T slots
+    if embed_many_fn is not None and mine:
+        E, Ev = channel_split
+        blocks = [(b[:E], b[E:E + Ev], b[E + Ev:]) for b in embed_many_fn([clips[ci] for ci in mine])]
+    elif mine:
+        blocks = [embed_clip_fn(clips[ci]) for ci in mine]
+
+    # ---- 2. all-gather #1: seediness planes ---------------------------------------------------------------------------
+    shape_info = None
+    if blocks:
+        seed0 = blocks[0][2]
+        dev, (h, w) = seed0.device, tuple(seed0.shape[-2:])
+        shape_info = [h, w, blocks[0][0].shape[0]]
+    if distributed and world > 1 and n_clips < world:     # some ranks own no clip: they learn the map size from the others
+        dev = _default_device() if not blocks else dev
+        info = torch.tensor(shape_info if shape_info else [0, 0, 0], dtype=torch.int64, device=dev)
+        infos = [torch.zeros_like(info) for _ in range(world)]
+        dist.all_gather(infos, info, group=group)
+        shape_info = next(i for i in infos if int(i[0]) > 0).tolist()
+        h, w = int(shape_info[0]), int(shape_info[1])
+    E_dims = int(shape_info[2])
+    hw = h * w
+    seeds_local = torch.zeros((per_rank, T, h, w), dtype=torch.float32, device=dev)
+    for slot, blk in enumerate(blocks):
+        seeds_local[slot] = blk[2].reshape(T, h, w)
+    if distributed and world > 1:
+        seeds_all = [torch.empty_like(seeds_local) for _ in range(world)]
+        t_ag1 = _Timer(seeds_local)
+        dist.all_gather(seeds_all, seeds_local, group=group)        # data-path collective #1 (RCCL over xGMI on the box)
+        t_ag1.stop()
+    else:
+        seeds_all, t_ag1 = [seeds_local], None
+
+    def plane_of(ci):
+        return clip_owner(ci, n_clips, world)
+    entries = []
+    for ci in range(n_clips):
+        owner, slot = plane_of(ci)
+        sd = seeds_all[owner][slot]
+        if sels[ci] is not None:
+            sd = sd[torch.as_tensor(sels[ci], device=sd.device)]
+        entries.append(EmbeddingMapEntry(uniq[ci], None, None, sd[None]))
+    fg_fn = fg_mask_fn if fg_mask_fn is not None else fg_masks_from_seediness
+    fg = ops.to_device(fg_fn(entries, seediness_thresh))              # [F, h, w] uint8
+    assert tuple(fg.shape[-2:]) == (h, w), "Size mismatch between embeddings {} and masks {}".format((h, w), tuple(fg.shape))
+    vox_all, offs_all = ops.compact(fg)
+
+    # ---- 3. cluster this rank's clips with label_start = 1; one byte per voxel ------------------------------------------
+    meta_planes = (ops.meta_bytes() + hw - 1) // hw
+    P = T + meta_planes                                               # planes per clip in the exchange buffer
+    codes_local = torch.zeros((per_rank, P * hw), dtype=torch.uint8, device=dev)
+    for slot, ci in enumerate(mine):
+        emb, bw, seed = blocks[slot]
+        if sels[ci] is not None:
+            sel = torch.as_tensor(sels[ci], device=emb.device)
+            emb, bw, seed = emb[:, sel], bw[:, sel], seed[:, sel]
+        fg_clip = fg[torch.as_tensor(uniq[ci], device=fg.device)]
+        pts = ops.gather(emb, bw, seed, fg_clip)
+        labels, meta_dev, _ = ops.cluster(clusterer, pts, 1, False)
+        ops.codes_from_labels(pts, labels, 1, codes_local[slot, :len(uniq[ci]) * hw])
+        codes_local[slot, T * hw:T * hw + ops.meta_bytes()] = ops.pack_meta(meta_dev)
+
+    # ---- 4. all-gather #2: label codes + clustering records -------------------------------------------------------------
+    if distributed and world > 1:
+        codes_all = torch.empty((world, per_rank, P * hw), dtype=torch.uint8, device=dev)
+        t_ag2 = _Timer(codes_local)
+        if codes_local.is_cuda:
+            dist.all_gather_into_tensor(codes_all, codes_local, group=group)      # data-path collective #2
+        else:
+            _all_gather_stack(codes_all, codes_local, world, group)
+        t_ag2.stop()
+    else:
+        codes_all, t_ag2 = codes_local[None], None
+    planes = codes_all.view(world * per_rank * P, hw)
+
+    def plane_index(ci, j):
+        owner, slot = plane_of(ci)
+        return (owner * per_rank + slot) * P + j
+
+    # ---- 5. tables for every (clip, frame), one read-back, host chain, final labels -------------------------------------
+    from .inference.online_chainer import frame_sources
+    src, _, _ = frame_sources(uniq)
+    item_of, plane_a, plane_b = {}, [], []
+    for ci, frames in enumerate(uniq):
+        for j, t in enumerate(frames):
+            item_of[(ci, j)] = len(plane_b)
+            c, js = src[t]
+            plane_a.append(-1 if (c, js) == (ci, j) else plane_index(c, js))
+            plane_b.append(plane_index(ci, j))
+    B = clusterer.max_instances + 2
+    tables_dev = ops.pair_tables(planes, plane_a, plane_b, B)
+    meta_rows = codes_all.view(world * per_rank, P * hw)[:, T * hw:T * hw + ops.meta_bytes()]
+    tables, offs, meta_raw = ops.read_back(tables_dev, offs_all, meta_rows.contiguous())
+    metas = []
+    for ci in range(n_clips):
+        owner, slot = plane_of(ci)
+        metas.append(ops.unpack_meta(meta_raw[owner * per_rank + slot].tobytes()))
+    t_host = time.perf_counter()
+    st = stitch_from_tables(uniq, tables, item_of, [m.K for m in metas], B)
+    host_ms = 1e3 * (time.perf_counter() - t_host)
+
+    offs = [int(v) for v in offs]
+    n_total = offs[-1]
+    items, luts = [], []
+    for t in range(n_frames):                                           # the track container's frames
+        assert t in st["src"], "frame %d is in no clip" % t
+        c, js = st["src"][t]
+        items.append((offs[t], offs[t + 1] - offs[t], t * hw, plane_index(c, js), offs[t]))
+        luts.append(st["lut_track"][(c, js)])
+    cursor = n_total
+    sub_slices = []
+    for ci, frames in enumerate(uniq):                                  # per-clip label lists (relabelled on the frames the clip adds)
+        row = []
+        for j, t in enumerate(frames):
+            n_t = offs[t + 1] - offs[t]
+            items.append((offs[t], n_t, t * hw, plane_index(ci, j), cursor))
+            luts.append(st["lut_sub"][(ci, j)])
+            row.append((cursor, cursor + n_t))
+            cursor += n_t
+        sub_slices.append(row)
+    max_count = max([it[1] for it in items] + [0])
+    out = ops.labels_from_codes(planes, vox_all, np.asarray(items, np.int64).reshape(-1, 5), np.stack(luts), max_count, cursor)
+    local = vox_all[:n_total].long() - torch.repeat_interleave(
+        torch.arange(n_frames, device=vox_all.device) * hw, torch.as_tensor([offs[t + 1] - offs[t] for t in range(n_frames)], device=vox_all.device))
+    ys, xs = torch.div(local, w, rounding_mode="floor"), local % w
+    conv = (lambda x: x.cpu()) if outputs_on_cpu else (lambda x: x)
+    out_h, ys, xs = conv(out), conv(ys), conv(xs)
+    track = [out_h[offs[t]:offs[t + 1]] for t in range(n_frames)]
+    mask_idxes = [(ys[offs[t]:offs[t + 1]], xs[offs[t]:offs[t + 1]]) for t in range(n_frames)]
+    subseq_labels = [[out_h[a:b] for a, b in row] for row in sub_slices]
+    # per-id point counts / lifetimes (TrackContainer.get_track_mask_idxes, online_chainer.py:94-117) from the tables
+    from collections import defaultdict
+    counts, first, last = defaultdict(lambda: 0), {}, {}
+    for t in range(n_frames):
+        c, js = st["src"][t]
+        per_bin = tables[item_of[(c, js)]].sum(0)
+        ids = st["lut_track"][(c, js)]
+        agg = {}
+        for b in np.flatnonzero(per_bin[1:]) + 1:
+            agg[int(ids[b])] = agg.get(int(ids[b]), 0) + int(per_bin[b])
+        for k, n in agg.items():
+            counts[k] += n
+            first[k] = min(first.get(k, 10000), t)
+            last[k] = max(last.get(k, -1), t)
+    lifetimes = {k: last[k] - first[k] for k in first}
+    subseq_meta = []
+    for ci in range(n_clips):
+        info = clusterer.meta_to_dict(metas[ci], E_dims, st["label_start"][ci])
+        info["instance_labels"] = st["instance_labels"][ci]
+        subseq_meta.append(info)
+    if stats is not None:
+        ag1_ms, ag2_ms = (t_ag1.elapsed() if t_ag1 else 0.0), (t_ag2.elapsed() if t_ag2 else 0.0)     # (events long complete: no extra sync)
+        stats.update(allgather_ms=ag1_ms + ag2_ms, allgather_seediness_ms=ag1_ms, allgather_codes_ms=ag2_ms, host_chain_ms=host_ms,
+                     allgather_bytes=(seeds_local.numel() * 4 + codes_local.numel()) * (world - 1) if world > 1 else 0,
+                     n_clips=n_clips, clips_this_rank=len(mine), world=world)
+    return (track, counts, lifetimes), mask_idxes, subseq_labels, [], subseq_meta
+
+
+def _all_gather_stack(out, local, world, group):
+    import torch.distributed as dist
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local, group=group)
+    for r, p_ in enumerate(parts):
+        out[r] = p_
+
+
+class _Timer(object):
+    """Elapsed time of a collective: device events on the GPU (recorded on the caller's stream, read later -- no host
+    synchronisation of its own), wall clock on the host."""
+
+    def __init__(self, t):
+        import time
+        self.gpu = t.is_cuda
+        if self.gpu:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            self.t0 = time.perf_counter()
+
+    def stop(self):
+        import time
+        if self.gpu:
+            self.e1.record()
+        else:
+            self.ms = 1e3 * (time.perf_counter() - self.t0)
+
+    def elapsed(self):
+        if self.gpu:
+            self.e1.synchronize()
+            return self.e0.elapsed_time(self.e1)
+        return self.ms
+
+
+@torch.no_grad()
+def run_sequence_replicated(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
                          fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None):
-    """embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w], seed [1,T,h,w]) on this rank's device; or
+    """Round-2 partitioning, kept for A/B runs and as the cross-check of the clip-parallel chain: only the EMBEDDING is sharded;
+    every rank receives all [E+Ev+1, T, h4, w4] head outputs and replicates fg mask + clustering + stitching for all clips.
+    embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w], seed [1,T,h,w]) on this rank's device; or
     embed_many_fn(list of this rank's clips) -> list of stacked [E+Ev+1,T,h,w] blocks (e.g. ClipPipeline.embed_many: several clips
     per encoder pass) together with channel_split = (E, Ev).
     Returns OnlineChainer.process(...) output, identical on every rank.  ``stats`` (dict, optional) receives the exchange's

@@ -72,3 +72,65 @@ class OracleChainerOps(object):
     def max_label(self, labels_list):
         nz = [l for l in labels_list if l.numel() > 0]
         return int(torch.cat(nz).max().item()) if nz else None
+
+    # ---- clip-parallel stitching twins (pipeline.run_sequence_sharded) ---------------------------------------------------
+    def compact(self, fg):
+        f = fg.numpy().reshape(fg.shape[0], -1)
+        vox = np.flatnonzero(f.reshape(-1)).astype(np.int32)
+        offs = np.concatenate([[0], np.cumsum(f.astype(bool).sum(1))]).astype(np.int64)
+        out = np.zeros(f.size, np.int32)
+        out[:vox.size] = vox
+        return torch.from_numpy(out), torch.from_numpy(offs)
+
+    def codes_from_labels(self, pts, labels, label_start, out):
+        n = int(pts["offs"][pts["T"]])
+        lab = labels.numpy()[:n]
+        out.zero_()
+        code = np.where(lab < 0, 255, lab - label_start + 1).astype(np.uint8)
+        out.numpy()[pts["vox"].numpy()[:n]] = code
+
+    def meta_bytes(self):
+        import ctypes
+        from stemseg_amd import hip
+        return ctypes.sizeof(hip.ClusterMeta)
+
+    def pack_meta(self, m):
+        import ctypes
+        from stemseg_amd import hip
+        rec = hip.ClusterMeta()
+        rec.K = m.K
+        for i in range(m.K):
+            for e in range(8):
+                rec.centers[i][e] = m.centers[i][e]
+                rec.bandwidths[i][e] = m.bandwidths[i][e]
+        return torch.from_numpy(np.frombuffer(bytes(rec), np.uint8).copy())
+
+    def unpack_meta(self, raw):
+        from stemseg_amd import hip
+        return hip.ClusterMeta.from_buffer_copy(bytes(raw))
+
+    @staticmethod
+    def _bins(c, B):
+        c = c.astype(np.int64)
+        return np.where(c == 255, B - 1, np.minimum(c, B - 1))
+
+    def pair_tables(self, codes, plane_a, plane_b, B):
+        c = codes.numpy()
+        out = np.zeros((len(plane_b), B, B), np.int32)
+        for k, (pa, pb) in enumerate(zip(plane_a, plane_b)):
+            b = c[pb]
+            m = b != 0
+            a = c[pa][m] if pa >= 0 else np.zeros(int(m.sum()), np.uint8)
+            out[k] = np.bincount(self._bins(a, B) * B + self._bins(b[m], B), minlength=B * B).reshape(B, B)
+        return torch.from_numpy(out)
+
+    def read_back(self, *tensors):
+        return [t.numpy().copy() for t in tensors]
+
+    def labels_from_codes(self, codes, vox, items, lut, max_count, n_out):
+        c, v = codes.numpy(), vox.numpy().astype(np.int64)
+        B = lut.shape[1]
+        out = np.zeros(n_out, np.int64)
+        for (src, cnt, vbase, plane, dst), l in zip(np.asarray(items).tolist(), np.asarray(lut)):
+            out[dst:dst + cnt] = l[self._bins(c[plane][v[src:src + cnt] - vbase], B)]
+        return torch.from_numpy(out)

@@ -1,6 +1,7 @@
-"""world_size-2 gloo test of the clip-sharded sequence path (stemseg_amd.pipeline.run_sequence_sharded):
-clips dealt round-robin, one all-gather of per-clip head outputs, replicated chain -> every rank must reproduce the
-single-process (reference-generated) golden result bit for bit.  Device ops are the oracle twin (no GPU here)."""
+"""gloo tests (world 1 / 2 / 3 / 8) of the clip-parallel sequence path (stemseg_amd.pipeline.run_sequence_sharded):
+every rank embeds AND clusters only its own clips with label_start = 1, two all-gathers (seediness planes; one-byte label
+codes + clustering records), the Hungarian chain runs on label-pair tables -> every rank must reproduce the single-process
+(reference-generated) golden result bit for bit.  Device ops are the oracle twin (no GPU here)."""
 import os
 import sys
 
@@ -13,7 +14,63 @@ import torch.multiprocessing as mp
 from tests.conftest import GOLDEN, ROOT
 
 
-def _worker(rank, world, port, tag, q):
+def _case(tag):
+    """-> (emb, bw, sd, fg, clips, overlap, expected dict) for a ``chainer.npz`` tag or the 48-clip ``long`` sequence."""
+    from tests import synth
+    if tag == "long":
+        g = np.load(os.path.join(GOLDEN, "chainer_long.npz"))
+        emb, bw, sd, fg = synth.synth_long_sequence(int(g["n_clips"]), seed=int(g["seed"]))
+        _, _, exp = synth.long_sequence_case(g, torch.from_numpy)
+        clips = [list(range(4 * i, 4 * i + 8)) for i in range(int(g["n_clips"]))]
+        return emb, bw, sd, fg, clips, 4, exp
+    g = np.load(os.path.join(GOLDEN, "chainer.npz"))
+    emb, bw, sd, fg = g[tag + "__emb"], g[tag + "__bw"], g[tag + "__sd"], g[tag + "__fg"]
+    clips = g[tag + "__subseqs"].tolist()
+    exp = dict(track=[g["%s_track_%02d" % (tag, t)] for t in range(fg.shape[0])],
+               counts=[tuple(r) for r in g[tag + "__pt_counts"].tolist()], life=[tuple(r) for r in g[tag + "__lifetimes"].tolist()],
+               instance_labels=[g["%s_clip%d_instance_labels" % (tag, i)].tolist() for i in range(len(clips))],
+               clip_labels=[g["%s_clip%d_labels" % (tag, i)] for i in range(len(clips))])
+    overlap = len(set(clips[0]) & set(clips[1])) if len(clips) > 1 else 4
+    return emb, bw, sd, fg, clips, overlap, exp
+
+
+def _run(tag, fn_name="run_sequence_sharded"):
+    """The sharded driver on this process's rank; -> (ok, clips embedded here, clips clustered here, expected own clips)."""
+    from stemseg_amd import config, pipeline
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    from tests.oracle_ops import OracleChainerOps
+    emb, bw, sd, fg, clips, overlap, exp = _case(tag)
+    config.load_preset("davis")
+    calls, clustered = [], []
+
+    def embed(frames):
+        calls.append(list(frames))
+        return (torch.from_numpy(emb[:, frames].copy()), torch.from_numpy(bw[:, frames].copy()), torch.from_numpy(sd[:, frames].copy()))
+
+    class CountingOps(OracleChainerOps):
+        def cluster(self, clusterer, pts, label_start, want_masks):
+            clustered.append(label_start)
+            return super().cluster(clusterer, pts, label_start, want_masks)
+    chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0, ops=CountingOps())
+    stats = {}
+    (track, counts, life), mask_idxes, clip_labels, _, meta = getattr(pipeline, fn_name)(
+        fg.shape[0], embed, chainer, "davis", frame_overlap=overlap, fg_mask_fn=lambda entries, thr: torch.from_numpy(fg), stats=stats)
+    ok = len(track) == len(exp["track"]) and all(l.dtype == torch.int64 and np.array_equal(l.numpy(), e) for l, e in zip(track, exp["track"]))
+    ok = ok and sorted(counts.items()) == exp["counts"] and sorted(life.items()) == exp["life"]
+    ok = ok and [m["instance_labels"] for m in meta] == exp["instance_labels"]
+    for t in range(fg.shape[0]):
+        ys, xs = np.nonzero(fg[t])
+        ok = ok and np.array_equal(mask_idxes[t][0].numpy(), ys) and np.array_equal(mask_idxes[t][1].numpy(), xs)
+    if "clip_labels" in exp:
+        ok = ok and all(np.array_equal(torch.cat(clip_labels[i]).numpy(), exp["clip_labels"][i]) for i in range(len(clips)))
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    mine = [clips[i] for i in pipeline.shard_clips(len(clips), rank, world)]
+    return bool(ok), calls, clustered, mine, len(clips)
+
+
+def _worker(rank, world, port, tag, fn_name, q):
     for p in (ROOT, os.path.join(ROOT, "stem-seg_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -21,48 +78,62 @@ def _worker(rank, world, port, tag, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from stemseg_amd import config
-        from stemseg_amd.inference.clusterers import SequentialClustering
-        from stemseg_amd.inference.online_chainer import OnlineChainer
-        from stemseg_amd.pipeline import run_sequence_sharded, shard_clips
-        from tests.oracle_ops import OracleChainerOps
-        g = np.load(os.path.join(GOLDEN, "chainer.npz"))
-        emb, bw, sd, fg = g[tag + "__emb"], g[tag + "__bw"], g[tag + "__sd"], g[tag + "__fg"]
-        clips = g[tag + "__subseqs"].tolist()
-        overlap = len(set(clips[0]) & set(clips[1])) if len(clips) > 1 else 4
-        config.load_preset("davis")
-        calls = []
-
-        def embed(frames):
-            calls.append(list(frames))
-            return (torch.from_numpy(emb[:, frames].copy()), torch.from_numpy(bw[:, frames].copy()), torch.from_numpy(sd[:, frames].copy()))
-        chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0, ops=OracleChainerOps())
-        (track, counts, life), _, _, _, meta = run_sequence_sharded(
-            fg.shape[0], embed, chainer, "davis", frame_overlap=overlap, fg_mask_fn=lambda entries, thr: torch.from_numpy(fg))
-        ok = all(np.array_equal(l.numpy(), g["%s_track_%02d" % (tag, t)]) for t, l in enumerate(track))
-        ok = ok and sorted(counts.items()) == [tuple(r) for r in g[tag + "__pt_counts"].tolist()]
-        ok = ok and all(meta[i]["instance_labels"] == g["%s_clip%d_instance_labels" % (tag, i)].tolist() for i in range(len(clips)))
-        ok = ok and calls == [clips[i] for i in shard_clips(len(clips), rank, world)]     # each rank embedded only its own clips
-        q.put((rank, bool(ok), len(calls)))
+        ok, calls, clustered, mine, n_clips = _run(tag, fn_name)
+        ok = ok and calls == mine                                         # each rank embedded only its own clips
+        if fn_name == "run_sequence_sharded":
+            ok = ok and clustered == [1] * len(mine)                      # ... and clustered only those, with label_start = 1
+        else:
+            ok = ok and len(clustered) == n_clips                         # (round-2 partitioning: the chain is replicated)
+        q.put((rank, bool(ok), len(calls), len(clustered)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single"])
-def test_sharded_sequence_two_ranks_gloo(tag):
+_PORTS = {}
+
+
+def _spawn(world, tag, fn_name="run_sequence_sharded"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400) + {"seq20_ov4": 0, "seq14_ov6": 1, "seq8_single": 2}[tag]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tag, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 300) + len(_PORTS)
+    _PORTS[(world, tag, fn_name)] = port
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tag, fn_name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [True, True], res
+    assert [r[1] for r in res] == [True] * world, res
+    return res
+
+
+@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single", "long"])
+def test_clip_parallel_chain_one_process_vs_golden(tag):
+    """world 1 (no process group): the table-based chain alone against the reference's outputs -- tracks, per-clip label lists,
+    coordinates, counts, lifetimes, instance lists; `long` drives the track ids to 527."""
+    ok, calls, clustered, mine, n_clips = _run(tag)
+    assert ok and len(calls) == n_clips and clustered == [1] * n_clips
+
+
+@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single"])
+def test_sharded_sequence_two_ranks_gloo(tag):
+    res = _spawn(2, tag)
     n_clips = {"seq20_ov4": 4, "seq14_ov6": 4, "seq8_single": 1}[tag]
-    assert sum(r[2] for r in res) == n_clips
+    assert sum(r[2] for r in res) == n_clips and sum(r[3] for r in res) == n_clips
+
+
+@pytest.mark.parametrize("world,tag", [(3, "seq20_ov4"), (3, "seq14_ov6"), (8, "long"), (8, "seq20_ov4")])
+def test_sharded_sequence_three_and_eight_ranks_gloo(world, tag):
+    """world 3: uneven blocks; world 8 on the 48-clip sequence: 6 clips per rank, ids to 527; world 8 on 4 clips: idle ranks."""
+    res = _spawn(world, tag)
+    n_clips = {"seq20_ov4": 4, "seq14_ov6": 4, "long": 48}[tag]
+    assert sum(r[2] for r in res) == n_clips and sum(r[3] for r in res) == n_clips
+
+
+def test_replicated_partitioning_still_matches_two_ranks_gloo():
+    """The round-2 form (only the embedding sharded, chain replicated) stays available as the cross-check."""
+    _spawn(2, "seq20_ov4", "run_sequence_replicated")
 
 
 def test_shard_clips_contiguous_blocks():
