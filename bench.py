@@ -12,14 +12,25 @@ clustering record (K, instance list), with the input frames already resident in 
 per lane; --lanes (default 3) steps are in flight on their own streams and workspaces.  value = clips / s.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
 are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
 
+    python bench.py --gpus N                          # N > 1 without a launcher: re-executes itself under torch.distributed.run
+    python bench.py --workload davis|ytvis|kitti      # BASELINE configs[1] (default) | configs[2] | configs[4]
     python bench.py --sequence [--frames 64|36]      # BASELINE configs[3]: ONE long sequence sharded over the ranks
 
 --sequence: a step = the whole sequence through ``pipeline.run_sequence_sharded`` -- clips dealt to the ranks in contiguous blocks
-(64 frames / overlap 4 -> 15 clips; 36 frames -> exactly 8, one per GPU at N = 8), every rank embeds its block of clips (up to 4
-per encoder pass; frames shared by neighbouring clips pass the trunk once; full batches as hipGraph replays), ONE all-gather (RCCL over xGMI) of the head outputs INSIDE the timed region, then the
-replicated chain (cross-clip fg mask, clustering, Hungarian stitching).  value = clips / s of the whole job (strong scaling:
-the sequence is fixed); the line also carries the all-gather's bytes / time and a checksum of the stitched track labels that
-must be the same at every N.  The default mode and this one share the model, weights and kernels.
+(64 frames / overlap 4 -> 15 clips; 36 frames -> exactly 8, one per GPU at N = 8); every rank embeds its block of clips (up to 8
+windows per encoder pass; frames shared by neighbouring clips pass the trunk once; full batches as hipGraph replays), all-gather #1
+(RCCL over xGMI) of the SEEDINESS planes -> cross-clip foreground mask; every rank gathers + clusters ITS OWN clips with
+label_start = 1; all-gather #2 of the one-byte label codes; the Hungarian chain runs on label-pair tables (host, microseconds per
+clip).  Both collectives are INSIDE the timed region.  value = clips / s of the whole job (strong scaling: the sequence is
+fixed); the line also carries the exchanges' bytes / time and a checksum of the stitched track labels that must be the same at
+every N.  ``--partition replicated`` selects the round-2 form (every rank receives all head outputs and repeats the whole chain)
+for A/B runs.  The default mode and this one share the model, weights and kernels.
+
+--workload: ``davis`` = BASELINE configs[1] (the metric's configuration, the default: T=8, 480x854 -> 480x864, R-101-FPN,
+embedding + seediness decoders); ``ytvis`` = configs[2] (T=8, 360x640 -> 384x640, youtube_vis.yaml heads: in-head seediness, 41+1
+class semseg decoder, --resize_embeddings: x4 trilinear of the head outputs and clustering at FULL resolution); ``kitti`` =
+configs[4] (T=8, 375x1242 --max_dim 1948 -> 608x1952, kitti_mots_2.yaml: xyt embeddings, 3+1 class semseg decoder, foreground
+from the semseg head).  Same JSON schema for all three.
 """
 import argparse
 import json
@@ -37,8 +48,29 @@ PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_conv3d_block4x_latest.json")   # written by tools/pmc_conv.py's summary step
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # same guide: bf16 MFMA, dense (the 2:1-sparse 5 PF figure is not used)
 PEAK_HBM_GBPS = 8000.0            # same guide: HBM3E, ~8 TB/s
-T, H, W = 8, 480, 864             # BASELINE config 1: DAVIS-shape 480p (480x854 padded to a multiple of 32)
 BACKBONE = "R-101-FPN"
+# BASELINE.json configs -> concrete shapes: padded network input H x W, the un-padded (valid) size, preset
+WORKLOADS = {
+    "davis": dict(T=8, H=480, W=864, valid=(480, 854), preset="davis", min_dim=480, max_dim=854, resize=1.0, model_kw={}, dim_mode="xyff",
+                  name="BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + seediness decoders, "
+                       "fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE),
+    "ytvis": dict(T=8, H=384, W=640, valid=(360, 640), preset="ytvis", min_dim=360, max_dim=640, resize=4.0, model_kw={"resize_scale": 4.0}, dim_mode="xyff",
+                  name="BASELINE configs[2]: YouTube-VIS-shape clips T=8 360x640 (padded 384x640), %s, youtube_vis.yaml heads (embedding "
+                       "decoder with in-head seediness, 41+1-class semseg decoder), --resize_embeddings: x4 trilinear of emb / bandwidth / "
+                       "seediness / class logits, fg = semseg fg probability > 0.5, clustering at FULL resolution (1.97 M voxels)" % BACKBONE),
+    "kitti": dict(T=8, H=608, W=1952, valid=(588, 1948), preset="kittimots", min_dim=800, max_dim=1948, resize=1.0, model_kw={}, dim_mode="xyt",
+                  name="BASELINE configs[4]: KITTI-MOTS-shape clips T=8 375x1242 --max_dim 1948 -> 588x1948 (padded 608x1952), %s, "
+                       "kitti_mots_2.yaml heads (xyt embeddings E = Ev = 3 with in-head seediness, 3+1-class semseg decoder), fg = semseg fg "
+                       "probability > 0.5, SequentialClustering (MIN_SEEDINESS_PROB 0.95)" % BACKBONE),
+}
+WL = WORKLOADS["davis"]
+T, H, W = WL["T"], WL["H"], WL["W"]
+
+
+def select_workload(name):
+    global WL, T, H, W
+    WL = WORKLOADS[name]
+    T, H, W = WL["T"], WL["H"], WL["W"]
 
 
 def synth_weights_(module, seed, seediness_gain=30.0):
@@ -78,10 +110,10 @@ def build_pipeline(device):
     from stemseg_amd import config
     from stemseg_amd.modeling.inference_model import InferenceModel
     from stemseg_amd.pipeline import ClipPipeline
-    config.load_preset("davis")
+    config.load_preset(WL["preset"])
     config.cfg.MODEL.BACKBONE.TYPE = BACKBONE
-    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = 480, 854
-    model = InferenceModel()
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = WL["min_dim"], WL["max_dim"]
+    model = InferenceModel(**WL["model_kw"])
     sd = synth_weights_(model._model, seed=1234)
     return ClipPipeline(model, device=device), sd
 
@@ -89,10 +121,11 @@ def build_pipeline(device):
 def make_clip(seed, device):
     g = torch.Generator(device="cpu").manual_seed(seed)
     frames = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.int32).float()
-    frames[:, :, :, 854:] = 102.9801          # right padding columns are zero after mean subtraction
     mean = torch.tensor([102.9801, 115.9465, 122.7717])[None, :, None, None]
     x = frames - mean
-    x[:, :, :, 854:] = 0.0
+    vh, vw = WL["valid"]
+    x[:, :, :, vw:] = 0.0                     # right / bottom padding is zero after mean subtraction (image_list.py:93-104)
+    x[:, :, vh:, :] = 0.0
     return x.to(device)
 
 
@@ -156,9 +189,15 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
     chainer = pipe.tg.chainer
     stats, ag_ms, res = {}, [], None
 
+    replicated = args.partition == "replicated"
+
     def one():
+        if replicated:
+            from stemseg_amd.pipeline import run_sequence_replicated
+            return run_sequence_replicated(F, None, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats,
+                                           embed_many_fn=embed_many, channel_split=split)
         return run_sequence_sharded(F, None, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats,
-                                    embed_many_fn=embed_many, channel_split=split)
+                                    embed_many_fn=embed_many, channel_split=split, outputs_on_cpu=False)
 
     def sync():
         torch.cuda.synchronize()
@@ -168,13 +207,16 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
         res = one()
     sync()
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(args.steps):
         res = one()
         ag_ms.append(stats["allgather_ms"])
+        host_ms.append(stats.get("host_chain_ms", 0.0))
     sync()
     dt = time.perf_counter() - t0
     (track, counts, life) = res[0]
     crc = zlib.crc32(torch.cat([t.cpu() for t in track]).numpy().tobytes()) if track else 0
+    ranks = rank_devices(device, rank, world, use_dist)
     if use_dist:
         t = torch.tensor([dt, float(crc)], dtype=torch.float64, device=device)
         tmax = t.clone()
@@ -187,19 +229,100 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
         n_clips = len(clips)
         print(json.dumps({
             "metric": "clips/sec (T=8, 480p) embed+cluster, one %d-frame sequence sharded over the GPUs" % F,
-            "value": round(n_clips * args.steps / dt, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(n_clips * args.steps / dt, 4), "unit": "clips/s", "n_gpus": world, "ranks": ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt in contiguous blocks "
-                                   "to %d rank(s), %s, both decoders; all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + "
-                                   "clustering + Hungarian stitching" % (F, overlap, n_clips, world, BACKBONE),
+                                   "to %d rank(s), %s, both decoders; %s" % (F, overlap, n_clips, world, BACKBONE,
+                                   "all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + clustering + Hungarian stitching (round-2 partitioning)"
+                                   if replicated else "all-gather #1 of the seediness planes -> fg mask; every rank clusters ITS clips with label_start = 1; "
+                                   "all-gather #2 of one-byte label codes + clustering records; Hungarian chain on label-pair tables (host)"),
                        "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "%d clips per encoder pass, %s" % (max(1, args.clips_per_step), "eager" if args.no_graph else "full batches as hipGraph replays on 2 lanes"),
                        "switches": library_switches()},
             "exchange": {"collective": ("all_gather (%s)" % ("RCCL" if os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl" else
                                                              os.environ["STEMSEG_BENCH_BACKEND"] + ": functional check, ranks share a GPU")) if world > 1 else "none (one rank)", "bytes_received_per_rank": stats["allgather_bytes"],
-                         "ms_median": round(sorted(ag_ms)[len(ag_ms) // 2], 3) if ag_ms else 0.0, "inside_timed_region": True},
+                         "ms_median": round(sorted(ag_ms)[len(ag_ms) // 2], 3) if ag_ms else 0.0, "inside_timed_region": True,
+                         "host_chain_ms_median": round(sorted(host_ms)[len(host_ms) // 2], 3) if host_ms else 0.0,
+                         "partition": args.partition},
             "result": {"frames": len(track), "fg_points": int(sum(counts.values())), "highest_track_id": int(max(list(counts) + [0])),
                        "label_checksum_crc32": int(crc), "note": "the checksum must be identical for every --gpus N"}}))
+
+
+def rank_devices(device, rank, world, use_dist):
+    """[{rank, device, name}] as the process group actually sees them (all-gathered) -- n_gpus in the line is len() of this."""
+    import torch.distributed as dist
+    if device.type != "cuda":
+        mine = [rank, -1]
+    else:
+        mine = [rank, device.index]
+    if not use_dist:
+        return [{"rank": mine[0], "device": mine[1]}]
+    t = torch.tensor(mine, dtype=torch.int64, device=device)
+    outs = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [{"rank": int(o[0]), "device": int(o[1])} for o in outs]
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: run this very command line under
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``, one rank per GPU over RCCL.
+    Refuses (exit code 3, nothing printed on stdout) when the box has fewer than N devices."""
+    import subprocess
+    backend = os.environ.get("STEMSEG_BENCH_BACKEND", "nccl")
+    stub = os.environ.get("STEMSEG_BENCH_STUB") == "1"
+    if backend == "nccl" and not stub:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print("[bench] --gpus %d requested but only %d device(s) are visible: not printing a line" % (args.gpus, n_dev), file=sys.stderr)
+            sys.exit(3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["STEMSEG_BENCH_CHILD"] = "1"
+    print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def stub_main(args, rank, world, use_dist):
+    """STEMSEG_BENCH_STUB=1 (tests only): the launcher, the process group, the barrier / max-over-ranks timing and the JSON
+    line of the real bench with a no-op step -- runs on a machine without a GPU (gloo)."""
+    import torch.distributed as dist
+    device = torch.device("cpu")
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    sync()
+    dt = time.perf_counter() - t0
+    ranks = rank_devices(device, rank, world, use_dist)
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(args.steps * world / dt, 4), "unit": "clips/s",
+                          "n_gpus": len(ranks), "ranks": ranks, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "synthetic", "config": {"workload": "STUB (no-op step): launcher / process-group test only"},
+                          "stub": True}))
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def library_switches():
@@ -236,24 +359,45 @@ def main():
                     help="BASELINE configs[3]: one long sequence, clips sharded over the ranks in contiguous blocks, RCCL all-gather of the head "
                          "outputs inside the timed region, replicated stitching (see the module docstring)")
     ap.add_argument("--frames", type=int, default=64, help="--sequence: frames of the sequence (64 -> 15 clips at overlap 4; 36 -> 8)")
+    ap.add_argument("--workload", default="davis", choices=sorted(WORKLOADS), help="BASELINE config to run (default: configs[1], the metric's)")
+    ap.add_argument("--partition", default="clips", choices=["clips", "replicated"],
+                    help="--sequence: 'clips' = every rank clusters its own clips, label codes exchanged (SURVEY 8(e)); 'replicated' = round-2 form")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
     args.graph = not args.no_graph
     if args.clips_per_step is None:          # default: 4 independent clips per encoder pass; --sequence: 8 overlapping windows (36 frames)
-        args.clips_per_step = 8 if args.sequence else 4
+        args.clips_per_step = 8 if args.sequence else (2 if args.workload == "kitti" else 4)      # (a KITTI clip is 2.9 DAVIS clips of pixels)
 
+    select_workload(args.workload)
+    if args.sequence and args.workload != "davis":
+        ap.error("--sequence is BASELINE configs[3] (DAVIS-shape frames); --workload applies to the clip bench")
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ                  # under torch.distributed.run (ours or the driver's)
+    if args.gpus > 1 and not launched:
+        self_launch(args)                                                            # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        print("[bench] --gpus %d but the launcher started %d rank(s): refusing to print a line" % (args.gpus, world), file=sys.stderr)
+        sys.exit(4)
     import torch.distributed as dist
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    use_dist = world > 1 or launched
+    stub = os.environ.get("STEMSEG_BENCH_STUB") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # STEMSEG_BENCH_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices,
         # the exchange goes through the host) -- never a performance number; the line's config says so
-        backend = os.environ.get("STEMSEG_BENCH_BACKEND", "nccl")
+        backend = "gloo" if stub else os.environ.get("STEMSEG_BENCH_BACKEND", "nccl")
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if stub:
+        return stub_main(args, rank, world, use_dist)
+    if use_dist:
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            print("[bench] %d ranks but only %d device(s) visible: refusing to print a line" % (world, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(3)
         if backend != "nccl":
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
@@ -362,10 +506,13 @@ def main():
     prof = hip.profile_read()
     hip.profile_enable(False)
     pipe.model.overlap_decoders = overlap
+    ranks = rank_devices(device, rank, world, use_dist)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl":
+            assert len({r["device"] for r in ranks}) == world, "ranks share a device: %s" % (ranks,)
 
     if rank == 0:
         clips_total = args.steps * world * NC
@@ -403,14 +550,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 traffic_note = "could not read %s: %r" % (TRAFFIC_FILE, e)
         res = {
-            "metric": "clips/sec (T=8, 480p) embed+cluster", "value": round(clips_total / dt, 4), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "metric": "clips/sec (T=8, 480p) embed+cluster" if args.workload == "davis" else "clips/sec (T=8, %dx%d) embed+cluster" % (H, W),
+            "value": round(clips_total / dt, 4), "unit": "clips/s",
+            "n_gpus": len(ranks), "ranks": ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 operands as bf16x3 split (3 bf16 MFMAs per product, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DAVIS-shape clips T=8 480x854 (padded 480x864), %s, embedding + "
-                                   "seediness decoders, fg = seediness > 0.25, SequentialClustering (<= 20 instances)" % BACKBONE,
-                       "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
+            "config": {"workload": WL["name"], "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
                        "switches": library_switches()},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
@@ -428,7 +574,7 @@ def main():
                          "conv_classes_eager": breakdown,
                          "hbm_kernels_eager": {"peak_gb_per_s": PEAK_HBM_GBPS, "bytes": "algorithmic: inputs read once + outputs written once", "kernels": hbm}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "davis":
             try:
                 pipe.model.set_lane(0)
                 gpu_out = pipe.step(clips[0][:T].contiguous())

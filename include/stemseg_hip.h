@@ -383,6 +383,12 @@ int stemseg_hip_semseg_accumulate(float* acc, const float* clip_logits, int32_t 
 int stemseg_hip_semseg_masks(const float* acc, const float* counts, int32_t F, int32_t C, int64_t HW, int32_t output_type,
                              float* fg, void* multiclass, void* stream);
 
+/* The same for ONE clip on its own (independent clips: every frame belongs to exactly one clip, the mean over clips is the
+ * clip's own logits): clip_logits [C][T][HW] -> fg_prob float [T][HW] (may be NULL) and fg_mask uint8 [T][HW] = fg_prob > thr
+ * (may be NULL) -- inference_model.py:197-231 + inference/main.py:142-144 without the [F][C][HW] accumulator round trip. */
+int stemseg_hip_semseg_fg_clip(const float* clip_logits, int32_t C, int32_t T, int64_t HW, float thr, float* fg_prob,
+                               uint8_t* fg_mask, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Pre-processing (inference_image_loader.py:23-43, data/common.py:12-30, structures/image_list.py:93-104), one launch:
  * frames uint8 [T][H0][W0][3] (device) -> bilinear resize to (new_h, new_w), align_corners=False -> optional / 255 ->

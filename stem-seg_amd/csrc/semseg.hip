@@ -72,7 +72,39 @@ __global__ __launch_bounds__(256) void semseg_masks_kernel(const float* __restri
     }
 }
 
+// One clip on its own (no cross-clip averaging: count 1, mean = 0. + x = x): foreground probability and the > thr mask straight
+// from the decoder's [C][T][HW] logits -- reads the 1 (C > 2) or 2 (C == 2) channels that matter, same arithmetic as
+// accumulate + masks.
+__global__ __launch_bounds__(256) void semseg_fg_clip_kernel(const float* __restrict__ logits, int C, long long THW, float thr,
+                                                             float* __restrict__ prob, unsigned char* __restrict__ mask) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < THW; i += (long long)gridDim.x * blockDim.x) {
+        float pr;
+        if (C == 2) {
+            const float x0 = __fdiv_rn(__fadd_rn(0.f, logits[i]), 1.f), x1 = __fdiv_rn(__fadd_rn(0.f, logits[THW + i]), 1.f);
+            const float m = fmaxf(x0, x1);
+            const float e0 = expf(x0 - m), e1 = expf(x1 - m);
+            pr = __fdiv_rn(e1, __fadd_rn(e0, e1));
+        } else {
+            const float xf = __fdiv_rn(__fadd_rn(0.f, logits[(long long)(C - 1) * THW + i]), 1.f);
+            pr = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-xf)));
+        }
+        if (prob) prob[i] = pr;
+        if (mask) mask[i] = (__fdiv_rn(pr, 1.f) > thr) ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int stemseg_hip_semseg_fg_clip(const float* clip_logits, int32_t C, int32_t T, int64_t HW, float thr, float* fg_prob,
+                                          uint8_t* fg_mask, void* stream) {
+    SS_CHECK_ARG(clip_logits && (fg_prob || fg_mask), "semseg_fg_clip: null pointer");
+    SS_CHECK_ARG(C >= 2 && T >= 1 && HW >= 1, "semseg_fg_clip: bad dims C=%d T=%d", C, T);
+    const long long n = (long long)T * HW;
+    hipLaunchKernelGGL(semseg_fg_clip_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(ceil_div(n, 256), 4096))), dim3(256), 0,
+                       as_stream(stream), clip_logits, C, n, thr, fg_prob, fg_mask);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
 
 extern "C" int stemseg_hip_semseg_accumulate(float* acc, const float* clip_logits, int32_t C, int32_t T, int64_t HW,
                                              const int32_t* frame_index, int32_t n_frames, void* stream) {

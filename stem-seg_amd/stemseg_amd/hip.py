@@ -114,6 +114,7 @@ SIGNATURES = {
     "stemseg_hip_codes_to_labels": (C.c_int, [_P, _P, _P, _I32, _I64, _P, _I64, _I32, _P, _P]),
     "stemseg_hip_semseg_accumulate": (C.c_int, [_P, _P, _I32, _I32, _I64, C.POINTER(C.c_int32), _I32, _P]),
     "stemseg_hip_semseg_masks": (C.c_int, [_P, _P, _I32, _I32, _I64, _I32, _P, _P, _P]),
+    "stemseg_hip_semseg_fg_clip": (C.c_int, [_P, _I32, _I32, _I64, _F, _P, _P, _P]),
     "stemseg_hip_preprocess_frames": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(C.c_float), C.POINTER(C.c_float), _I32, _I32, _P, _P]),
     "stemseg_hip_scatter_instance_index": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _P]),
     "stemseg_hip_resample_instance_masks": (C.c_int, [_P, _I32, _I32, C.c_float, _I32, _I32, _I32, _I32, _P, _P]),
@@ -500,6 +501,16 @@ def semseg_masks(acc, counts, output_type="probs"):
         mc = torch.empty(Fn, Cn - 1, H, W, dtype=torch.float32, device=acc.device)
     check(lib().stemseg_hip_semseg_masks(ptr(acc, torch.float32), ptr(counts, torch.float32), Fn, Cn, H * W, code, ptr(fg), ptr(mc) if mc is not None else None, stream()))
     return fg, mc
+
+
+def semseg_fg_clip(clip_logits, thr=0.5, want_prob=False):
+    """One independent clip: logits [C,T,H,W] -> (fg mask uint8 [T,H,W], fg probability float [T,H,W] | None)."""
+    require_gpu()
+    Cn, T, H, W = clip_logits.shape
+    mask = torch.empty(T, H, W, dtype=torch.uint8, device=clip_logits.device)
+    prob = torch.empty(T, H, W, dtype=torch.float32, device=clip_logits.device) if want_prob else None
+    check(lib().stemseg_hip_semseg_fg_clip(ptr(clip_logits, torch.float32), Cn, T, H * W, float(thr), ptr(prob), ptr(mask), stream()))
+    return mask, prob
 
 
 def scatter_instance_index(ys, xs, labels, lut, H, W):

@@ -232,11 +232,11 @@ class InferenceModel(nn.Module):
         return emb, bw, seed
 
     @torch.no_grad()
-    def semseg_logits_clip(self, T, H, W, dev):
-        """Class logits [C, T, h4*r, w4*r] of the clip whose features sit in the zero-haloed buffers (inference_model.py:121-124)."""
+    def semseg_logits_clip(self, T, H, W, dev, slot=0):
+        """Class logits [C, T, h4*r, w4*r] of the clip whose features sit in the zero-haloed buffers of ``slot`` (inference_model.py:121-124)."""
         sh = self._model.semseg_head
         sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
-        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev)], (T, H // 4, W // 4)), 2)
+        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2)
         if self.resize_scale != 1.0:
             logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return logits.contiguous()

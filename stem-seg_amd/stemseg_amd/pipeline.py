@@ -31,34 +31,51 @@ class ClipPipeline(object):
         return self.model.embed_frames(frames.contiguous())
 
     @torch.no_grad()
-    def cluster(self, emb, bw, seed, label_start=1):
-        """Single-clip fg mask (seediness > thr), gather, clustering.  Returns device tensors only."""
+    def cluster(self, emb, bw, seed, label_start=1, fg=None):
+        """Single-clip fg mask (seediness > thr unless ``fg`` is given), gather, clustering.  Returns device tensors only."""
         T = seed.shape[1]
-        acc = torch.empty_like(seed[0])
-        hip.seediness_accumulate(acc, seed[0].contiguous(), True)
-        fg = hip.fg_mask(acc, 1.0, self.seediness_thresh)
+        if fg is None:
+            acc = torch.empty_like(seed[0])
+            hip.seediness_accumulate(acc, seed[0].contiguous(), True)
+            fg = hip.fg_mask(acc, 1.0, self.seediness_thresh)
         e, b, s, vox, offs = hip.fg_gather(emb.contiguous(), bw.contiguous(), seed.contiguous(), fg)
         labels, meta_dev, _, _ = self.clusterer.enqueue(e, b, s, label_start, offs[T:])
         return dict(labels=labels, meta=meta_dev, voxel_index=vox, frame_offsets=offs, fg=fg)
 
-    @torch.no_grad()
-    def step(self, frames):
-        emb, bw, seed = self.embed(frames)
-        out = self.cluster(emb, bw, seed)
+    def _finish_clip(self, emb, bw, seed, T, H, W, slot=0):
+        """Everything after the embedding decoder of one independent clip.  Presets with a semseg head (YouTube-VIS, KITTI-MOTS):
+        third decoder -> class logits (x resize_scale, inference_model.py:121-124) -> foreground = its fg probability > 0.5
+        (inference_model.py:197-231, inference/main.py:142-144); under --resize_embeddings the head outputs are up-sampled x4 and
+        the clip is clustered at full resolution (online_chainer.py:127-140)."""
+        fg, logits = None, None
+        if self.model.has_semseg_head:
+            logits = self.model.semseg_logits_clip(T, H, W, emb.device, slot=slot)
+            fg, _ = hip.semseg_fg_clip(logits, 0.5)
+        r = int(self.model.resize_scale)
+        if r != 1:
+            emb, bw = hip.upsample_trilinear(emb.contiguous(), 1, r, r), hip.upsample_trilinear(bw.contiguous(), 1, r, r)
+            if seed.shape[-1] != emb.shape[-1]:          # (a separate seediness head is already resized by the model, :156)
+                seed = hip.upsample_trilinear(seed.contiguous(), 1, r, r)
+        out = self.cluster(emb, bw, seed, fg=fg)
         out.update(emb=emb, bw=bw, seed=seed)
+        if logits is not None:
+            out["semseg_logits"] = logits
         return out
 
+    @torch.no_grad()
+    def step(self, frames):
+        T, _, H, W = frames.shape
+        emb, bw, seed = self.embed(frames)
+        return self._finish_clip(emb, bw, seed, T, H, W)
 
     @torch.no_grad()
     def step_batch(self, frames, n_clips):
         """``n_clips`` clips stacked along the frame axis ([n_clips * T, 3, H, W]): one encoder pass, then decoders + fg mask +
         gather + clustering per clip.  Returns a list of ``step``-style dicts."""
-        outs = []
-        for emb, bw, seed in self.model.embed_frames_batch(frames.contiguous(), n_clips):
-            out = self.cluster(emb, bw, seed)
-            out.update(emb=emb, bw=bw, seed=seed)
-            outs.append(out)
-        return outs
+        NT, _, H, W = frames.shape
+        # (with a semseg head its decoder reads clip c's zero-haloed FPN buffers, slot c, which stay valid after the pass)
+        return [self._finish_clip(emb, bw, seed, NT // n_clips, H, W, slot=c)
+                for c, (emb, bw, seed) in enumerate(self.model.embed_frames_batch(frames.contiguous(), n_clips))]
 
     @torch.no_grad()
     def capture_embed(self, example_frames, n_clips=None, lane=0):
@@ -106,14 +123,16 @@ class ClipPipeline(object):
             def collect(k):
                 if pending[k] is not None:
                     gs[k].wait()
-                    for c, (emb, bw, seed) in zip(pending[k], gs[k].out):
+                    for c, (emb, bw, seed) in zip(pending[k][0], gs[k].out):
                         out[c] = torch.cat([emb, bw, seed], 0)
                     pending[k] = None
             for n, g in enumerate(full):
                 k = n % len(gs)
                 collect(k)                                   # the lane's previous outputs, before the replay overwrites them
-                gs[k].run_async(frames[torch.as_tensor(pass_frames(g), device=dev)])
-                pending[k] = g
+                x = frames[torch.as_tensor(pass_frames(g), device=dev)]
+                x.record_stream(gs[k].stream)                # the lane's stream copies it into the graph's input: the caching
+                gs[k].run_async(x)                           # allocator must not hand the block out again before that copy ran
+                pending[k] = (g, x)                          # (and the tensor itself stays referenced until collect(k))
             for k in range(len(gs)):
                 collect(k)
         for g in groups:
@@ -205,7 +224,7 @@ def clip_owner(ci, n_clips, world_size):
 
 @torch.no_grad()
 def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
-                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None, outputs_on_cpu=True):
+                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None, outputs_on_cpu=True, comm=None):
     """One long sequence over the ranks of ``group``, partitioned as SURVEY.md 8(e) lays out:
 
       1. every rank embeds ITS contiguous block of clips (``embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w],
@@ -226,11 +245,10 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     exchanges' sizes and durations."""
     import time
     import numpy as np
-    import torch.distributed as dist
     from .inference.online_chainer import stitch_from_tables
-    distributed = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if distributed else 0
-    world = dist.get_world_size(group) if distributed else 1
+    dist = comm if comm is not None else TorchComm(group)           # (comm: tests drive N "virtual ranks" in one process)
+    distributed = dist.world > 1
+    rank, world = dist.rank, dist.world
     ops, clusterer = chainer.ops, chainer.clusterer
     assert chainer.resize_scale == 1.0, "the sharded sequence path clusters at the heads' resolution (resize_scale 1.0)"
     clips, _ = get_subsequence_frames(n_frames, cfg.INPUT.NUM_FRAMES, dataset_name, frame_overlap)
@@ -259,7 +277,7 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
         dev = _default_device() if not blocks else dev
         info = torch.tensor(shape_info if shape_info else [0, 0, 0], dtype=torch.int64, device=dev)
         infos = [torch.zeros_like(info) for _ in range(world)]
-        dist.all_gather(infos, info, group=group)
+        dist.all_gather(infos, info)
         shape_info = next(i for i in infos if int(i[0]) > 0).tolist()
         h, w = int(shape_info[0]), int(shape_info[1])
     E_dims = int(shape_info[2])
@@ -270,7 +288,7 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     if distributed and world > 1:
         seeds_all = [torch.empty_like(seeds_local) for _ in range(world)]
         t_ag1 = _Timer(seeds_local)
-        dist.all_gather(seeds_all, seeds_local, group=group)        # data-path collective #1 (RCCL over xGMI on the box)
+        dist.all_gather(seeds_all, seeds_local)        # data-path collective #1 (RCCL over xGMI on the box)
         t_ag1.stop()
     else:
         seeds_all, t_ag1 = [seeds_local], None
@@ -308,10 +326,7 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     if distributed and world > 1:
         codes_all = torch.empty((world, per_rank, P * hw), dtype=torch.uint8, device=dev)
         t_ag2 = _Timer(codes_local)
-        if codes_local.is_cuda:
-            dist.all_gather_into_tensor(codes_all, codes_local, group=group)      # data-path collective #2
-        else:
-            _all_gather_stack(codes_all, codes_local, world, group)
+        dist.all_gather_into_tensor(codes_all, codes_local)            # data-path collective #2
         t_ag2.stop()
     else:
         codes_all, t_ag2 = codes_local[None], None
@@ -400,12 +415,28 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     return (track, counts, lifetimes), mask_idxes, subseq_labels, [], subseq_meta
 
 
-def _all_gather_stack(out, local, world, group):
-    import torch.distributed as dist
-    parts = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(parts, local, group=group)
-    for r, p_ in enumerate(parts):
-        out[r] = p_
+class TorchComm(object):
+    """The two collectives of the sharded path on torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, gloo in the
+    CPU tests); world 1 when no process group is initialised."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+
+    def all_gather(self, outs, t):
+        self.dist.all_gather(outs, t.contiguous(), group=self.group)
+
+    def all_gather_into_tensor(self, out, t):
+        if t.is_cuda:
+            self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        else:                                                          # (gloo: list form)
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(parts, t.contiguous(), group=self.group)
+            for r, p_ in enumerate(parts):
+                out[r] = p_
 
 
 class _Timer(object):

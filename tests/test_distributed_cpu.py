@@ -34,7 +34,7 @@ def _case(tag):
     return emb, bw, sd, fg, clips, overlap, exp
 
 
-def _run(tag, fn_name="run_sequence_sharded"):
+def _run(tag, fn_name="run_sequence_sharded", comm=None):
     """The sharded driver on this process's rank; -> (ok, clips embedded here, clips clustered here, expected own clips)."""
     from stemseg_amd import config, pipeline
     from stemseg_amd.inference.clusterers import SequentialClustering
@@ -55,7 +55,8 @@ def _run(tag, fn_name="run_sequence_sharded"):
     chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0, ops=CountingOps())
     stats = {}
     (track, counts, life), mask_idxes, clip_labels, _, meta = getattr(pipeline, fn_name)(
-        fg.shape[0], embed, chainer, "davis", frame_overlap=overlap, fg_mask_fn=lambda entries, thr: torch.from_numpy(fg), stats=stats)
+        fg.shape[0], embed, chainer, "davis", frame_overlap=overlap, fg_mask_fn=lambda entries, thr: torch.from_numpy(fg), stats=stats,
+        **({"comm": comm} if comm is not None else {}))
     ok = len(track) == len(exp["track"]) and all(l.dtype == torch.int64 and np.array_equal(l.numpy(), e) for l, e in zip(track, exp["track"]))
     ok = ok and sorted(counts.items()) == exp["counts"] and sorted(life.items()) == exp["life"]
     ok = ok and [m["instance_labels"] for m in meta] == exp["instance_labels"]
@@ -64,8 +65,8 @@ def _run(tag, fn_name="run_sequence_sharded"):
         ok = ok and np.array_equal(mask_idxes[t][0].numpy(), ys) and np.array_equal(mask_idxes[t][1].numpy(), xs)
     if "clip_labels" in exp:
         ok = ok and all(np.array_equal(torch.cat(clip_labels[i]).numpy(), exp["clip_labels"][i]) for i in range(len(clips)))
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = comm.rank if comm is not None else (dist.get_rank() if dist.is_initialized() else 0)
+    world = comm.world if comm is not None else (dist.get_world_size() if dist.is_initialized() else 1)
     mine = [clips[i] for i in pipeline.shard_clips(len(clips), rank, world)]
     return bool(ok), calls, clustered, mine, len(clips)
 
@@ -129,6 +130,15 @@ def test_sharded_sequence_three_and_eight_ranks_gloo(world, tag):
     res = _spawn(world, tag)
     n_clips = {"seq20_ov4": 4, "seq14_ov6": 4, "long": 48}[tag]
     assert sum(r[2] for r in res) == n_clips and sum(r[3] for r in res) == n_clips
+
+
+@pytest.mark.parametrize("world,tag", [(4, "seq14_ov6"), (5, "long")])
+def test_virtual_ranks_in_one_process(world, tag):
+    """The thread-based virtual-rank harness (tests/virtual_ranks.py) that the GPU suite uses on its single device."""
+    from tests.virtual_ranks import run_virtual_ranks
+    res = run_virtual_ranks(world, lambda comm: _run(tag, comm=comm))
+    assert all(r[0] for r in res)
+    assert [r[1] for r in res] == [r[3] for r in res] and all(r[2] == [1] * len(r[3]) for r in res)
 
 
 def test_replicated_partitioning_still_matches_two_ranks_gloo():

@@ -1,0 +1,116 @@
+"""GPU tests of the clip-parallel sequence path (pipeline.run_sequence_sharded): the four stitching entry
+points against their numpy twins, the reference-generated chainer goldens through the HIP path at world 1, and N "virtual
+ranks" on the one device (threads + an emulated all-gather: every rank's own-clip clustering with label_start = 1, the code
+planes, the pair tables and the LUT gather all run the real kernels with the owner / plane arithmetic of a world-N job)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+from tests.test_distributed_cpu import _case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from stemseg_amd import hip as h
+    h.require_gpu()
+    return h
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def test_stitching_kernels_vs_numpy_twins(hip):
+    """fg_compact / labels_to_codes / pair_tables / codes_to_labels == tests/oracle_ops.py on ragged random planes."""
+    from stemseg_amd.inference.online_chainer import HipChainerOps
+    from tests.oracle_ops import OracleChainerOps
+    ops, ref = HipChainerOps(), OracleChainerOps()
+    rs = np.random.RandomState(3)
+    for (F, h, w, K) in ((5, 7, 9, 3), (8, 120, 216, 20), (3, 33, 65, 64), (2, 1, 1, 1)):
+        B = K + 2
+        fg = (rs.uniform(size=(F, h, w)) < 0.4).astype(np.uint8)
+        vox, offs = ops.compact(dev(fg))
+        rvox, roffs = ref.compact(torch.from_numpy(fg))
+        n = int(roffs[-1])
+        assert np.array_equal(offs.cpu().numpy(), roffs.numpy()) and np.array_equal(vox.cpu().numpy()[:n], rvox.numpy()[:n])
+        # a "clip" = all F frames: labels for the n points, label_start 7
+        labels = np.where(rs.uniform(size=n) < 0.2, -1, 7 + rs.randint(0, K, n)).astype(np.int64)
+        pts = dict(vox=vox, offs=offs, T=F)
+        codes = torch.zeros(2, F * h * w, dtype=torch.uint8, device="cuda")
+        ops.codes_from_labels(pts, dev(np.concatenate([labels, np.full(F * h * w - n, 5, np.int64)])), 7, codes[0])
+        rcodes = torch.zeros(2, F * h * w, dtype=torch.uint8)
+        ref.codes_from_labels(dict(vox=rvox, offs=roffs, T=F), torch.from_numpy(labels), 7, rcodes[0])
+        assert np.array_equal(codes[0].cpu().numpy(), rcodes[0].numpy())
+        # a second labelling of the same foreground for the pair tables
+        labels2 = np.where(rs.uniform(size=n) < 0.1, -1, 1 + rs.randint(0, K, n)).astype(np.int64)
+        ops.codes_from_labels(pts, dev(labels2), 1, codes[1])
+        ref.codes_from_labels(dict(vox=rvox, offs=roffs, T=F), torch.from_numpy(labels2), 1, rcodes[1])
+        planes, rplanes = codes.view(2 * F, h * w), rcodes.view(2 * F, h * w)
+        pa = [-1 if t % 3 == 0 else t for t in range(F)]
+        pb = [F + t for t in range(F)]
+        tabs = ops.pair_tables(planes, pa, pb, B)
+        (tabs_h,) = ops.read_back(tabs)
+        assert np.array_equal(tabs_h, ref.pair_tables(rplanes, pa, pb, B).numpy())
+        assert int(tabs_h.sum()) == n
+        items, luts, cur = [], [], 0
+        o = roffs.numpy()
+        for t in range(F):
+            items.append((int(o[t]), int(o[t + 1] - o[t]), t * h * w, F + t, cur))
+            cur += int(o[t + 1] - o[t])
+            luts.append(rs.randint(-1, 4000, B).astype(np.int64))
+        mx = max(i[1] for i in items)
+        out = ops.labels_from_codes(planes, vox, np.asarray(items, np.int64), np.stack(luts), mx, cur)
+        rout = ref.labels_from_codes(rplanes, rvox, np.asarray(items, np.int64), np.stack(luts), mx, cur)
+        assert np.array_equal(out.cpu().numpy(), rout.numpy())
+
+
+def _run_gpu(tag, comm=None, fn_name="run_sequence_sharded"):
+    from stemseg_amd import config, pipeline
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    emb, bw, sd, fg, clips, overlap, exp = _case(tag)
+    config.load_preset("davis")
+    emb_d, bw_d, sd_d, fg_d = dev(emb), dev(bw), dev(sd), dev(fg)
+
+    def embed(frames):
+        idx = torch.as_tensor(frames, device="cuda")
+        return emb_d[:, idx].contiguous(), bw_d[:, idx].contiguous(), sd_d[:, idx].contiguous()
+    chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cuda:0"), 1.0)
+    kw = {"comm": comm} if comm is not None else {}
+    (track, counts, life), mask_idxes, clip_labels, _, meta = getattr(pipeline, fn_name)(
+        fg.shape[0], embed, chainer, "davis", frame_overlap=overlap, fg_mask_fn=lambda entries, thr: fg_d, **kw)
+    ok = len(track) == len(exp["track"]) and all(np.array_equal(l.cpu().numpy(), e) for l, e in zip(track, exp["track"]))
+    ok = ok and sorted(counts.items()) == exp["counts"] and sorted(life.items()) == exp["life"]
+    ok = ok and [m["instance_labels"] for m in meta] == exp["instance_labels"]
+    for t in range(fg.shape[0]):
+        ys, xs = np.nonzero(fg[t])
+        ok = ok and np.array_equal(mask_idxes[t][0].cpu().numpy(), ys) and np.array_equal(mask_idxes[t][1].cpu().numpy(), xs)
+    if "clip_labels" in exp:
+        ok = ok and all(np.array_equal(torch.cat(clip_labels[i]).cpu().numpy(), exp["clip_labels"][i]) for i in range(len(clips)))
+    crc = zlib.crc32(torch.cat([t.cpu() for t in track]).numpy().tobytes())
+    centers = [m["instance_centers"] for m in meta]
+    return bool(ok), crc, centers
+
+
+@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single", "long"])
+def test_clip_parallel_chain_on_gpu_vs_golden(hip, tag):
+    ok, crc, centers = _run_gpu(tag)
+    assert ok
+    ok2, crc2, centers2 = _run_gpu(tag, fn_name="run_sequence_replicated") if tag != "long" else (True, crc, centers)
+    assert ok2 and crc2 == crc and centers2 == centers            # the replicated chain of round 2 agrees
+
+
+@pytest.mark.parametrize("world,tag", [(2, "seq20_ov4"), (3, "seq14_ov6"), (8, "long"), (8, "seq20_ov4")])
+def test_virtual_ranks_on_one_gpu_identical_tracks(hip, world, tag):
+    """Every virtual rank ends with the reference's tracks and the same checksum as the one-rank run."""
+    from tests.virtual_ranks import run_virtual_ranks
+    ok1, crc1, centers1 = _run_gpu(tag)
+    res = run_virtual_ranks(world, lambda comm: _run_gpu(tag, comm=comm))
+    assert ok1 and all(r[0] for r in res)
+    assert {r[1] for r in res} == {crc1}
+    assert all(r[2] == centers1 for r in res)
