@@ -231,7 +231,7 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
             "metric": "clips/sec (T=8, 480p) embed+cluster, one %d-frame sequence sharded over the GPUs" % F,
             "value": round(n_clips * args.steps / dt, 4), "unit": "clips/s", "n_gpus": world, "ranks": ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16x3", "data": "synthetic",
+            "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt in contiguous blocks "
                                    "to %d rank(s), %s, both decoders; %s" % (F, overlap, n_clips, world, BACKBONE,
                                    "all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + clustering + Hungarian stitching (round-2 partitioning)"
@@ -325,6 +325,10 @@ def stub_main(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+PRECISION_DTYPE = {"f32": "f32", "bf16x3": "f32 operands as bf16x3 split (3 bf16 MFMAs per product, fp32 accumulate; ~1e-4)",
+                   "bf16x6": "f32 (every operand split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate: fp32-level results)"}
+
+
 def library_switches():
     """The A/B switches the library reads from the environment (csrc/conv_igemm.hip), as set for this run."""
     return {k: os.environ.get(k, "default") for k in ("STEMSEG_K3_DB", "STEMSEG_FLAT", "STEMSEG_PLANNER", "STEMSEG_T_FASTEST", "STEMSEG_GLDS", "STEMSEG_GN_EPILOGUE", "STEMSEG_TILE224", "STEMSEG_AUTOSPLIT")}
@@ -344,8 +348,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
-                    help="MFMA mode of every convolution: exact fp32 (default) or the 3-term bf16 split (fp32 accumulate)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+                    help="MFMA mode of every convolution: fp32-input MFMA (default); bf16x6 = exact three-term bf16 split of every fp32 "
+                         "operand, six products, fp32 accumulate (fp32-level results); bf16x3 = two-term split, three products (~1e-4)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the step (use under rocprofv3)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)      # (the default; kept for old command lines)
@@ -517,7 +522,7 @@ def main():
     if rank == 0:
         clips_total = args.steps * world * NC
         # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes)
-        peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / 3.0
+        peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / (3.0 if args.precision == "bf16x3" else 6.0)
         k3 = [prof[t] for t in hip.PROFILE_CONV_TAGS["conv3x3x3"] if t in prof]
         ms = sum(p[0] for p in k3)
         fl = sum(p[1] for p in k3)
@@ -554,12 +559,12 @@ def main():
             "value": round(clips_total / dt, 4), "unit": "clips/s",
             "n_gpus": len(ranks), "ranks": ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 operands as bf16x3 split (3 bf16 MFMAs per product, fp32 accumulate)",
+            "dtype": PRECISION_DTYPE[args.precision],
             "data": "synthetic",
             "config": {"workload": WL["name"], "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
                        "switches": library_switches()},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % ("fp32 MFMA 32x32x2" if args.precision == "f32" else "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3"),
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s"}[args.precision],
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic, "traffic_note": traffic_note,
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),

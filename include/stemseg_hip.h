@@ -97,12 +97,21 @@ typedef struct StemsegConvEpilogue {
     int32_t      precision;        /* STEMSEG_PRECISION_F32 (exact fp32 MFMA) or STEMSEG_PRECISION_BF16X3: every fp32 operand is
                                       split hi + lo into bf16 and a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores
                                       with fp32 accumulation (~2^-17 relative per product, 5.3x the fp32-MFMA rate); packed_w
-                                      must then come from stemseg_hip_pack_conv_weight_bf16x3 */
+                                      must then come from stemseg_hip_pack_conv_weight_bf16x3.
+                                      STEMSEG_PRECISION_BF16X6: every fp32 operand is split EXACTLY into three bf16 terms
+                                      (hi + mid + lo, 24 significand bits) and a*b is the sum of the six products of weight
+                                      >= 2^-16 on the bf16 matrix cores, fp32 accumulation: the dropped products are <= 2^-23
+                                      |a*b|, below the rounding of the fp32 accumulation itself -- fp32-level results at 2.7x
+                                      the fp32-MFMA rate; packed_w from stemseg_hip_pack_conv_weight_split(..., planes = 3) */
 } StemsegConvEpilogue;
 #define STEMSEG_PRECISION_F32    0
 #define STEMSEG_PRECISION_BF16X3 1
+#define STEMSEG_PRECISION_BF16X6 2
 int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t Cin, int32_t taps);
 int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
+/* planes = 2: the bf16x3 packing above; planes = 3: the bf16x6 packing (hi | mid | lo planes per k-group). */
+int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes);
+int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream);
 /* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).
  * epilogue may be NULL (plain conv + bias). */
 int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
@@ -180,7 +189,7 @@ typedef struct StemsegDecoderDesc {
                                     streams and the call returns without joining; the caller must enqueue
                                     stemseg_hip_decoder_join(concurrency, stream) before it consumes `out` or re-uses the
                                     inputs / workspace.  Lets a twin decoder be enqueued in between (both fill the chip). */
-    int32_t precision;           /* STEMSEG_PRECISION_F32 | STEMSEG_PRECISION_BF16X3 for every convolution of the decoder
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 for every convolution of the decoder
                                     (weights in StemsegDecoderWeights must be packed for the same mode)                    */
 } StemsegDecoderDesc;
 
@@ -220,7 +229,7 @@ typedef struct StemsegEncoderDesc {
     int32_t blocks[4];           /* bottleneck blocks per stage: R-50 {3,4,6,3}, R-101 {3,4,23,3}       */
     int32_t T, H, W;             /* frames per call and padded frame size (multiples of 32)              */
     int32_t out_channels;        /* 256                                                                  */
-    int32_t precision;           /* STEMSEG_PRECISION_F32 | STEMSEG_PRECISION_BF16X3 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
     int32_t n_clips;             /* >= 1: the T frames are n_clips consecutive clips of T / n_clips frames; each clip's four maps
                                     go to their own output volumes (frames are independent in the encoder, so several clips
                                     share one pass: layer3 / layer4 launches grow from 0.4 to n_clips x 0.4 waves of the chip) */

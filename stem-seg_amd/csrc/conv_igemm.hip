@@ -35,6 +35,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace stemseg {
 
@@ -91,10 +92,22 @@ struct ConvKParams {
 // the MFMA stream and the barrier.  Out-of-range pieces (tile columns past the row end, the run before the plane's first
 // row) are fetched from a clamped in-bounds address instead of being zero-filled: they only feed positions that are never
 // stored.  Needs Cin % CK == 0 and Cout % MT == 0 (the launcher falls back to the register-staged twin otherwise).
-template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, bool BF_ = false, bool DB_ = false,
+// bf16x6 ("X6", BF_ = 2): every fp32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 significand
+// bits; both remainders are exact fp32 subtractions), and a*b is evaluated as the six products of weight >= 2^-16,
+//   lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi   (smallest first),
+// on v_mfma_f32_32x32x16_bf16 -- products exact, fp32 accumulate.  The three dropped products (mid*lo, lo*mid, lo*lo) are
+// <= 2^-23 |a*b|, i.e. below the rounding of the fp32 accumulation itself: the result carries fp32-level error (measured
+// against an fp64 convolution in tests/test_gpu_parity.py next to the fp32-MFMA path) at 16/6 = 2.7x the fp32-MFMA rate.
+// Unlike the x3 mode the split happens ONCE, when a chunk is staged: LDS holds three bf16 planes of the input tile with the
+// channels interleaved in PAIRS (one 32-bit word = the same position of channels 2p and 2p+1), so a lane's 8 k-values of a
+// k-group are four ds_read_b32 per plane and the k-loop is ds_read + MFMA only.  Weights arrive pre-split; their slab is
+// staged in two k-group phases that ping-pong with the MFMA stream (phase A's slots are refilled for the next chunk while
+// phase B computes and vice versa, through registers), the input tile is prefetched into registers and written at the chunk end.
+template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, int BF_ = 0, bool DB_ = false,
           int PMAX_ = 0, bool GL_ = false>
 struct ConvCfg {
-    static constexpr bool PIPE = PIPE_, BF = BF_, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
+    static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ == 2, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
+    static constexpr int NPL = X6 ? 3 : 2;                              // bf16 planes per operand
     static constexpr int PMAX = PMAX_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
@@ -107,25 +120,31 @@ struct ConvCfg {
     static constexpr int NT = NSEG * 32;                                // FLAT: voxels (flat plane positions) per tile
     static constexpr int FL = NT + 2 * PMAX + 8;                        // FLAT: staged run per (channel, dt): tile + one row and 4 either side
     static constexpr int IN_CH_STRIDE = FLAT ? KT * FL : KT * RH * XP;
-    static constexpr int IN_FLOATS = CK * IN_CH_STRIDE;
+    static constexpr int IN_PAIR_STRIDE = KT * RH * XP;                 // X6: words of one channel pair of one plane
+    static constexpr int IN_PLANE_STRIDE = (CK / 2) * IN_PAIR_STRIDE;   // X6: words of one bf16 plane
+    static constexpr int IN_FLOATS = X6 ? 3 * IN_PLANE_STRIDE : CK * IN_CH_STRIDE;
     // bf16x3 grouping: taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
     static constexpr int TPG = TAPS >= 27 ? 4 : (TAPS >= 9 ? 2 : 1);
     static constexpr int CPH = 8 / TPG;
     static constexpr int NTG = (TAPS + TPG - 1) / TPG;                  // tap groups
     static constexpr int NCG = BF ? CK / (2 * CPH) : 1;                 // channel groups per chunk
     static constexpr int G = NTG * NCG;                                 // 16-wide k-groups per chunk
-    static constexpr int W_FLOATS = BF ? 2 * G * 2 * MT * 4 : CK * TAPS * MT;   // bf16x3: [hi|lo][G][half][MT] x 16 B
+    static constexpr int W_FLOATS = BF ? NPL * G * 2 * MT * 4 : CK * TAPS * MT;   // bf16x3: [hi|lo][G][half][MT] x 16 B; x6: [G][hi|mid|lo][half][MT]
+    static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
     static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
     static constexpr int LDS_FLOATS = BUF_FLOATS * (DB ? 2 : 1);
     static_assert(!BF || CK % (2 * CPH) == 0, "bf16x3: chunk must hold whole k-groups");
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
     static_assert(CK % 4 == 0 || (DB && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (DB)");
-    static_assert(LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU");
+    static_assert(LDS_FLOATS * 4 <= (X6 ? 160 : 80) * 1024, "two workgroups per CU (x6 eight-wave tiles: one)");
+    static_assert(!X6 || (!FLAT && !DB && !GL && G >= 2 && CK % 2 == 0), "x6: 2-D / 3-D tiles, two weight phases");
     static_assert(!FLAT || (!BF && (!DB || GL) && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: fp32 3x3 taps only");
     static_assert(!GL || (DB && !BF), "direct-to-LDS staging is the double-buffered fp32 form");
     // workgroups per CU the register allocator must leave room for: the GL forms carry no staging registers, so the tiles whose
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
+    // (the second __launch_bounds__ argument is waves per SIMD: an eight-wave x6 workgroup alone on its CU is two per SIMD as well)
     static constexpr int MIN_WG = (GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2);
+    static constexpr int NWAVES = WM * WN;
 };
 
 template <class C>
@@ -192,6 +211,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
         b_ptr_bf[ni] = in_lds + half * (C::CPH * C::IN_CH_STRIDE) + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+    }
+    const unsigned int* b_ptr6[C::NI];  // x6: word (channel pair) planes; lane half h owns the pairs [h*CPH/2, (h+1)*CPH/2) of every k-group
+#pragma unroll
+    for (int ni = 0; ni < C::NI; ++ni) {
+        const int s = wn * C::NI + ni;
+        b_ptr6[ni] = reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
     }
     const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
@@ -316,6 +341,157 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         }
         for (int q = tid; q < NWQ; q += C::NTHREADS) *reinterpret_cast<float4*>(w_lds + q * 4) = fetch_w(c0, q);
     };
+
+    // ---- x6 staging --------------------------------------------------------------------------------------
+    // exact three-way split of an fp32 value into bf16 terms (both remainders are exact fp32 subtractions)
+    auto split3 = [](const float x, unsigned int& h, unsigned int& m, unsigned int& l) {
+        const __bf16 bh = (__bf16)x;
+        const float r1 = x - (float)bh;
+        const __bf16 bm = (__bf16)r1;
+        const __bf16 bl = (__bf16)(r1 - (float)bm);
+        h = *reinterpret_cast<const unsigned short*>(&bh);
+        m = *reinterpret_cast<const unsigned short*>(&bm);
+        l = *reinterpret_cast<const unsigned short*>(&bl);
+    };
+    constexpr int NQ6 = (C::CK / 2) * C::KT * C::RH * XQ;               // 16-B pieces of a channel PAIR's rows: [pair][dt][row][xq]
+    constexpr int IN_PT6 = C::X6 ? (NQ6 + C::NTHREADS - 1) / C::NTHREADS : 1;
+    constexpr int NWQ_A = C::NPL * C::GA * 2 * C::MT, NWQ6 = C::NPL * C::G * 2 * C::MT;   // 16-B pieces of weight phase A / of the slab
+    auto in6_rel = [&](int q, int& c) -> int64_t {                   // piece q -> float offset of its first channel (c0 = 0) from in_tile
+        const int xq = q % XQ;
+        int rr = q / XQ;
+        const int r = rr % C::RH;
+        rr /= C::RH;
+        const int dt = rr % C::KT;
+        c = 2 * (rr / C::KT);
+        const int yy = min(y0 + r, p.in_H - 1);
+        return (int64_t)c * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xq * 4;
+    };
+    auto fetch_in6 = [&](int c0, int q, float4& v0, float4& v1) {    // piece q of both channels of its pair
+        int c;
+        const int64_t rel = in6_rel(q, c) + (int64_t)c0 * p.in_cs;
+        v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + c < p.Cin && tile_base + rel + 4 <= p.in_limit) v0 = *reinterpret_cast<const float4*>(in_tile + rel);
+        if (c0 + c + 1 < p.Cin && tile_base + rel + p.in_cs + 4 <= p.in_limit) v1 = *reinterpret_cast<const float4*>(in_tile + rel + p.in_cs);
+    };
+    // the same for the register prefetch inside the chunk loop: the per-thread part of the address is loop invariant (a 32-bit
+    // byte offset, computed once), the chunk only moves the uniform base
+    unsigned int in6_voff[IN_PT6];
+    int in6_c[IN_PT6];
+    if constexpr (C::X6) {
+#pragma unroll
+        for (int k = 0; k < IN_PT6; ++k) {
+            const int q = tid + k * C::NTHREADS;
+            int c = 0;
+            const int64_t rel = q < NQ6 ? in6_rel(q, c) : 0;
+            in6_voff[k] = (unsigned int)(rel * 4);
+            in6_c[k] = q < NQ6 ? c : (1 << 30);                         // (beyond the tile: never loaded)
+        }
+    }
+    const int64_t in6_room = (p.in_limit - 4 - tile_base) * 4;        // last valid 16-B piece, as a byte offset from in_tile
+    auto fetch_in6_fast = [&](int c0, int k, float4& v0, float4& v1) __attribute__((always_inline)) {
+        const int64_t ub = (int64_t)c0 * p.in_cs * 4;                  // uniform
+        const char* base = reinterpret_cast<const char*>(in_tile) + ub;
+        v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + in6_c[k] < p.Cin && ub + in6_voff[k] <= in6_room) v0 = *reinterpret_cast<const float4*>(base + in6_voff[k]);
+        if (c0 + in6_c[k] + 1 < p.Cin && ub + p.in_cs * 4 + in6_voff[k] <= in6_room) v1 = *reinterpret_cast<const float4*>(base + p.in_cs * 4 + in6_voff[k]);
+    };
+    auto store_in6 = [&](int q, const float4& v0, const float4& v1) { // split both channels, interleave, three 16-B stores
+        unsigned int h0, m0, l0, h1, m1, l1;
+        uint4 ph, pm, pl;
+        split3(v0.x, h0, m0, l0); split3(v1.x, h1, m1, l1); ph.x = h0 | (h1 << 16); pm.x = m0 | (m1 << 16); pl.x = l0 | (l1 << 16);
+        split3(v0.y, h0, m0, l0); split3(v1.y, h1, m1, l1); ph.y = h0 | (h1 << 16); pm.y = m0 | (m1 << 16); pl.y = l0 | (l1 << 16);
+        split3(v0.z, h0, m0, l0); split3(v1.z, h1, m1, l1); ph.z = h0 | (h1 << 16); pm.z = m0 | (m1 << 16); pl.z = l0 | (l1 << 16);
+        split3(v0.w, h0, m0, l0); split3(v1.w, h1, m1, l1); ph.w = h0 | (h1 << 16); pm.w = m0 | (m1 << 16); pl.w = l0 | (l1 << 16);
+        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
+        *reinterpret_cast<uint4*>(d) = ph;
+        *reinterpret_cast<uint4*>(d + C::IN_PLANE_STRIDE) = pm;
+        *reinterpret_cast<uint4*>(d + 2 * C::IN_PLANE_STRIDE) = pl;
+    };
+    auto stage_in6_direct = [&](int c0) {                             // global -> split -> LDS without overlap (prologue, odd strides)
+        if (p.vec4) {
+            for (int q = tid; q < NQ6; q += C::NTHREADS) {
+                float4 v0, v1;
+                fetch_in6(c0, q, v0, v1);
+                store_in6(q, v0, v1);
+            }
+        } else {
+            constexpr int NE6 = (C::CK / 2) * C::KT * C::RH * C::XP;     // one word (pair, position) per iteration
+            for (int q = tid; q < NE6; q += C::NTHREADS) {
+                const int xx = q % C::XP;
+                int rr = q / C::XP;
+                const int r = rr % C::RH;
+                rr /= C::RH;
+                const int dt = rr % C::KT;
+                const int c = 2 * (rr / C::KT);
+                const int yy = min(y0 + r, p.in_H - 1);
+                const int64_t rel = (int64_t)(c0 + c) * p.in_cs + (int64_t)dt * p.in_ts + (int64_t)yy * p.in_ys + xx;
+                float a0 = 0.f, a1 = 0.f;
+                if (c0 + c < p.Cin && tile_base + rel < p.in_limit) a0 = in_tile[rel];
+                if (c0 + c + 1 < p.Cin && tile_base + rel + p.in_cs < p.in_limit) a1 = in_tile[rel + p.in_cs];
+                unsigned int h0, m0, l0, h1, m1, l1;
+                split3(a0, h0, m0, l0);
+                split3(a1, h1, m1, l1);
+                unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q;
+                d[0] = h0 | (h1 << 16);
+                d[C::IN_PLANE_STRIDE] = m0 | (m1 << 16);
+                d[2 * C::IN_PLANE_STRIDE] = l0 | (l1 << 16);
+            }
+        }
+    };
+    // weight pieces of chunk c0's slab (packed order [grp][plane][half][co] = the LDS image); columns past Cout are fetched from
+    // the row's last valid channel (they feed rows never stored)
+    constexpr int W_PT6 = C::X6 ? (NWQ_A + C::NTHREADS - 1) / C::NTHREADS : 1;      // phase A is the larger phase
+    // address = uniform base (chunk, first row of the piece run, co0) + ONE loop-invariant 32-bit per-thread offset: NTHREADS and the
+    // phase boundaries are multiples of MT, so a thread keeps its column and walks the rows in steps of NTHREADS / MT
+    static_assert(C::NTHREADS % C::MT == 0 && NWQ_A % C::MT == 0, "weight pieces: a thread keeps its column");
+    const unsigned int w6_voff = C::X6 ? ((unsigned int)(tid / C::MT) * (unsigned int)p.Cout + (unsigned int)min(tid % C::MT, p.Cout - 1 - co0)) * 16u : 0u;
+    auto w6_src = [&](int c0, int q_uniform) __attribute__((always_inline)) -> const char* {      // q_uniform = q - tid (a multiple of MT)
+        const char* base = reinterpret_cast<const char*>(p.wpk) +
+                           (((int64_t)(c0 / C::CK) * (C::NPL * C::G * 2) + q_uniform / C::MT) * p.Cout + co0) * 16;
+        return base + w6_voff;
+    };
+    // MFMA stream over the k-groups [g0, g1) of the staged chunk: 3 x MI b128 (A) + 3 x NI x 4 b32 (B) per 6 x MI x NI MFMAs
+    auto compute6 = [&](auto g0c, auto g1c) __attribute__((always_inline)) {
+        constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
+#pragma unroll
+        for (int grp = 0; grp < C::G; ++grp) {
+            if (grp < g0 || grp >= g1) continue;
+            const int cg = grp / C::NTG, tg = grp % C::NTG;
+            bf16x8 b[3][C::NI];
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    uint4 w4;
+                    unsigned int* wv = reinterpret_cast<unsigned int*>(&w4);
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const int j0 = 2 * wd, tapi = j0 / C::CPH, chl = j0 % C::CPH;
+                        int tap = tg * C::TPG + tapi;
+                        tap = tap < C::TAPS ? tap : C::TAPS - 1;       // padded taps: any valid address (their weights are zero)
+                        const int dt = tap / (C::KH * C::KW), dy = (tap / C::KW) % C::KH, dx = tap % C::KW;
+                        const int off = pl * C::IN_PLANE_STRIDE + (cg * C::CPH + chl / 2) * C::IN_PAIR_STRIDE + (dt * C::RH + dy) * C::XP + dx;
+                        wv[wd] = b_ptr6[ni][off];
+                    }
+                    b[pl][ni] = __builtin_bit_cast(bf16x8, w4);
+                }
+#pragma unroll
+            for (int mi = 0; mi < C::MI; ++mi) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[pl] = *reinterpret_cast<const bf16x8*>(a_base + (((grp * 3 + pl) * 2) * C::MT + mi * 32) * 16);
+                // smallest products first (planes: 0 hi, 1 mid, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
+#define SS_X6_TERM(PA, PB)                                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
+                SS_X6_TERM(2, 0) SS_X6_TERM(0, 2) SS_X6_TERM(1, 1) SS_X6_TERM(1, 0) SS_X6_TERM(0, 1) SS_X6_TERM(0, 0)
+#undef SS_X6_TERM
+            }
+        }
+    };
     // ---- MFMA stream over one staged chunk: every tap is a shifted LDS read ------------------------------
     auto compute = [&](const int buf_off = 0) {
         if constexpr (C::BF) {
@@ -410,7 +586,61 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
 
     const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
     const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
-    if constexpr (C::DB && C::GL) {
+    if constexpr (C::X6) {
+        // The weight slab is staged in two k-group phases that ping-pong with the MFMA stream: while phase A computes, the next
+        // chunk's phase-A weights and input tile wait in registers; they are written when phase A's slots fall idle, the
+        // registers then carry the next chunk's phase-B weights under phase B's MFMA stream.  Three barriers per chunk, no
+        // global-memory latency exposed.
+        typedef std::integral_constant<int, 0> Q0;
+        typedef std::integral_constant<int, NWQ_A> QA;
+        typedef std::integral_constant<int, NWQ6> QE;
+        float4 rin[2 * IN_PT6];
+        typedef float f32x4 __attribute__((ext_vector_type(4)));      // (a native vector: struct copies of float4 stay memcpys)
+        f32x4 rw6[W_PT6];
+        auto fetch_w6 = [&](int c0, auto q0c, auto q1c) __attribute__((always_inline)) {                             // pieces [q0, q1) -> registers
+            constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+    #pragma unroll
+            for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if (q < q1) rw6[k] = *reinterpret_cast<const f32x4*>(w6_src(c0, q0 + k * C::NTHREADS)); }
+        };
+        auto store_w6 = [&](auto q0c, auto q1c) __attribute__((always_inline)) {
+            constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+    #pragma unroll
+            for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if (q < q1) *reinterpret_cast<f32x4*>(w_lds + q * 4) = rw6[k]; }
+        };
+        if (c_begin < c_end) {
+            for (int q = tid; q < NWQ6; q += C::NTHREADS) *reinterpret_cast<float4*>(w_lds + q * 4) = *reinterpret_cast<const float4*>(w6_src(c_begin, q - tid));
+            stage_in6_direct(c_begin);
+        }
+        __syncthreads();
+        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
+            const bool more = c0 + C::CK < c_end;
+            if (more) {
+                fetch_w6(c0 + C::CK, Q0{}, QA{});
+                if (p.vec4) {
+#pragma unroll
+                    for (int k = 0; k < IN_PT6; ++k) fetch_in6_fast(c0 + C::CK, k, rin[2 * k], rin[2 * k + 1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMA stream
+            compute6(Q0{}, std::integral_constant<int, C::GA>{});
+            __syncthreads();                                   // phase A's slots are idle
+            if (more) {
+                store_w6(Q0{}, QA{});
+                fetch_w6(c0 + C::CK, QA{}, QE{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute6(std::integral_constant<int, C::GA>{}, std::integral_constant<int, C::G>{});
+            __syncthreads();                                   // everyone is done with phase B's slots and this chunk's input tile
+            if (more) {
+                store_w6(QA{}, QE{});
+                if (p.vec4) {
+#pragma unroll
+                    for (int k = 0; k < IN_PT6; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ6) store_in6(q, rin[2 * k], rin[2 * k + 1]); }
+                } else stage_in6_direct(c0 + C::CK);
+                __syncthreads();
+            }
+        }
+    } else if constexpr (C::DB && C::GL) {
         // double-buffered LDS filled by LDS-DMA: chunk i+1 is enqueued into the idle buffer, chunk i's MFMA stream runs, and
         // the __syncthreads() that ends the chunk carries the vmcnt(0) that retires the DMA (the compiler puts no wait in
         // front of the ds_reads: checked in the ISA) -- one barrier per chunk, nothing between the last MFMA and the barrier
@@ -505,8 +735,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         // [group][slot] table per tile.  No atomics anywhere: bit-identical run to run.
         __syncthreads();                                       // the staged tiles are dead: their LDS is reused below
         constexpr int GPW8 = C::MI * 4;                        // 8-channel groups per wave (x2 for 4-channel groups)
-        double* red = reinterpret_cast<double*>(smem + 4 * 32 * 36);          // behind the epilogue's transpose buffers
-        static_assert(4 * 32 * 36 + 2 * C::WM * C::WN * GPW8 * 2 * 2 <= C::LDS_FLOATS, "GN partial sums must fit the staging LDS");
+        double* red = reinterpret_cast<double*>(smem + C::NWAVES * 32 * 36);  // behind the epilogue's transpose buffers
+        static_assert(C::NWAVES * 32 * 36 + 2 * C::WM * C::WN * GPW8 * 2 * 2 <= C::LDS_FLOATS, "GN partial sums must fit the staging LDS");
         const bool g4 = p.gn_cpg == 4;
         bool ok[C::NI];
 #pragma unroll
@@ -572,7 +802,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         __syncthreads();                                       // all waves are done with the staged tiles
         constexpr int TP = 36;                                 // padded row pitch (floats), keeps float4 reads aligned
         float* tl = smem + wave * (32 * TP);
-        static_assert(4 * 32 * 36 <= C::LDS_FLOATS, "epilogue transpose buffer must fit the staging LDS");
+        static_assert(C::NWAVES * 32 * 36 <= C::LDS_FLOATS, "epilogue transpose buffer must fit the staging LDS");
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
             const int s = wn * C::NI + ni;
@@ -790,6 +1020,43 @@ __global__ void pack_conv_weight_bf16x3_kernel(const float* __restrict__ w, uint
     }
 }
 
+// bf16x6 packing: [Cout][Cin][taps] fp32 -> per chunk [G][hi|mid|lo][half][Cout][8 bf16] (same k-group element order as bf16x3;
+// group-major so that a weight PHASE -- a run of k-groups -- is one contiguous LDS image)
+__global__ void pack_conv_weight_bf16x6_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int Cin, int taps,
+                                                int CK, int TPG) {
+    const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
+    const int nchunks = (Cin + CK - 1) / CK;
+    const int64_t n = (int64_t)nchunks * G * 3 * 2 * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t r = i / Cout;
+        const int h = (int)(r & 1);
+        r >>= 1;
+        const int pl = (int)(r % 3);
+        r /= 3;
+        const int grp = (int)(r % G);
+        const int chunk = (int)(r / G);
+        const int cg = grp / NTG, tg = grp % NTG;
+        unsigned short v[8];
+        for (int j = 0; j < 8; ++j) {
+            const int tapi = j / CPH, chl = j % CPH;
+            const int tap = tg * TPG + tapi, ci = chunk * CK + cg * 2 * CPH + h * CPH + chl;
+            float x = 0.f;
+            if (tap < taps && ci < Cin) x = w[((int64_t)co * Cin + ci) * taps + tap];
+            const __bf16 hi = (__bf16)x;
+            const float r1 = x - (float)hi;
+            const __bf16 mid = (__bf16)r1;
+            const __bf16 lo = (__bf16)(r1 - (float)mid);
+            const __bf16 pick = pl == 0 ? hi : (pl == 1 ? mid : lo);
+            v[j] = *reinterpret_cast<const unsigned short*>(&pick);
+        }
+        uint4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+        packed[i] = o;
+    }
+}
+
 // tile shapes --------------------------------------------------------------------------------------
 //                       KT KH KW  CK  MI NI WM WN COLS
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
@@ -855,6 +1122,19 @@ using X2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, false, true>;
 using X2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true, true>;
 using X2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true, true>;
 using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
+
+// bf16x6 tiles.  3x3x3: eight waves share one 86 KB weight slab (one workgroup per CU, two waves per SIMD); 2-D and 1x1 tiles
+// keep four-wave shapes (two workgroups per CU) except the big 2-D tile
+using Y3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 1, false, 2>;   // 128 co x (16 rows x 32 cols), 512 threads
+using Y3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 4, 1, false, 2>;   // 128 co x ( 8 rows x 32 cols), 512 threads
+using Y3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 4, 1, false, 2>; // 128 co x ( 4 rows x 32 cols), 512 threads
+using Y2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 1, false, 2>;   // 128 co x (16 rows x 32 cols), 512 threads (the weight prefetch of a four-wave tile spills)
+using Y2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, false, 2>;   // 128 co x (4 rows x 32 cols)
+using Y2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, false, 2>; // 128 co x (2 rows x 32 cols)
+using Y2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, false, 2>;   //  64 co x (8 rows x 32 cols)
+using Y1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, 2>;  // 128 co x 256 voxels
+using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, 2>; // 128 co x 128 voxels
+using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, 2>;  //  64 co x 256 voxels
 
 // sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
 // MFMA peak)
@@ -922,7 +1202,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), 1, (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
     constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
-    const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : tile_rows);   // 8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
+    const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : (tile_rows == 16 ? 9 : tile_rows));   // 9/8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
     if (ksplit > 1) {
@@ -1072,6 +1352,8 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats, const ConvEpilogue* epi) {
     SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
     const bool bf = epi && epi->precision == 1;
+    const bool x6 = epi && epi->precision == 2;
+    SS_CHECK_ARG(!epi || (epi->precision >= 0 && epi->precision <= 2), "conv3d: precision %d (0 f32, 1 bf16x3, 2 bf16x6)", epi ? epi->precision : 0);
     const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1), k2 = (kt == 1 && kh == 3 && kw == 3);
     SS_CHECK_ARG(k3 || k1 || k2, "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3 or 1x1x1)", kt, kh, kw);
     const bool flat = epi && epi->dec_W > 0;
@@ -1110,6 +1392,34 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
     p.vec4 = aligned ? 1 : 0;
     SS_CHECK_ARG(reinterpret_cast<uintptr_t>(packed_w) % 16 == 0, "conv3d: packed weights must be 16-byte aligned");
+    if (x6) {
+        // bf16x6: the weights were packed with stemseg_hip_pack_conv_weight_split(..., planes = 3).  Tile = the largest whose
+        // launch (with split-K where scratch is given) still covers the chip; tile_cfg 1 / 2 / 3 force big / medium / small.
+        int cfg = tile_cfg;
+        if (k3) {
+            if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
+            if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats);
+            if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats);
+            return launch_cfg<Y3Small>(p, s, scratch, scratch_floats);
+        }
+        if (k2) {
+            if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats);
+            if (cfg <= 0 || cfg > 3) {
+                const int64_t need = scratch ? 96 : 384;
+                cfg = num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= need ? 1 : (num_workgroups<Y2Med>(p.Cout, p.T, p.H, p.W) >= need ? 2 : 3);
+            }
+            if (cfg == 1) return launch_cfg<Y2Big>(p, s, scratch, scratch_floats);
+            if (cfg == 2) return launch_cfg<Y2Med>(p, s, scratch, scratch_floats);
+            return launch_cfg<Y2Small>(p, s, scratch, scratch_floats);
+        }
+        if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats);
+        if (cfg <= 0 || cfg > 2) {
+            cfg = (num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
+            if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
+        }
+        if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats);
+        return launch_cfg<Y1Small>(p, s, scratch, scratch_floats);
+    }
     if (k3) {
         int cfg = tile_cfg;
         if (cfg <= 0 || cfg > 3) {
@@ -1279,6 +1589,28 @@ extern "C" int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t 
     const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH);
     return (int64_t)((Cin + CK - 1) / CK) * 2 * (NTG * NCG) * 2 * Cout * 16;
+}
+
+extern "C" int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes) {
+    if (planes == 2) return stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps);
+    if (planes != 3) return 0;
+    return stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps) / 2 * 3;
+}
+
+extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream) {
+    using namespace stemseg;
+    if (planes == 2) return stemseg_hip_pack_conv_weight_bf16x3(w, packed, Cout, Cin, taps, stream);
+    SS_CHECK_ARG(planes == 3, "pack_conv_weight_split: planes must be 2 (bf16x3) or 3 (bf16x6)");
+    SS_CHECK_ARG(w && packed, "pack_conv_weight_split: null pointer");
+    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_split: taps must be 27, 9 or 1");
+    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
+    SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_split: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
+    const int64_t n = stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) / 16;
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(pack_conv_weight_bf16x6_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
+                       taps, CK, TPG);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
 }
 
 extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,

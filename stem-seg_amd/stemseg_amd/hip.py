@@ -84,6 +84,8 @@ SIGNATURES = {
     "stemseg_hip_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_packed_weight_bytes_bf16x3": (C.c_int64, [_I32, _I32, _I32]),
     "stemseg_hip_pack_conv_weight_bf16x3": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "stemseg_hip_packed_weight_bytes_split": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "stemseg_hip_pack_conv_weight_split": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
     "stemseg_hip_conv3d_gn_scratch_doubles": (C.c_int64, [_I32, _I32]),
     "stemseg_hip_conv3d_gn": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
@@ -176,7 +178,7 @@ def profile_enable(on):
 
 
 # profiler tags: convolutions by tile class (work = FLOP) and the streaming kernels (work = algorithmic bytes)
-PROFILE_CONV_TAGS = {"conv3x3x3": (8, 4, 2), "conv1x3x3": (28, 27, 24, 22), "conv1x1x1": (18, 17, 14, 16, 12)}
+PROFILE_CONV_TAGS = {"conv3x3x3": (9, 8, 4, 2), "conv1x3x3": (36, 28, 27, 24, 22), "conv1x1x1": (18, 17, 14, 16, 12)}
 PROFILE_HBM_TAGS = {40: "upsample_trilinear", 41: "gn_stats (partial + finalize)", 42: "gn_relu (apply)", 43: "gn_relu_pool (apply + AvgPool3d)",
                     44: "heads", 45: "fg_gather (count + scan + scatter)", 46: "cluster (all rounds + final)", 47: "stem_conv7x7",
                     48: "maxpool3x3s2", 49: "subsample2", 50: "upsample2x_add (FPN top-down)"}
@@ -238,20 +240,22 @@ def pack_conv_weight(w):
     return out
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
 def pack_conv_weight_any(w, precision="f32"):
-    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA) or 'bf16x3' (3-term bf16 split, fp32 accumulate)."""
+    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA), 'bf16x3' (two bf16 terms per operand, 3 products) or 'bf16x6'
+    (exact three-term split, 6 products: fp32-level results); fp32 accumulate throughout."""
     if precision == "f32":
         return pack_conv_weight(w)
-    assert precision == "bf16x3", precision
+    assert precision in ("bf16x3", "bf16x6"), precision
+    planes = 2 if precision == "bf16x3" else 3
     w = w.contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w[0, 0].numel()
-    nbytes = lib().stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps)
+    nbytes = lib().stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, planes)
     out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)      # opaque 16-B-aligned blob
-    check(lib().stemseg_hip_pack_conv_weight_bf16x3(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, stream()))
+    check(lib().stemseg_hip_pack_conv_weight_split(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, planes, stream()))
     return out
 
 

@@ -1,0 +1,169 @@
+"""bf16x6 convolution mode (STEMSEG_PRECISION_BF16X6): every fp32 operand split EXACTLY into three bf16 terms, six products on
+the bf16 matrix cores, fp32 accumulation.  The claim under test is "fp32-level results": against an fp64 convolution of the
+same inputs the x6 kernel's error must be of the order of the exact-fp32-MFMA kernel's own error (both are dominated by the
+rounding of the fp32 accumulation), on every kernel class, tile shape, split-K, ragged / unaligned shapes and fused epilogue."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from stemseg_amd import hip as h
+    h.require_gpu()
+    return h
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def _ref64(x, w, b, kt):
+    y = F.conv3d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double(), None if b is None else torch.from_numpy(b).double(),
+                 padding=(kt // 2, w.shape[3] // 2, w.shape[4] // 2))[0]
+    return y.numpy()
+
+
+def _haloed(hip, x, kt):
+    """[C,T,H,W] -> zero-haloed device volume for a (kt,3,3) conv (16-B aligned rows)."""
+    Cn, T, H, W = x.shape
+    if kt == 3:
+        buf, g = hip.alloc_padded(Cn, T, H, W)
+        hip.copy_to_volume(dev(x), 0, hip.padded_interior_view(buf, g, Cn, T, H, W))
+        return buf, hip.padded_halo_view(buf, g, Cn, T, H, W)
+    pitch = (W + 2 + 3) // 4 * 4
+    buf = torch.zeros(Cn, T, H + 2, pitch, device="cuda")
+    buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
+    return buf, hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cn, T, H + 2, W + 2, buf.numel())
+
+
+def _both(hip, vin, w, b, out_shape, k, cfg, scratch_floats=0, flat=False):
+    res = {}
+    for prec in ("f32", "bf16x6"):
+        out = torch.full(out_shape, float("nan"), device="cuda")
+        vout = hip.flat_volume(out) if flat else hip.dense_volume(out)
+        scratch = torch.full((scratch_floats,), float("nan"), device="cuda") if scratch_floats else None
+        hip.conv3d(vin, hip.pack_conv_weight_any(dev(w), prec), None if b is None else dev(b), vout, k, cfg, scratch, dict(precision=prec))
+        torch.cuda.synchronize()
+        res[prec] = out.cpu().numpy().astype(np.float64)
+    return res
+
+
+def _check(name, res, ref):
+    e32 = float(np.abs(res["f32"] - ref).max())
+    e6 = float(np.abs(res["bf16x6"] - ref).max())
+    scale = float(np.abs(ref).max())
+    print("[bf16x6] %-46s max|err| vs fp64: fp32-MFMA %.3e, bf16x6 %.3e (ratio %.2f; max|ref| %.3g); x6 vs fp32-MFMA %.3e"
+          % (name, e32, e6, e6 / max(e32, 1e-30), scale, float(np.abs(res["bf16x6"] - res["f32"]).max())))
+    assert np.isfinite(res["bf16x6"]).all()
+    assert e6 <= max(3.0 * e32, 4e-7 * scale), "bf16x6 is not at the fp32 error level"
+    return e32, e6
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["k3", "k2", "k1"])
+def test_bf16x6_every_tile_shape_vs_fp64(hip, kind, cfg):
+    rs = 71 + cfg
+    if kind == "k1":
+        if cfg == 3:
+            pytest.skip("1x1 has two tile shapes")
+        Cin, Cout, V = 256, 128, 4 * 30 * 54
+        x, w, b = _rand((Cin, V), rs), _rand((Cout, Cin, 1, 1, 1), rs + 1, 1.0 / np.sqrt(Cin)), _rand((Cout,), rs + 2)
+        ref = w.reshape(Cout, Cin).astype(np.float64) @ x.astype(np.float64) + b.astype(np.float64)[:, None]
+        res = _both(hip, hip.flat_volume(dev(x)), w, b, (Cout, V), 1, cfg, flat=True)
+    else:
+        kt = 3 if kind == "k3" else 1
+        Cin, Cout, T, H, W = (64, 128, 3, 21, 40) if kind == "k3" else (64, 128, 2, 17, 70)
+        x, w, b = _rand((Cin, T, H, W), rs), _rand((Cout, Cin, kt, 3, 3), rs + 1, 1.0 / np.sqrt(Cin * 9 * kt)), _rand((Cout,), rs + 2)
+        ref = _ref64(x, w, b, kt)
+        buf, vin = _haloed(hip, x, kt)
+        res = _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), cfg)
+    _check("%s cfg%d" % (kind, cfg), res, ref)
+
+
+@pytest.mark.parametrize("case", [("k3", 8, 64, 3, 5, 37), ("k3", 256, 128, 2, 9, 40), ("k3", 12, 32, 1, 2, 3), ("k3", 16, 160, 4, 17, 70),
+                                  ("k2", 8, 64, 2, 9, 37), ("k2", 256, 256, 2, 6, 27), ("k2", 64, 64, 3, 17, 40), ("k2", 128, 128, 8, 30, 54)])
+def test_bf16x6_ragged_shapes_and_splitk(hip, case):
+    """Odd extents (tiles that hang over every edge, Cin not a multiple of the chunk, Cout below the tile), with and without
+    split-K (fixed-order reduce: run-to-run identical)."""
+    kind, Cin, Cout, T, H, W = case
+    kt = 3 if kind == "k3" else 1
+    x, w, b = _rand((Cin, T, H, W), 5), _rand((Cout, Cin, kt, 3, 3), 6, 1.0 / np.sqrt(Cin * 9 * kt)), _rand((Cout,), 7)
+    ref = _ref64(x, w, b, kt)
+    buf, vin = _haloed(hip, x, kt)
+    _check("%s %s" % (kind, case[1:]), _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), 0), ref)
+    r1 = _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), 0, scratch_floats=16 * Cout * T * H * W)
+    r2 = _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), 0, scratch_floats=16 * Cout * T * H * W)
+    _check("%s %s split-K" % (kind, case[1:]), r1, ref)
+    assert np.array_equal(r1["bf16x6"], r2["bf16x6"])
+
+
+def test_bf16x6_unaligned_input_rows(hip):
+    """A dense (un-haloed) source volume whose rows are not 16-B aligned takes the scalar staging path."""
+    Cin, Cout, T, H, W = 16, 64, 2, 7, 13
+    x, w, b = _rand((Cin, T + 2, H + 2, W + 2), 11), _rand((Cout, Cin, 3, 3, 3), 12, 0.05), _rand((Cout,), 13)
+    xd = dev(x)
+    ref = F.conv3d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double(), torch.from_numpy(b).double())[0].numpy()
+    _check("k3 unaligned rows", _both(hip, hip.dense_volume(xd), w, b, (Cout, T, H, W), 3, 0), ref)
+
+
+@pytest.mark.parametrize("shape", [(64, 256, 2, 9, 37), (1024, 256, 2, 6, 27), (256, 1024, 3, 15, 27)])
+def test_bf16x6_1x1_decode_residual_relu(hip, shape):
+    """The encoder's 1x1 convs: flat [C][V] input, output decoded into a zero-haloed volume, residual + ReLU in the epilogue."""
+    Cin, Cout, T, H, W = shape
+    V = T * H * W
+    x, w, b = _rand((Cin, V), 21), _rand((Cout, Cin, 1, 1, 1), 22, 1.0 / np.sqrt(Cin)), _rand((Cout,), 23)
+    r = _rand((Cout, V), 24)
+    ref = np.maximum(w.reshape(Cout, Cin).astype(np.float64) @ x.astype(np.float64) + b.astype(np.float64)[:, None] + r, 0.0)
+    xd, rd = dev(x), dev(r)
+    res = {}
+    for prec in ("f32", "bf16x6"):
+        pitch = (W + 2 + 3) // 4 * 4
+        buf = torch.zeros(Cout, T, H + 2, pitch, device="cuda")
+        vout = hip.Volume(buf.data_ptr() + 4 * (pitch + 1), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cout, T, H, W, buf.numel() - (pitch + 1))
+        hip.conv3d(hip.flat_volume(xd), hip.pack_conv_weight_any(dev(w), prec), dev(b), vout, 1, 0, None,
+                   dict(relu=1, residual=rd, res_strides=(V, H * W, W), decode=(H, W), precision=prec))
+        torch.cuda.synchronize()
+        res[prec] = buf[:, :, 1:H + 1, 1:W + 1].reshape(Cout, V).cpu().numpy().astype(np.float64)
+        assert float(buf[:, :, 0].abs().max()) == 0.0 and float(buf[:, :, :, 0].abs().max()) == 0.0      # the halo stays zero
+    _check("k1 decode+res+relu %s" % (shape,), res, ref)
+
+
+@pytest.mark.parametrize("case", [(64, 128, 2, 9, 40), (32, 256, 8, 24, 64), (256, 128, 8, 60, 108)])
+def test_bf16x6_conv_with_groupnorm_statistics(hip, case):
+    """conv3d_gn in x6 mode: statistics of the x6 output from the conv epilogue (plain and split-K) vs numpy on the result."""
+    Cin, Cout, T, H, W = case
+    x, w, b = _rand((Cin, T, H, W), 31), _rand((Cout, Cin, 3, 3, 3), 32, 1.0 / np.sqrt(Cin * 27)), _rand((Cout,), 33)
+    buf, vin = _haloed(hip, x, 3)
+    for scratch_floats in (0, 8 * Cout * T * H * W):
+        out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        scratch = torch.empty(scratch_floats, device="cuda") if scratch_floats else None
+        stats = hip.conv3d_gn(vin, hip.pack_conv_weight_any(dev(w), "bf16x6"), dev(b), hip.dense_volume(out), 3, 32, 1e-5, 0, scratch, "bf16x6")
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().astype(np.float64).reshape(32, -1)
+        mean, var = o.mean(1), o.var(1)
+        st = stats.cpu().numpy().reshape(32, 2)
+        assert np.abs(st[:, 0] - mean).max() <= 2e-6 * max(1.0, np.abs(mean).max())
+        assert np.abs(st[:, 1] - 1.0 / np.sqrt(var + 1e-5)).max() <= 1e-4 * (1.0 / np.sqrt(var + 1e-5)).max()
+    ref = _ref64(x, w, b, 3)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5
+
+
+def test_bf16x6_block4x_shape_is_fp32_accurate_and_deterministic(hip):
+    """The dominant launch (256 -> 128 channels, T=8, 120x216): x6 vs fp64 next to the fp32-MFMA kernel, twice."""
+    Cin, Cout, T, H, W = 256, 128, 8, 120, 216
+    x, w, b = _rand((Cin, T, H, W), 41), _rand((Cout, Cin, 3, 3, 3), 42, 1.0 / np.sqrt(Cin * 27)), _rand((Cout,), 43)
+    ref = _ref64(x[:, :3, :40], w, b, 3)[:, 1]                      # fp64 on a slab (t = 1 of the first three planes, 40 rows)
+    buf, vin = _haloed(hip, x, 3)
+    r1 = _both(hip, vin, w, b, (Cout, T, H, W), 3, 0, scratch_floats=4 * Cout * T * H * W)
+    r2 = _both(hip, vin, w, b, (Cout, T, H, W), 3, 0, scratch_floats=4 * Cout * T * H * W)
+    assert np.array_equal(r1["bf16x6"], r2["bf16x6"])
+    sl = {k: v[:, 1, :39] for k, v in r1.items()}
+    _check("block_4x 256->128 T=8 120x216", sl, ref[:, :39])

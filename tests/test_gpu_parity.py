@@ -258,7 +258,7 @@ def test_encoder_vs_golden(hip, golden, btype):
         assert report("encoder %s 1/%d (rel to max %.3g)" % (btype, s, scale), got / scale, ref / scale) <= 1e-4
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 def test_encoder_batch_of_8_odd_size_vs_oracle(hip, precision):
     """T = 8 frames, 96 x 160 (w32 = 5: ragged 32-column tiles everywhere), R-50, vs the CPU oracle."""
     from stemseg_amd.modeling.backbone import ResNetFPN
@@ -458,7 +458,7 @@ def test_seediness_decoder_vs_golden(hip, golden, T):
     assert np.array_equal(a, b), "decoder is not run-to-run deterministic"
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 def test_decoder_full_size_480x864_vs_oracle(hip, precision):
     """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle, both MFMA modes."""
     T, h32, w32 = 8, 15, 27
@@ -567,7 +567,7 @@ def _semseg_head(ncls, fg, ws, inter=(128, 128, 64, 64)):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("name", ["sem_bin", "sem_kitti", "sem_ytvis"])
 def test_semseg_decoder_vs_golden(hip, golden, name, precision):
     """2 / 3+1 channels go through the fused heads kernel, 40+1 through the 1x1x1 MFMA conv (zero-padded to 64 rows)."""
@@ -976,7 +976,7 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 def test_config0_vs_reference_cpu_path(hip, golden, precision):
     """BASELINE configs[0] -- one synthetic 8 x 256 x 448 clip, random-init ResNet-50 -- through the whole HIP path (uint8 frames
     -> pre-processing -> encoder -> decoders -> fg mask -> gather -> clustering -> chainer) against what the REFERENCE itself
@@ -998,7 +998,7 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         model._model.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])).reshape(msd[k].shape) for k in msd})
         model = model.cuda()
         model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
-        exact = precision == "f32"
+        exact = precision in ("f32", "bf16x6")        # bf16x6 = exact three-term split, six products: held to the fp32 standard
         tg = TrackGenerator(model, "davis", seediness_thresh=thr, frame_overlap=4)
         embeddings, fg, _ = tg.do_inference([f for f in frames])
         e = embeddings[0]
@@ -1028,7 +1028,7 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 def test_ytvis_flow_vs_reference(hip, golden, precision):
     """BASELINE configs[2] flow (reduced size) vs the REFERENCE's own CPU result (tests/golden/model_ytvis.npz): YouTube-VIS preset
     -- 7-channel embedding head with in-head seediness, 40+1-channel semseg head (inter [256]*4, wide head on the MFMA conv),
@@ -1050,7 +1050,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         model._model.load_state_dict(new)
         model = model.cuda()
         model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
-        exact = precision == "f32"
+        exact = precision in ("f32", "bf16x6")        # bf16x6 = exact three-term split, six products: held to the fp32 standard
         frames = synth.synth_frames(12, 96, 128, seed=81)
         tg = TrackGenerator(model, "ytvis", resize_scale=4.0, frame_overlap=4)
         out = model([f for f in frames], g["subseqs"].tolist())
@@ -1096,7 +1096,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 def test_kitti_flow_vs_reference(hip, golden, precision):
     """KITTI-MOTS preset ('xyt' embeddings: the time coordinate is an embedding dimension, no free dims; in-head seediness; 3+1
     channel semseg head through the fused heads kernel) at a reduced wide-aspect size, 14 frames as three overlapping clips, vs
@@ -1117,7 +1117,7 @@ def test_kitti_flow_vs_reference(hip, golden, precision):
         model._model.load_state_dict(new)
         model = model.cuda()
         model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
-        exact = precision == "f32"
+        exact = precision in ("f32", "bf16x6")        # bf16x6 = exact three-term split, six products: held to the fp32 standard
         frames = synth.synth_frames(14, 60, 190, seed=91)
         tg = TrackGenerator(model, "kittimots", frame_overlap=4)
         out = model([f for f in frames], g["subseqs"].tolist())
@@ -1250,7 +1250,7 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("size", [(96, 160), (256, 448)])
 def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
     """One clip through ClipPipeline.step (the bench's unit of work) vs the oracle pipeline -- at a reduced size and at
