@@ -1139,6 +1139,7 @@ using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, 2>;  //  64 co x 256 vo
 // sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
 // MFMA peak)
 constexpr double CU_FLOPS_F32 = 0.46e12;
+constexpr double CU_FLOPS_X6 = 1.0e12;      // bf16x6: fp32-equivalent FLOP/s of one CU while its MFMA stream runs (first measurements)
 #ifndef STEMSEG_GLDS_DEFAULT
 #define STEMSEG_GLDS_DEFAULT 9
 #endif
@@ -1298,9 +1299,10 @@ static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int
 
 // big launches (>= 512 workgroups of the 8-row tile): 8-row tile vs 4-row tile, each with its best row cut
 template <class Big, class Med>
-static int launch_planned(const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, int occ_big, int occ_med) {
-    const RowPlan a = plan_rows<Big>(p, scratch != nullptr, scratch_floats, CU_FLOPS_F32, occ_big, 1.0);
-    const RowPlan b = plan_rows<Med>(p, scratch != nullptr, scratch_floats, CU_FLOPS_F32, occ_med, 0.92);
+static int launch_planned(const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, int occ_big, int occ_med,
+                          double cu_flops = CU_FLOPS_F32) {
+    const RowPlan a = plan_rows<Big>(p, scratch != nullptr, scratch_floats, cu_flops, occ_big, 1.0);
+    const RowPlan b = plan_rows<Med>(p, scratch != nullptr, scratch_floats, cu_flops, occ_med, 0.92);
     if (b.cost < 0.97 * a.cost) return launch_rows<Med>(p, s, scratch, scratch_floats, b);
     return launch_rows<Big>(p, s, scratch, scratch_floats, a);
 }
@@ -1398,6 +1400,9 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         int cfg = tile_cfg;
         if (k3) {
             if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
+            // big launches: the row planner (whole rows + split-K rows, see plan_rows) with one eight-wave workgroup per CU
+            static const bool plan6 = [] { const char* e = getenv("STEMSEG_X6_PLANNER"); return !(e && e[0] == '0'); }();
+            if (cfg == 1 && plan6 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<Y3Big, Y3Med>(p, s, scratch, scratch_floats, 1, 1, CU_FLOPS_X6);
             if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats);
             if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats);
             return launch_cfg<Y3Small>(p, s, scratch, scratch_floats);

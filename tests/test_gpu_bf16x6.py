@@ -77,7 +77,8 @@ def test_bf16x6_every_tile_shape_vs_fp64(hip, kind, cfg):
         Cin, Cout, V = 256, 128, 4 * 30 * 54
         x, w, b = _rand((Cin, V), rs), _rand((Cout, Cin, 1, 1, 1), rs + 1, 1.0 / np.sqrt(Cin)), _rand((Cout,), rs + 2)
         ref = w.reshape(Cout, Cin).astype(np.float64) @ x.astype(np.float64) + b.astype(np.float64)[:, None]
-        res = _both(hip, hip.flat_volume(dev(x)), w, b, (Cout, V), 1, cfg, flat=True)
+        xd = dev(x)                                                  # (a Volume holds a raw pointer: keep the tensor alive)
+        res = _both(hip, hip.flat_volume(xd), w, b, (Cout, V), 1, cfg, flat=True)
     else:
         kt = 3 if kind == "k3" else 1
         Cin, Cout, T, H, W = (64, 128, 3, 21, 40) if kind == "k3" else (64, 128, 2, 17, 70)

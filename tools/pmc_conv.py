@@ -16,7 +16,8 @@ hip.require_gpu()
 buf, g = hip.alloc_padded(Cin, T, H, W)
 x = torch.randn(Cin, T, H, W, device="cuda")
 hip.copy_to_volume(x, 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
-w = hip.pack_conv_weight(torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.02)
+PREC = os.environ.get("PREC", "f32")
+w = hip.pack_conv_weight_any(torch.randn(Cout, Cin, 3, 3, 3, device="cuda") * 0.02, PREC)
 b = torch.randn(Cout, device="cuda")
 out = torch.empty(Cout, T, H, W, device="cuda")
 scratch = torch.empty(2 * out.numel(), device="cuda") if os.environ.get("PMC_NO_SCRATCH") is None else None   # enables the row-balanced launch
@@ -24,7 +25,7 @@ torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 for _ in range(reps):
-    hip.conv3d(hip.padded_halo_view(buf, g, Cin, T, H, W), w, b, hip.dense_volume(out), 3, cfg, scratch)
+    hip.conv3d(hip.padded_halo_view(buf, g, Cin, T, H, W), w, b, hip.dense_volume(out), 3, cfg, scratch, dict(precision=PREC))
 ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps
