@@ -241,6 +241,10 @@ def pack_conv_weight(w):
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+# MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision): "f32" = fp32-input MFMA;
+# "bf16x6" = exact three-term bf16 split, six products (fp32-level results, ~1.5x faster end to end); STEMSEG_PRECISION overrides
+DEFAULT_PRECISION = os.environ.get("STEMSEG_PRECISION", "f32")
+assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
 
 
 def pack_conv_weight_any(w, precision="f32"):

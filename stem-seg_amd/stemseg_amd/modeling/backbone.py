@@ -101,7 +101,7 @@ class ResNetFPN(nn.Module):
         self.fpn = _FPN(out_channels)
         self.out_channels, self.is_3d = out_channels, False
         self._packed, self._sig, self._ws = None, None, {}
-        self.precision = "f32"    # "f32" | "bf16x3" (see stemseg_hip.h)
+        self.precision = hip.DEFAULT_PRECISION    # "f32" | "bf16x3" (see stemseg_hip.h)
         self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
 
     # ---- FrozenBN folding: w' = w * scale[:, None, None, None], b' = shift (exact: eps == 0) -------------------

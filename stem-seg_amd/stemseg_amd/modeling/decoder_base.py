@@ -63,7 +63,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
         self.detached = False     # True: the call does not join; ``join()`` must follow (twin-decoder overlap)
-        self.precision = "f32"    # "f32": exact fp32 MFMA | "bf16x3": 3-term bf16 split MFMA with fp32 accumulation
+        self.precision = hip.DEFAULT_PRECISION    # "f32": exact fp32 MFMA | "bf16x3": 3-term bf16 split MFMA with fp32 accumulation
         self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
 
     # ---- to be provided by the concrete decoder ---------------------------------------------------
