@@ -143,8 +143,9 @@ struct ConvCfg {
     // workgroups per CU the register allocator must leave room for: the GL forms carry no staging registers, so the tiles whose
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
     // (the second __launch_bounds__ argument is waves per SIMD: an eight-wave x6 workgroup alone on its CU is two per SIMD as well)
-    static constexpr int MIN_WG = (GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2);
     static constexpr int NWAVES = WM * WN;
+    static constexpr int MIN_WG = X6 ? (LDS_FLOATS * 4 * 2 <= 160 * 1024 ? NWAVES / 2 : NWAVES / 4)      // x6: workgroups per CU by LDS x waves per SIMD of one
+                                     : ((GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2));
 };
 
 template <class C>
@@ -455,11 +456,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
-#pragma unroll
-        for (int grp = 0; grp < C::G; ++grp) {
-            if (grp < g0 || grp >= g1) continue;
+        auto ld_b = [&](const int grp, bf16x8 (&b)[3][C::NI]) __attribute__((always_inline)) {
             const int cg = grp / C::NTG, tg = grp % C::NTG;
-            bf16x8 b[3][C::NI];
 #pragma unroll
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
@@ -477,19 +475,43 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     }
                     b[pl][ni] = __builtin_bit_cast(bf16x8, w4);
                 }
+        };
+        auto ld_a = [&](const int grp, const int mi, bf16x8 (&a)[3]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int mi = 0; mi < C::MI; ++mi) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[pl] = *reinterpret_cast<const bf16x8*>(a_base + (((grp * 3 + pl) * 2) * C::MT + mi * 32) * 16);
-                // smallest products first (planes: 0 hi, 1 mid, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
+            for (int pl = 0; pl < 3; ++pl)
+                a[pl] = *reinterpret_cast<const bf16x8*>(a_base + (((grp * 3 + pl) * 2) * C::MT + mi * 32) * 16);
+        };
+        // smallest products first (planes: 0 hi, 1 mid, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
+        auto mm = [&](const int mi, const bf16x8 (&a)[3], const bf16x8 (&b)[3][C::NI]) __attribute__((always_inline)) {
 #define SS_X6_TERM(PA, PB)                                                                                                     \
     _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
-                SS_X6_TERM(2, 0) SS_X6_TERM(0, 2) SS_X6_TERM(1, 1) SS_X6_TERM(1, 0) SS_X6_TERM(0, 1) SS_X6_TERM(0, 0)
+            SS_X6_TERM(2, 0) SS_X6_TERM(0, 2) SS_X6_TERM(1, 1) SS_X6_TERM(1, 0) SS_X6_TERM(0, 1) SS_X6_TERM(0, 0)
 #undef SS_X6_TERM
+        };
+        // software pipeline over the (k-group, mi) steps: the A fragments of step s + 1 are requested from LDS BEFORE the
+        // 6 x NI MFMAs of step s are issued (two register sets), a group's B fragments right after the previous group's last
+        // MFMAs -- left to itself the compiler reads each fragment right in front of the MFMAs that consume it and waits there
+        constexpr int NSTEP = (g1 - g0) * C::MI;
+        bf16x8 bfr[3][C::NI], a0[3], a1[3];
+        ld_b(g0, bfr);
+        ld_a(g0, 0, a0);
+#pragma unroll
+        for (int st = 0; st < NSTEP; st += 2) {
+            const int grp = g0 + st / C::MI, mi = st % C::MI;
+            if (st + 1 < NSTEP) ld_a(g0 + (st + 1) / C::MI, (st + 1) % C::MI, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(mi, a0, bfr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < NSTEP) {
+                if ((st + 1) % C::MI == 0) ld_b(g0 + (st + 1) / C::MI, bfr);
+                if (st + 2 < NSTEP) ld_a(g0 + (st + 2) / C::MI, (st + 2) % C::MI, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm((st + 1) % C::MI, a1, bfr);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 2 < NSTEP && (st + 2) % C::MI == 0) ld_b(g0 + (st + 2) / C::MI, bfr);
             }
+            (void)grp;
         }
     };
     // ---- MFMA stream over one staged chunk: every tap is a shifted LDS read ------------------------------
@@ -1398,10 +1420,18 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         // bf16x6: the weights were packed with stemseg_hip_pack_conv_weight_split(..., planes = 3).  Tile = the largest whose
         // launch (with split-K where scratch is given) still covers the chip; tile_cfg 1 / 2 / 3 force big / medium / small.
         int cfg = tile_cfg;
+        // STEMSEG_X6_TILES (debug / A-B): bit 0 no big 3x3x3 tile, bit 1 no big 2-D tile, bit 2 no big 1x1 tile, bit 3 no split-K
+        static const int x6_off = [] { const char* e = getenv("STEMSEG_X6_TILES"); return e ? atoi(e) : 0; }();
+        if (x6_off & 8) { scratch = nullptr; scratch_floats = 0; }
+        if (cfg <= 0 || cfg > 3) {
+            if (k3 && (x6_off & 1)) cfg = 2;
+            if (k2 && (x6_off & 2) && p.Cout > 64) cfg = 2;
+            if (k1 && (x6_off & 4) && p.Cout > 64) cfg = 2;
+        }
         if (k3) {
             if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
             // big launches: the row planner (whole rows + split-K rows, see plan_rows) with one eight-wave workgroup per CU
-            static const bool plan6 = [] { const char* e = getenv("STEMSEG_X6_PLANNER"); return !(e && e[0] == '0'); }();
+            static const bool plan6 = [] { const char* e = getenv("STEMSEG_X6_PLANNER"); return e && e[0] == '1'; }();   // (measured: 63.6 clips/s with, 64.7 without)
             if (cfg == 1 && plan6 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<Y3Big, Y3Med>(p, s, scratch, scratch_floats, 1, 1, CU_FLOPS_X6);
             if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats);
             if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats);

@@ -241,9 +241,12 @@ def pack_conv_weight(w):
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
-# MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision): "f32" = fp32-input MFMA;
-# "bf16x6" = exact three-term bf16 split, six products (fp32-level results, ~1.5x faster end to end); STEMSEG_PRECISION overrides
-DEFAULT_PRECISION = os.environ.get("STEMSEG_PRECISION", "f32")
+# MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision): "bf16x6" (default) =
+# every fp32 operand split EXACTLY into three bf16 terms, six products, fp32 accumulation -- fp32-level results (error vs an
+# fp64 convolution = that of the fp32-input MFMA kernel, tests/test_gpu_bf16x6.py; labels identical on every reference flow)
+# at ~1.5x the end-to-end rate; "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands; "bf16x3" = two-term split (~1e-4, opt-in).
+# STEMSEG_PRECISION overrides the default.
+DEFAULT_PRECISION = os.environ.get("STEMSEG_PRECISION", "bf16x6")
 assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
 
 
