@@ -419,7 +419,10 @@ def read_cluster_meta(meta_dev):
         buf = _meta_pinned[key] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
     buf.copy_(meta_dev, non_blocking=True)
     torch.cuda.current_stream(meta_dev.device).synchronize()
-    return ClusterMeta.from_buffer_copy(buf.numpy().tobytes())
+    meta = ClusterMeta.from_buffer_copy(buf.numpy().tobytes())
+    if meta.K < 0:
+        raise RuntimeError("stemseg_hip_cluster: the one-launch clusterer's grid barrier timed out (STEMSEG_CLUSTER_PERSISTENT)")
+    return meta
 
 
 def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):
