@@ -62,6 +62,19 @@ def _frames(T, H, W, valid_w, seed):
     return x.contiguous()
 
 
+def _assert_exact_or_in_band(what, got, ref_labels, ref_meta, band):
+    """Integer outputs: identical, or every mismatch is a point whose ORACLE probability sits within ``band`` of a threshold
+    (0.5 primary, 0.3 secondary) in some round -- SURVEY.md A.2 'bit-exactness test design' (libm vs GPU exp / sqrt last-ulp
+    differences: band 2e-6 on identical inputs; 1e-4 when the float maps themselves differ by the 1e-6 of two fp32 pipelines)."""
+    bad = np.flatnonzero(np.asarray(got) != np.asarray(ref_labels))
+    print("[fullsize] %s: %d / %d labels differ" % (what, bad.size, np.asarray(ref_labels).size))
+    if bad.size:
+        P = np.stack(ref_meta["instance_probs"])
+        near = (np.abs(P - 0.5) < band).any(0) | (np.abs(P - 0.3) < band).any(0)
+        assert np.all(near[bad]), "%s: %d label mismatches away from the threshold band" % (what, int((~near[bad]).sum()))
+    return bad.size
+
+
 def _labels_on_grid(fg, labels):
     out = np.full(fg.size, -2, np.int64)
     out[np.flatnonzero(np.asarray(fg).reshape(-1))] = np.asarray(labels)
@@ -79,7 +92,7 @@ def test_config1_davis_r101_clip_480x864_vs_oracle(hip):
         out = pipe.step(frames.cuda())
         torch.cuda.synchronize()
         t0 = time.time()
-        ref = opipe.embed_and_cluster_clip(frames, sd, "R-101-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+        ref = opipe.embed_and_cluster_clip(frames, sd, "R-101-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3], return_probs=True)
         print("[fullsize] oracle clip took %.1f s" % (time.time() - t0))
         assert _maxerr("config1 emb", out["emb"].cpu().numpy(), ref["emb"].numpy()) <= 1e-3
         assert _maxerr("config1 seediness", out["seed"].cpu().numpy(), ref["seed"].numpy()) <= 1e-3
@@ -94,14 +107,16 @@ def test_config1_davis_r101_clip_480x864_vs_oracle(hip):
         print("[fullsize] config1: fg %d vs %d (%d differ), K %d vs %d, labels identical on %.5f of the common fg"
               % (g_fg.sum(), c_fg.sum(), (g_fg != c_fg).sum(), meta.K, len(ref["meta"]["instance_labels"]), agree))
         assert n == g_fg.sum() > 100000 and (g_fg != c_fg).mean() < 1e-4
-        assert meta.K == len(ref["meta"]["instance_labels"]) >= 10 and agree >= 0.999
+        assert meta.K == len(ref["meta"]["instance_labels"]) >= 10
+        if np.array_equal(g_fg, c_fg):           # same points on both sides: every label identical, or inside the threshold band
+            _assert_exact_or_in_band("config1 HIP maps vs oracle maps", out["labels"][:n].cpu().numpy(), ref["labels"], ref["meta"], 1e-4)
+        else:
+            assert agree >= 0.9999
         # integer bookkeeping proper: the oracle's float maps through the HIP gather + clusterer -> the oracle's labels
         o2 = pipe.cluster(ref["emb"].cuda().contiguous(), ref["bw"].cuda().contiguous(), ref["seed"].cuda().contiguous())
         n2 = int(o2["frame_offsets"].cpu()[-1])
         assert n2 == ref["labels"].shape[0]
-        bad = int((o2["labels"][:n2].cpu().numpy() != ref["labels"]).sum())
-        print("[fullsize] config1 clusterer on the oracle's maps: %d / %d labels differ" % (bad, n2))
-        assert bad <= max(2, n2 // 2000)
+        _assert_exact_or_in_band("config1 clusterer on the oracle's maps", o2["labels"][:n2].cpu().numpy(), ref["labels"], ref["meta"], 2e-6)
     finally:
         config.load_preset("defaults")
 
@@ -124,7 +139,7 @@ def test_config1_davis_reference_resize_704x1248_vs_oracle(hip):
         out = pipe.step(frames.cuda())
         torch.cuda.synchronize()
         t0 = time.time()
-        ref = opipe.embed_and_cluster_clip(frames, sd, "R-50-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+        ref = opipe.embed_and_cluster_clip(frames, sd, "R-50-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3], return_probs=True)
         print("[fullsize] oracle 704x1248 clip took %.1f s" % (time.time() - t0))
         assert tuple(out["emb"].shape) == (4, 8, 176, 312)
         assert _maxerr("davis 704x1248 emb", out["emb"].cpu().numpy(), ref["emb"].numpy()) <= 1e-3
@@ -132,9 +147,9 @@ def test_config1_davis_reference_resize_704x1248_vs_oracle(hip):
         assert _maxerr("davis 704x1248 bandwidth (rel)", (out["bw"].cpu() / ref["bw"]).numpy(), np.ones(ref["bw"].shape)) <= 1e-3
         o2 = pipe.cluster(ref["emb"].cuda().contiguous(), ref["bw"].cuda().contiguous(), ref["seed"].cuda().contiguous())
         n2 = int(o2["frame_offsets"].cpu()[-1])
-        bad = int((o2["labels"][:n2].cpu().numpy() != ref["labels"]).sum()) if n2 == ref["labels"].shape[0] else -1
-        print("[fullsize] davis 704x1248: %d fg points, K %d, %d labels differ" % (n2, len(ref["meta"]["instance_labels"]), bad))
-        assert n2 == ref["labels"].shape[0] and 0 <= bad <= max(2, n2 // 2000)
+        assert n2 == ref["labels"].shape[0]
+        print("[fullsize] davis 704x1248: %d fg points, K %d" % (n2, len(ref["meta"]["instance_labels"])))
+        _assert_exact_or_in_band("davis 704x1248 clusterer on the oracle's maps", o2["labels"][:n2].cpu().numpy(), ref["labels"], ref["meta"], 2e-6)
     finally:
         config.load_preset("defaults")
 
@@ -180,16 +195,16 @@ def test_config4_kitti_clip_608x1952_vs_oracle(hip):
         assert (fg.cpu().numpy() != r_fg).mean() < 1e-4
         # clustering at this N: the oracle's maps + mask through the HIP gather / clusterer vs the oracle's labels
         min_seed = float(np.quantile(r_seed.numpy()[0][r_fg.astype(bool)], 0.9)) if r_fg.any() else 0.5
-        ref_lab, ref_meta, _ = opipe.cluster_clip(r_emb, r_bw, r_seed, r_fg, min_seediness=min_seed, free_dim_stds=[])
+        ref_lab, ref_meta, _ = opipe.cluster_clip(r_emb, r_bw, r_seed, r_fg, min_seediness=min_seed, free_dim_stds=[], return_probs=True)
         from stemseg_amd.inference.clusterers import SequentialClustering
         cl = SequentialClustering(0.5, 0.3, min_seed, 0, [], "cuda:0")
         e, b, s, vox, offs = hip.fg_gather(r_emb.cuda().contiguous(), r_bw.cuda().contiguous(), r_seed.cuda().contiguous(), torch.from_numpy(r_fg).cuda())
         labels, meta_dev, _, _ = cl.enqueue(e, b, s, 1, offs[8:])
         n = int(offs.cpu()[-1])
         meta = hip.read_cluster_meta(meta_dev)
-        bad = int((labels[:n].cpu().numpy() != ref_lab).sum())
-        print("[fullsize] config4: %d fg points, K %d vs %d, %d labels differ" % (n, meta.K, len(ref_meta["instance_labels"]), bad))
-        assert n == ref_lab.shape[0] and meta.K == len(ref_meta["instance_labels"]) and bad <= max(2, n // 2000)
+        print("[fullsize] config4: %d fg points, K %d vs %d" % (n, meta.K, len(ref_meta["instance_labels"])))
+        assert n == ref_lab.shape[0] and meta.K == len(ref_meta["instance_labels"])
+        _assert_exact_or_in_band("config4 clusterer on the oracle's maps", labels[:n].cpu().numpy(), ref_lab, ref_meta, 2e-6)
     finally:
         config.load_preset("defaults")
 

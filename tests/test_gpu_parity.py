@@ -1273,7 +1273,7 @@ def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
     frames = torch.from_numpy(synth.synth_frames(8, size[0], size[1], seed=33).astype(np.float32)).permute(0, 3, 1, 2) - \
         torch.tensor(config.cfg.INPUT.IMAGE_MEAN)[None, :, None, None]
     out = pipe.step(frames.cuda())
-    ref = opipe.embed_and_cluster_clip(frames, sd, "R-50-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3])
+    ref = opipe.embed_and_cluster_clip(frames, sd, "R-50-FPN", "xyff", 4, True, free_dim_stds=[0.3, 0.3], return_probs=True)
     assert report("pipeline emb", out["emb"].cpu().numpy(), ref["emb"].numpy()) <= 1e-3
     assert report("pipeline seed", out["seed"].cpu().numpy(), ref["seed"].numpy()) <= 1e-3
     assert report("pipeline bw (rel)", (out["bw"].cpu() / ref["bw"]).numpy(), np.ones(ref["bw"].shape)) <= 1e-3
@@ -1285,5 +1285,8 @@ def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
     assert n == ref["labels"].shape[0]
     bad = np.flatnonzero(o2["labels"][:n].cpu().numpy() != ref["labels"])
     print("[parity] pipeline labels: %d / %d differ" % (bad.size, n))
-    assert bad.size <= max(2, n // 2000)
+    if bad.size:          # identical, or inside the threshold band of the oracle's own probabilities
+        P = np.stack(ref["meta"]["instance_probs"])
+        near = (np.abs(P - 0.5) < 2e-6).any(0) | (np.abs(P - 0.3) < 2e-6).any(0)
+        assert near[bad].all()
     config.load_preset("defaults")
