@@ -36,6 +36,7 @@ extern "C" {
 #define STEMSEG_E_WORKSPACE    -3   /* workspace too small                            */
 #define STEMSEG_E_UNSUPPORTED  -4
 
+#define STEMSEG_MAX_HEAD_OUT   10   /* fused heads kernel: embedding + variance + seediness channels (xytff + seediness = 9) */
 #define STEMSEG_MAX_INSTANCES  64   /* upper bound for ClusterParams.max_instances    */
 #define STEMSEG_MAX_EMB_DIMS    8
 
@@ -171,11 +172,11 @@ typedef struct StemsegDecoderDesc {
     int32_t in_channels;         /* FPN channels (256)                                                      */
     int32_t inter[4];            /* INTER_CHANNELS for the 32x,16x,8x,4x branches (256,256,128,128)          */
     int32_t T, H4, W4;           /* clip length and 1/4-resolution output size; H4 % 8 == 0, W4 % 8 == 0    */
-    int32_t gn_groups;           /* 32                                                                      */
+    int32_t gn_groups;           /* 32; 0 = NORMALIZATION_LAYER 'none' (nn.Identity, model_builder.py:29-33): gn_w / gn_b must then be ones / zeros */
     float   gn_eps;              /* 1e-5                                                                    */
-    int32_t pool[3];             /* common.py:8-24 : is temporal pooling layer i active (T=8: 1,1,0)        */
+    int32_t pool[3];             /* common.py:8-24 : temporal pooling layer i: 0 absent, 1 AvgPool3d, 2 MaxPool3d (POOL_TYPE; T=8: 1,1,0) */
     int32_t t_scale[3];          /* common.py:27-35: temporal up-sampling factors (T=8: 1,2,2)              */
-    int32_t n_out;               /* head output channels: 1..8 = fused heads kernel (emb + var + seed / seediness);
+    int32_t n_out;               /* head output channels: 1..10 = fused heads kernel (emb + var + seed / seediness);
                                     a multiple of 32 = plain linear head through the 1x1x1 MFMA conv (semseg logits,
                                     semseg_decoder.py:116; weights->head_w is then a packed conv weight, act is ignored) */
     int32_t act[STEMSEG_MAX_EMB_DIMS * 2];        /* per output channel, see stemseg_hip_heads          */

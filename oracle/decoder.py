@@ -56,13 +56,18 @@ def add_offset(emb, mode, t_scale=1.0):
     return emb + grid
 
 
+# model_builder.py:29-33: POOL_TYPE 'avg' | 'max', NORMALIZATION_LAYER 'gn' | 'none' (every preset uses avg / gn)
+VARIANT = {"pool": "avg", "norm": "gn"}
+
+
 def _block(x, sd, prefix, idx, pool):
-    """conv3x3x3(+bias) -> GroupNorm(32) -> ReLU -> [AvgPool3d(3,(2,1,1),1)]  (embedding_decoder.py:20-60)"""
+    """conv3x3x3(+bias) -> GroupNorm(32) | Identity -> ReLU -> [AvgPool3d | MaxPool3d (3,(2,1,1),1)]  (embedding_decoder.py:20-60)"""
     x = F.conv3d(x, _t(sd[prefix + "%d.weight" % idx]), _t(sd[prefix + "%d.bias" % idx]), padding=1)
-    x = F.group_norm(x, 32, _t(sd[prefix + "%d.weight" % (idx + 1)]), _t(sd[prefix + "%d.bias" % (idx + 1)]), 1e-5)
+    if VARIANT["norm"] == "gn":
+        x = F.group_norm(x, 32, _t(sd[prefix + "%d.weight" % (idx + 1)]), _t(sd[prefix + "%d.bias" % (idx + 1)]), 1e-5)
     x = F.relu(x)
     if pool:
-        x = F.avg_pool3d(x, 3, stride=(2, 1, 1), padding=1)
+        x = F.avg_pool3d(x, 3, stride=(2, 1, 1), padding=1) if VARIANT["pool"] == "avg" else F.max_pool3d(x, 3, stride=(2, 1, 1), padding=1)
     return x
 
 

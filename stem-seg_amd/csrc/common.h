@@ -8,6 +8,10 @@
 
 #include "../../include/stemseg_hip.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "libstemseg_hip is written for 64-lane wavefronts (gfx950): shuffles, ballots and MFMA layouts assume it"
+#endif
+
 namespace stemseg {
 
 void set_error(const char* fmt, ...);
@@ -98,6 +102,7 @@ static inline int64_t gn_scratch_doubles(int Cout, int groups) { return (int64_t
 int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
                      int tile_cfg, hipStream_t s, float* splitk_scratch, int64_t splitk_scratch_floats, const ConvEpilogue* epi, int groups,
                      float eps, float* stats, double* gn_scratch);
+int launch_gn_identity_stats(float* stats, int groups, hipStream_t s);
 int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s);
 int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
                         const float* beta, int pool, const StemsegVolume& out, hipStream_t s);

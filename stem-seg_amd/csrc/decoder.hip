@@ -71,10 +71,12 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     SS_CHECK_ARG(d->T >= 1 && d->H4 >= 8 && d->W4 >= 8 && d->H4 % 8 == 0 && d->W4 % 8 == 0,
                  "decoder: T=%d H4=%d W4=%d (H4, W4 must be positive multiples of 8)", d->T, d->H4, d->W4);
     SS_CHECK_ARG(d->in_channels % 4 == 0 && d->in_channels > 0, "decoder: in_channels %% 4");
-    for (int i = 0; i < 4; ++i) SS_CHECK_ARG(d->inter[i] > 0 && d->inter[i] % 32 == 0 && d->inter[i] % d->gn_groups == 0,
+    SS_CHECK_ARG(d->gn_groups >= 0 && d->gn_groups <= 64, "decoder: gn_groups %d (0 = no normalisation layer, else 1..64)", d->gn_groups);
+    for (int i = 0; i < 4; ++i) SS_CHECK_ARG(d->inter[i] > 0 && d->inter[i] % 32 == 0 && (d->gn_groups == 0 || d->inter[i] % d->gn_groups == 0),
                                              "decoder: inter[%d]=%d must be a multiple of 32 and of gn_groups", i, d->inter[i]);
-    SS_CHECK_ARG((d->n_out >= 1 && d->n_out <= 8) || (d->n_out <= 256 && d->n_out % 32 == 0),
-                 "decoder: n_out=%d (1..8 through the fused heads kernel, or a multiple of 32 <= 256 through the 1x1x1 MFMA conv)", d->n_out);
+    for (int i = 0; i < 3; ++i) SS_CHECK_ARG(d->pool[i] >= 0 && d->pool[i] <= 2, "decoder: pool[%d]=%d (0 none, 1 AvgPool3d, 2 MaxPool3d)", i, d->pool[i]);
+    SS_CHECK_ARG((d->n_out >= 1 && d->n_out <= STEMSEG_MAX_HEAD_OUT) || (d->n_out <= 256 && d->n_out % 32 == 0),
+                 "decoder: n_out=%d (1..%d through the fused heads kernel, or a multiple of 32 <= 256 through the 1x1x1 MFMA conv)", d->n_out, STEMSEG_MAX_HEAD_OUT);
     SS_CHECK_ARG(d->input_layout >= 0 && d->input_layout <= 2, "decoder: input_layout");
     p.cin = d->in_channels; p.c32 = d->inter[0]; p.c16 = d->inter[1]; p.c8 = d->inter[2]; p.c4 = d->inter[3];
     p.T = d->T; p.G = d->gn_groups;
@@ -114,10 +116,9 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     p.X4 = take((int64_t)p.c4 * p.T * p.h[3] * p.w[3]);
     for (int i = 0; i < 4; ++i) {
         p.stats[i] = take(2 * 64);
-        p.gn_scratch[i] = take(2 * gn_scratch_doubles(64 * 8, 64));   // doubles (2 floats each): groups (<= 64) x GN_SLOT_CAP x 2
+        p.gn_scratch[i] = take(2 * gn_scratch_doubles(64 * 8, p.G > 0 ? p.G : 1));   // doubles (2 floats each): the decoder's OWN group count x GN_SLOT_CAP x 2
     }
     p.total = off;
-    SS_CHECK_ARG(p.G <= 64, "decoder: gn_groups > 64");
     return STEMSEG_OK;
 }
 
@@ -163,6 +164,13 @@ static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b,
     StemsegVolume d = dense_volume(D, Cout, T, H, W);
     ConvEpilogue e;
     e.precision = precision;
+    if (G == 0) {      // NORMALIZATION_LAYER 'none' (model_builder.py:29-33): conv -> ReLU -> pool; gw / gb are ones / zeros from the caller
+        int rc0 = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e);
+        if (rc0) return rc0;
+        rc0 = launch_gn_identity_stats(stats, 1, s);
+        if (rc0) return rc0;
+        return launch_gn_relu_pool(D, Cout, T, H, W, 1, stats, gw, gb, pool, dst, s);
+    }
     // the conv's epilogue (or its split-K reduce) leaves the GroupNorm partial sums: its output is not read again for them
     int rc = launch_conv3d_gn(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e, G, eps, stats, scratch);
     if (rc) return rc;
@@ -335,7 +343,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
     if (rc) return rc;
     // 5. heads (:131-143)
-    if (desc->n_out > 8) {
+    if (desc->n_out > STEMSEG_MAX_HEAD_OUT) {
         // wide linear head (semseg_decoder.py:116: conv_out, class logits, no activation): the 1x1x1 MFMA conv; head_w is
         // then a PACKED conv weight with Cout = n_out (zero-padded to a multiple of 32 by the caller), head_b may be NULL
         rc = launch_conv3d(flat_volume(ws + p.X4, p.c4, V4), wts->head_w, wts->head_b, flat_volume(out, desc->n_out, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);

@@ -97,7 +97,7 @@ static int launch_heads_n(const HeadsParams& p, hipStream_t s) {
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
                  const float* gt, const float* gy, const float* gx, float* out, hipStream_t s) {
     SS_CHECK_ARG(x && w && out, "heads: null pointer");
-    SS_CHECK_ARG(hs.n_out >= 1 && hs.n_out <= 8, "heads: n_out=%d unsupported (1..8)", hs.n_out);
+    SS_CHECK_ARG(hs.n_out >= 1 && hs.n_out <= STEMSEG_MAX_HEAD_OUT, "heads: n_out=%d unsupported (1..%d)", hs.n_out, STEMSEG_MAX_HEAD_OUT);
     SS_CHECK_ARG(Cin % 4 == 0 && W % 4 == 0, "heads: Cin %% 4 == 0 and W %% 4 == 0 required (Cin=%d, W=%d)", Cin, W);
     SS_CHECK_ARG((reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0), "heads: 16-byte alignment");
     HeadsParams p;
@@ -122,7 +122,9 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
         case 5: rc = launch_heads_n<5>(p, s); break;
         case 6: rc = launch_heads_n<6>(p, s); break;
         case 7: rc = launch_heads_n<7>(p, s); break;
-        default: rc = launch_heads_n<8>(p, s); break;
+        case 8: rc = launch_heads_n<8>(p, s); break;
+        case 9: rc = launch_heads_n<9>(p, s); break;          // xytff + seediness (embedding_utils.py:4-25): 5 + 3 + 1
+        default: rc = launch_heads_n<10>(p, s); break;
     }
     profile_end(ev, s);
     return rc;
@@ -134,7 +136,7 @@ extern "C" int stemseg_hip_heads(const float* x, int32_t Cin, int32_t T, int32_t
                                  int32_t n_out, const int32_t* act_host, const int32_t* grid_axis_host, const float* grid_t,
                                  const float* grid_y, const float* grid_x, float* out, void* stream) {
     using namespace stemseg;
-    SS_CHECK_ARG(act_host && grid_axis_host && n_out >= 1 && n_out <= 8, "heads: bad head spec");
+    SS_CHECK_ARG(act_host && grid_axis_host && n_out >= 1 && n_out <= STEMSEG_MAX_HEAD_OUT, "heads: bad head spec");
     HeadSpec hs;
     hs.n_out = n_out;
     for (int o = 0; o < n_out; ++o) { hs.act[o] = act_host[o]; hs.grid_axis[o] = grid_axis_host[o]; }

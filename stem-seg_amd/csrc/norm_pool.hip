@@ -113,6 +113,8 @@ struct GnApplyParams {
     float* out;
     int64_t out_cs, out_ts, out_ys;
     int C, T, H, W, To, cpg;
+    int pool_max;                  // pooled forms: 0 = AvgPool3d (sum / 27, count_include_pad), 1 = MaxPool3d (values are >= 0 after the ReLU, so the
+                                   // -inf padding of nn.MaxPool3d and a zero start give the same maximum)
 };
 
 // Scalar form, any destination layout: one thread per output element, x fastest.
@@ -147,11 +149,12 @@ __global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int xx = x + dx;
                         if (xx < 0 || xx >= p.W) continue;
-                        acc += fmaxf(fmaf(row[xx], a, b), 0.f);
+                        const float rv = fmaxf(fmaf(row[xx], a, b), 0.f);
+                        acc = p.pool_max ? fmaxf(acc, rv) : acc + rv;
                     }
                 }
             }
-            v = acc / 27.0f;
+            v = p.pool_max ? acc : acc / 27.0f;
         } else {
             v = fmaxf(fmaf(xc[(int64_t)to * HW + (int64_t)y * p.W + x], a, b), 0.f);
         }
@@ -206,13 +209,25 @@ __global__ __launch_bounds__(256) void gn_relu_pool4_kernel(const GnApplyParams 
                 r[k] = (xx >= 0 && xx < p.W) ? fmaxf(fmaf(row[xx], a, b), 0.f) : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += (r[j] + r[j + 1]) + r[j + 2];
+            for (int j = 0; j < 4; ++j) acc[j] = p.pool_max ? fmaxf(acc[j], fmaxf(fmaxf(r[j], r[j + 1]), r[j + 2])) : acc[j] + ((r[j] + r[j + 1]) + r[j + 2]);
         }
     }
     float* o = p.out + (int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)y * p.out_ys + x0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (x0 + j < p.W) o[j] = acc[j] / 27.0f;
+        if (x0 + j < p.W) o[j] = p.pool_max ? acc[j] : acc[j] / 27.0f;
+}
+
+__global__ void gn_identity_stats_kernel(float* stats, int groups) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < groups) { stats[2 * g] = 0.f; stats[2 * g + 1] = 1.f; }
+}
+// NORMALIZATION_LAYER 'none' (nn.Identity): mean 0, rstd 1 -- with gamma 1, beta 0 the apply kernels then compute fma(x, 1, 0) = x
+int launch_gn_identity_stats(float* stats, int groups, hipStream_t s) {
+    SS_CHECK_ARG(stats && groups > 0, "gn_identity_stats: bad arguments");
+    hipLaunchKernelGGL(gn_identity_stats_kernel, dim3((unsigned)ceil_div(groups, 64)), dim3(64), 0, s, stats, groups);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
 }
 
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s) {
@@ -247,6 +262,8 @@ int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, 
     p.x = x; p.stats = stats; p.gamma = gamma; p.beta = beta;
     p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
     p.C = C; p.T = T; p.H = H; p.W = W; p.To = To; p.cpg = C / groups;
+    p.pool_max = pool == 2 ? 1 : 0;
+    SS_CHECK_ARG(pool >= 0 && pool <= 2, "gn_relu_pool: pool code %d (0 none, 1 average, 2 max)", pool);
     const int64_t total = (int64_t)C * To * H * W;
     const int64_t S = (int64_t)T * H * W;
     const bool small = S < (1ll << 31) && total < (1ll << 40);      // 32-bit offsets inside a channel

@@ -168,6 +168,9 @@ def ptr(t, dtype=None):
         return None
     assert t.is_cuda, "device tensor required"
     assert t.is_contiguous(), "contiguous tensor required"
+    # kernels are enqueued on the CURRENT device's current stream (``stream()``): a tensor of another device would be touched from
+    # the wrong device / an unordered stream -- wrap the call in ``torch.cuda.device(t.device)``
+    assert t.device.index == torch.cuda.current_device(), "tensor on %s but the current device is cuda:%d" % (t.device, torch.cuda.current_device())
     if dtype is not None:
         assert t.dtype == dtype, "expected %s, got %s" % (dtype, t.dtype)
     return C.c_void_p(t.data_ptr())

@@ -33,13 +33,17 @@ class SqueezeExpandTrunk(nn.Module):
         self.num_frames = cfg.INPUT.NUM_FRAMES if num_frames is None else num_frames
         if self.num_frames not in POOL_TABLE:
             raise NotImplementedError("clip length %r" % (self.num_frames,))
-        if PoolType is not nn.AvgPool3d:
-            raise NotImplementedError("HIP decoder implements POOL_TYPE 'avg' (AvgPool3d) only")
+        if PoolType not in (nn.AvgPool3d, nn.MaxPool3d):      # the two entries of POOL_TYPE (model_builder.py:29-33)
+            raise NotImplementedError("HIP decoder implements POOL_TYPE 'avg' (AvgPool3d) and 'max' (MaxPool3d)")
+        self.pool_code = 2 if PoolType is nn.MaxPool3d else 1
         self.pool_flags, self.t_scales = POOL_TABLE[self.num_frames], TSCALE_TABLE[self.num_frames]
         probe = NormType(inter_channels[0])
-        if not isinstance(probe, nn.GroupNorm):
-            raise NotImplementedError("HIP decoder implements NORMALIZATION_LAYER 'gn' (GroupNorm) only")
-        self.gn_groups, self.gn_eps = probe.num_groups, probe.eps
+        if isinstance(probe, nn.GroupNorm):
+            self.gn_groups, self.gn_eps = probe.num_groups, probe.eps
+        elif isinstance(probe, nn.Identity):                 # NORMALIZATION_LAYER 'none'
+            self.gn_groups, self.gn_eps = 0, 0.0
+        else:
+            raise NotImplementedError("HIP decoder implements NORMALIZATION_LAYER 'gn' (GroupNorm) and 'none' (Identity)")
         self.in_channels, self.inter_channels = in_channels, list(inter_channels)
 
         def pools(n):
@@ -85,8 +89,12 @@ class SqueezeExpandTrunk(nn.Module):
                 conv, gn = getattr(self, blk)[idx], getattr(self, blk)[idx + 1]
                 conv_w.append(hip.pack_conv_weight_any(conv.weight.detach().float(), self.precision))
                 conv_b.append(conv.bias.detach().float().contiguous())
-                gn_w.append(gn.weight.detach().float().contiguous())
-                gn_b.append(gn.bias.detach().float().contiguous())
+                if self.gn_groups:
+                    gn_w.append(gn.weight.detach().float().contiguous())
+                    gn_b.append(gn.bias.detach().float().contiguous())
+                else:                                        # no normalisation layer: scale 1, shift 0
+                    gn_w.append(torch.ones(conv.out_channels, dtype=torch.float32, device=dev))
+                    gn_b.append(torch.zeros(conv.out_channels, dtype=torch.float32, device=dev))
             fuse = [hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8, self.conv_4)]
             hw, hb, act, axes = self._head_spec()
             c.clear()
@@ -104,7 +112,7 @@ class SqueezeExpandTrunk(nn.Module):
         d.T, d.H4, d.W4 = T, H4, W4
         d.gn_groups, d.gn_eps = self.gn_groups, self.gn_eps
         for i in range(3):
-            d.pool[i], d.t_scale[i] = self.pool_flags[i], self.t_scales[i]
+            d.pool[i], d.t_scale[i] = self.pool_flags[i] * self.pool_code, self.t_scales[i]
         d.n_out = len(act)
         return d
 
@@ -134,7 +142,7 @@ class SqueezeExpandTrunk(nn.Module):
         c = self._packed()
         act = list(c["act"]) if act_override is None else list(act_override)
         d = self._desc(T, H4, W4, layout, act)
-        for o in range(d.n_out if d.n_out <= 8 else 0):      # wide linear heads (n_out % 32 == 0) carry no activation table
+        for o in range(d.n_out if d.n_out <= 10 else 0):     # wide linear heads (n_out % 32 == 0) carry no activation table
             d.act[o], d.grid_axis[o] = act[o], c["axes"][o]
         d.input_layout = layout
         d.concurrency = int(self.concurrency)

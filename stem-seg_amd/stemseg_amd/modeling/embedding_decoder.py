@@ -38,9 +38,9 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
             self.conv_seediness = nn.Conv3d(c4, 1, kernel_size=1, padding=0, bias=False)
             self.seediness_channels = 1
         n_head = n_emb + self.variance_channels + self.seediness_channels
-        if n_head > 8:
+        if n_head > 10:
             raise NotImplementedError("embedding head with %d output channels (mode '%s', EMBEDDING_SIZE %d%s): the fused HIP "
-                                      "heads kernel emits at most 8 (every preset of the reference needs <= 7)"
+                                      "heads kernel emits at most 10 (the widest mode embedding_utils admits, xytff + seediness, needs 9)"
                                       % (n_head, experimental_dims, embedding_size, ", seediness" if seediness_output else ""))
         self.tanh_activation = tanh_activation
         self.register_buffer("time_scale", torch.tensor(1.0, dtype=torch.float32))

@@ -44,6 +44,18 @@ class InferenceOnlyModel(nn.Module):
         raise NotImplementedError("training is outside the MI355X hot path (SURVEY.md section 2); use InferenceModel")
 
 
+# model_builder.py:29-33 (POOLER_REGISTRY / NORM_REGISTRY of the reference)
+_POOLERS = {"avg": nn.AvgPool3d, "max": nn.MaxPool3d}
+
+
+def _norm(kind, groups):
+    if kind == "gn":
+        return lambda c: nn.GroupNorm(groups, c)
+    if kind == "none":
+        return lambda c: nn.Identity()
+    raise ValueError("NORMALIZATION_LAYER '%s' (gn | none)" % kind)
+
+
 def build_model(restore_pretrained_backbone_wts=False, logger=None):
     """backbone + heads from the global cfg (model_builder.py:247-369 minus losses / pretrained-weight restore)."""
     _config.refresh()
@@ -52,24 +64,22 @@ def build_model(restore_pretrained_backbone_wts=False, logger=None):
     m = InferenceOnlyModel()
     m.backbone = BACKBONE_REGISTRY[cfg.MODEL.BACKBONE.TYPE](cfg)
     e = cfg.MODEL.EMBEDDINGS
-    norm = lambda c: nn.GroupNorm(e.GN_NUM_GROUPS, c)  # noqa: E731
-    assert e.NORMALIZATION_LAYER == "gn" and e.POOL_TYPE == "avg"
+    norm = _norm(e.NORMALIZATION_LAYER, e.GN_NUM_GROUPS)
     m.embedding_head = EMBEDDING_HEAD_REGISTRY[e.HEAD_TYPE](
         m.backbone.out_channels, e.INTER_CHANNELS, e.EMBEDDING_SIZE, tanh_activation=e.TANH_ACTIVATION,
         seediness_output=not cfg.MODEL.USE_SEEDINESS_HEAD, experimental_dims=cfg.MODEL.EMBEDDING_DIM_MODE,
-        PoolType=nn.AvgPool3d, NormType=norm)
+        PoolType=_POOLERS[e.POOL_TYPE], NormType=norm)
     m.seediness_head = None
     if cfg.MODEL.USE_SEEDINESS_HEAD:
         s = cfg.MODEL.SEEDINESS
         m.seediness_head = SEEDINESS_HEAD_REGISTRY[s.HEAD_TYPE](
-            m.backbone.out_channels, s.INTER_CHANNELS, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(s.GN_NUM_GROUPS, c))
+            m.backbone.out_channels, s.INTER_CHANNELS, PoolType=_POOLERS[s.POOL_TYPE], NormType=_norm(s.NORMALIZATION_LAYER, s.GN_NUM_GROUPS))
     m.semseg_head = None
     if cfg.MODEL.USE_SEMSEG_HEAD:
         g = cfg.MODEL.SEMSEG
-        assert g.NORMALIZATION_LAYER == "gn" and g.POOL_TYPE == "avg"
         m.semseg_head = SEMSEG_HEAD_REGISTRY[g.HEAD_TYPE](
             m.backbone.out_channels, cfg.INPUT.NUM_CLASSES, inter_channels=g.INTER_CHANNELS, feature_scales=g.FEATURE_SCALE,
-            foreground_channel=g.FOREGROUND_CHANNEL, PoolType=nn.AvgPool3d, NormType=lambda c: nn.GroupNorm(g.GN_NUM_GROUPS, c))
+            foreground_channel=g.FOREGROUND_CHANNEL, PoolType=_POOLERS[g.POOL_TYPE], NormType=_norm(g.NORMALIZATION_LAYER, g.GN_NUM_GROUPS))
         m.semseg_feature_map_scale = list(g.FEATURE_SCALE)
     m.embedding_head_feature_map_scale = list(e.SCALE)
     m.seediness_head_feature_map_scale = list(cfg.MODEL.SEEDINESS.FEATURE_SCALE)

@@ -96,8 +96,19 @@ class ClipPipeline(object):
         out = [None] * len(clips)
         T = len(clips[0])
         stride = clips[1][0] - clips[0][0] if len(clips) > 1 else T
-        windows = bool(share_overlap) and 0 < stride < T and all(
-            list(c) == list(range(clips[0][0] + i * stride, clips[0][0] + i * stride + T)) for i, c in enumerate(clips))
+        # windows = the longest on-stride prefix of the clips (get_subsequence_frames appends an off-stride tail clip whenever
+        # (F - T) % (T - overlap) != 0: it is embedded on its own, the prefix still shares the trunk)
+        n_win = 0
+        if bool(share_overlap) and 0 < stride < T:
+            while n_win < len(clips) and list(clips[n_win]) == list(range(clips[0][0] + n_win * stride, clips[0][0] + n_win * stride + T)):
+                n_win += 1
+        if n_win < 2:
+            n_win = 0
+        if 0 < n_win < len(clips):
+            head = self.embed_many(frames, clips[:n_win], batch, lanes, use_graph, share_overlap)
+            tail = self.embed_many(frames, clips[n_win:], batch, lanes, use_graph, False)
+            return head + tail
+        windows = n_win == len(clips) and n_win > 0
         groups = [list(range(i, min(i + batch, len(clips)))) for i in range(0, len(clips), batch)]
 
         def pass_frames(g):                                 # frame indices of one encoder pass

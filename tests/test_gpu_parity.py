@@ -442,6 +442,35 @@ def test_embedding_decoder_vs_golden_and_oracle(hip, golden, T):
         assert np.array_equal(out2[:nE], out[:nE])
 
 
+@pytest.mark.parametrize("variant", [("xytff", 5, True, "avg", "gn"), ("xyfff", 5, True, "max", "gn"), ("xytff", 5, True, "max", "none"), ("xyff", 4, False, "avg", "none")])
+def test_embedding_decoder_wide_heads_max_pool_no_norm_vs_oracle(hip, variant):
+    """Everything model_builder.py:29-33 and embedding_utils.py:4-25 admit beyond the presets: 9-channel heads (xytff + seediness:
+    5 embedding + 3 variance + 1), POOL_TYPE 'max' (nn.MaxPool3d) and NORMALIZATION_LAYER 'none' (nn.Identity), vs the oracle's
+    torch-CPU composition of the same modules."""
+    from stemseg_amd.modeling.embedding_decoder import SqueezingExpandDecoder as Emb
+    mode, E, seed_out, pool, norm = variant
+    T, h32, w32 = 8, 2, 3
+    Pool = torch.nn.AvgPool3d if pool == "avg" else torch.nn.MaxPool3d
+    Norm = _gn if norm == "gn" else (lambda c: torch.nn.Identity())
+    m = Emb(256, [256, 256, 128, 128], E, True, seed_out, mode, PoolType=Pool, NormType=Norm, num_frames=T)
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in m.state_dict().items()], 77, prefix="embedding_head.")
+    if norm == "none":            # no normalisation: keep the activations of seven stacked convs in range
+        sd = {k: (np.asarray(v) * (0.35 if k.endswith(".weight") and np.asarray(v).ndim == 5 and np.asarray(v).shape[-1] == 3 else 1.0)).astype(np.float32) for k, v in sd.items()}
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(m.state_dict()[k].shape) for k, v in sd.items()})
+    m = m.cuda().eval()
+    feats = synth.synth_features(T, h32, w32, seed=78)
+    out = m([dev(f)[None] for f in feats])[0].cpu().numpy()
+    odec.VARIANT.update(pool=pool, norm=norm)
+    try:
+        ref = odec.embedding_decoder(feats, sd, mode).numpy()
+    finally:
+        odec.VARIANT.update(pool="avg", norm="gn")
+    n_emb = odec.nb_embedding_dims(mode)
+    assert out.shape == ref.shape and out.shape[0] == n_emb + (E - odec.nb_free_dims(mode)) + int(seed_out)
+    sc = np.maximum(1.0, np.abs(ref))
+    assert report("emb decoder %s pool=%s norm=%s (%d channels)" % (mode, pool, norm, out.shape[0]), out / sc, ref / sc) <= 1e-3
+
+
 @pytest.mark.parametrize("T", [8, 16, 4, 2, 24])
 def test_seediness_decoder_vs_golden(hip, golden, T):
     from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
@@ -1246,6 +1275,15 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
             scale = np.maximum(1.0, np.abs(r_))                      # (bandwidth channels are exp(.) * 10: compare relatively)
             assert report("embed_many clip %d vs per-clip (rel)" % i, g_ / scale, r_ / scale) <= 1e-5
             assert torch.equal(got[i], again[i]) and torch.equal(got[i], eager[i])
+        # a sequence whose length leaves an OFF-STRIDE tail clip (22 frames: windows 0, 4, 8, 12 + the tail 14..21, what
+        # get_subsequence_frames cuts when (F - T) % (T - overlap) != 0): the on-stride prefix still shares the trunk
+        clips2 = [list(range(s0, s0 + 8)) for s0 in (0, 4, 8, 12)] + [list(range(14, 22))]
+        ref2 = [torch.cat(pipe.embed(frames[c].contiguous()), 0).clone() for c in clips2]
+        got2 = pipe.embed_many(frames, clips2, batch=2, lanes=2)
+        torch.cuda.synchronize()
+        for i in range(len(clips2)):
+            sc = np.maximum(1.0, np.abs(ref2[i].cpu().numpy()))
+            assert float(np.abs((got2[i] - ref2[i]).cpu().numpy() / sc).max()) <= 1e-5, "tail-clip sequence, clip %d" % i
     finally:
         config.load_preset("defaults")
 
