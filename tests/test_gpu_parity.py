@@ -449,7 +449,7 @@ def test_embedding_decoder_wide_heads_max_pool_no_norm_vs_oracle(hip, variant):
     torch-CPU composition of the same modules."""
     from stemseg_amd.modeling.embedding_decoder import SqueezingExpandDecoder as Emb
     mode, E, seed_out, pool, norm = variant
-    T, h32, w32 = 8, 2, 3
+    T, h32, w32 = 8, 3, 4
     Pool = torch.nn.AvgPool3d if pool == "avg" else torch.nn.MaxPool3d
     Norm = _gn if norm == "gn" else (lambda c: torch.nn.Identity())
     m = Emb(256, [256, 256, 128, 128], E, True, seed_out, mode, PoolType=Pool, NormType=Norm, num_frames=T)
@@ -462,7 +462,7 @@ def test_embedding_decoder_wide_heads_max_pool_no_norm_vs_oracle(hip, variant):
     out = m([dev(f)[None] for f in feats])[0].cpu().numpy()
     odec.VARIANT.update(pool=pool, norm=norm)
     try:
-        ref = odec.embedding_decoder(feats, sd, mode).numpy()
+        ref = odec.embedding_decoder(feats, {"embedding_head." + k: v for k, v in sd.items()}, mode).numpy()
     finally:
         odec.VARIANT.update(pool="avg", norm="gn")
     n_emb = odec.nb_embedding_dims(mode)
