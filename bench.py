@@ -548,12 +548,13 @@ def main():
                             "us_per_clip": round(1e3 * m_ * per_clip, 1), "gb_per_s": round(by / m_ / 1e6, 1),
                             "frac_of_hbm_peak": round(by / m_ / 1e6 / PEAK_HBM_GBPS, 3)})
         traffic, traffic_note = None, "not collected in this process: PMC counters need their own rocprofv3 --pmc passes (tools/gpu_round.sh pmc)"
-        if args.precision == "f32" and os.path.exists(TRAFFIC_FILE):
+        tfile = TRAFFIC_FILE if args.precision == "f32" else TRAFFIC_FILE.replace("_latest", "_%s_latest" % args.precision)
+        if os.path.exists(tfile):
             try:
-                tj = json.load(open(TRAFFIC_FILE))
-                traffic, traffic_note = tj["gb_per_launch_group"], "offline, %s: %s" % (os.path.relpath(TRAFFIC_FILE, ROOT), tj["note"])
+                tj = json.load(open(tfile))
+                traffic, traffic_note = tj["gb_per_launch_group"], "offline, %s: %s" % (os.path.relpath(tfile, ROOT), tj["note"])
             except Exception as e:  # noqa: BLE001
-                traffic_note = "could not read %s: %r" % (TRAFFIC_FILE, e)
+                traffic_note = "could not read %s: %r" % (tfile, e)
         res = {
             "metric": "clips/sec (T=8, 480p) embed+cluster" if args.workload == "davis" else "clips/sec (T=8, %dx%d) embed+cluster" % (H, W),
             "value": round(clips_total / dt, 4), "unit": "clips/s",

@@ -12,6 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+prec = os.environ.get("PREC", "f32")
+latest = "pmc_conv3d_block4x_latest.json" if prec == "f32" else "pmc_conv3d_block4x_%s_latest.json" % prec
 
 
 def counters(tag):
@@ -32,7 +34,7 @@ def counters(tag):
 fetch, write = counters("FETCH_SIZE").get("FETCH_SIZE", {}), counters("WRITE_SIZE").get("WRITE_SIZE", {})
 sq = counters("SQ_WAVES")
 sq.update(counters("SQ_LDS_BANK"))
-lines = ["# rocprofv3 --pmc passes on tools/pmc_conv.py (block_4x conv of BASELINE configs[1]: Cin 256 -> Cout 128 over [8,120,216]), %d convs per pass" % reps]
+lines = ["# rocprofv3 --pmc passes on tools/pmc_conv.py (block_4x conv of BASELINE configs[1]: Cin 256 -> Cout 128 over [8,120,216]), %d convs per pass, precision %s" % (reps, prec)]
 res = {}
 if fetch and write:
     f = {k: v[0] * 1024 * 2 / reps for k, v in fetch.items()}      # KB -> bytes, x2 gfx950 correction, per conv
@@ -59,5 +61,5 @@ lines += [l.rstrip() for l in open(os.path.join(ROOT, "gpurun_out", "pmc_FETCH_S
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 open(os.path.join(ROOT, "gpurun_out", "%s_pmc_conv3d_block4x.txt" % rnd), "w").write("\n".join(lines) + "\n")
 if res:
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "pmc_conv3d_block4x_latest.json"), "w"))
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", latest), "w"))
 print("\n".join(lines))
