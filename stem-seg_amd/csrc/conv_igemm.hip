@@ -1157,6 +1157,7 @@ using Y2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, false, 2>;   //  64 co x (8 row
 using Y1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, 2>;  // 128 co x 256 voxels
 using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, 2>; // 128 co x 128 voxels
 using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, 2>;  //  64 co x 256 voxels
+using Y1Wide = ConvCfg<1, 1, 1, 32, 4, 2, 2, 4, 8, false, 2>; // 256 co x 256 voxels, 512 threads: an input element is split once per 256 output channels
 
 // sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
 // MFMA peak)
@@ -1448,6 +1449,11 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
             return launch_cfg<Y2Small>(p, s, scratch, scratch_floats);
         }
         if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats);
+        if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats);
+        // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
+        // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
+        if ((tile_cfg <= 0 || tile_cfg > 3) && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(p.Cout, p.T, p.H, p.W) >= 128)
+            return launch_cfg<Y1Wide>(p, s, nullptr, 0);
         if (cfg <= 0 || cfg > 2) {
             cfg = (num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
             if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
