@@ -566,7 +566,8 @@ def main():
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
                        "switches": library_switches()},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s"}[args.precision],
-                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s" if args.precision == "f32" else "TFLOP/s (fp32-equivalent: conv FLOPs / time; the MFMA pipe issues %d bf16 products per fp32 product)" % (3 if args.precision == "bf16x3" else 6),
+                         "frac": round(ach / peak, 4), "achieved_vs_fp32_input_mfma_peak": round(ach / PEAK_MFMA_F32_TFLOPS, 3),
                          "traffic": traffic, "traffic_note": traffic_note,
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "how": "hipEvent pairs (in-library profiler, on the launch's own stream) around every tagged launch over %d eager "
