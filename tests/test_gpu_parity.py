@@ -1288,6 +1288,65 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
         config.load_preset("defaults")
 
 
+@pytest.mark.parametrize("preset", ["ytvis", "kittimots"])
+def test_clip_pipeline_step_on_semseg_presets(hip, preset):
+    """ClipPipeline.step on the presets with a semseg head (the bench's unit of work for BASELINE configs[2] / [4]): third decoder
+    -> class logits (x resize_scale) -> fg = fg probability > 0.5 (semseg_fg_clip == accumulate + get_semseg_masks + threshold for
+    one independent clip); YouTube-VIS: --resize_embeddings, head outputs x4 and clustering at full resolution.  Every stage vs
+    the per-stage entry points, labels vs the oracle's clusterer on the same maps (exact)."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset(preset)
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        r = 4 if preset == "ytvis" else 1
+        model = InferenceModel(resize_scale=float(r))
+        sd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 61))).reshape(v.shape) for k, v in sd.items()}
+        new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 25.0
+        model._model.load_state_dict(new)
+        pipe = ClipPipeline(model)
+        T, H, W = 8, 96, 160
+        frames = dev(synth.synth_frames(T, H, W, seed=61).astype(np.float32).transpose(0, 3, 1, 2) - 110.0)
+        out = pipe.step(frames)
+        torch.cuda.synchronize()
+        # stage by stage through the per-stage entry points
+        emb, bw, seed = model.embed_frames(frames)
+        logits = model.semseg_logits_clip(T, H, W, emb.device)
+        assert torch.equal(out["semseg_logits"], logits)
+        acc = torch.zeros((T, logits.shape[0]) + tuple(logits.shape[2:]), device="cuda")
+        hip.semseg_accumulate(acc, logits.contiguous(), list(range(T)))
+        fg_p, _ = hip.semseg_masks(acc, torch.ones(T, device="cuda"), None)
+        fg_ref = torch.stack([hip.fg_mask(p_.contiguous(), 1.0, 0.5) for p_ in fg_p], 0)
+        assert torch.equal(out["fg"], fg_ref) and float(fg_ref.float().mean()) > 0.02
+        if r != 1:
+            emb, bw, seed = [hip.upsample_trilinear(x.contiguous(), 1, r, r) for x in (emb, bw, seed)]
+        assert tuple(out["emb"].shape[-2:]) == (H // 4 * r, W // 4 * r)
+        assert torch.equal(out["emb"], emb) and torch.equal(out["bw"], bw) and torch.equal(out["seed"], seed)
+        # clustering vs the oracle on the same maps
+        c = config.cfg.CLUSTERING
+        nfree = 2 if preset == "ytvis" else 0
+        e_, b_, s_, cnt = opipe.gather_fg(emb.cpu().numpy(), bw.cpu().numpy(), seed.cpu().numpy(), fg_ref.cpu().numpy())
+        ref, ref_meta = sequential_clustering(e_, b_, s_, label_start=1, min_seediness=c.MIN_SEEDINESS_PROB,
+                                              free_dim_stds=[0.3, 0.3][:nfree], return_probs=True)
+        n = int(out["frame_offsets"].cpu()[-1])
+        meta = hip.read_cluster_meta(out["meta"])
+        got = out["labels"][:n].cpu().numpy()
+        assert n == ref.shape[0] and meta.K == len(ref_meta["instance_labels"])
+        bad = np.flatnonzero(got != ref)
+        print("[parity] step %s: %d fg points, K = %d, %d labels differ" % (preset, n, meta.K, bad.size))
+        if bad.size:
+            P = np.stack(ref_meta["instance_probs"])
+            near = (np.abs(P - 0.5) < 2e-6).any(0) | (np.abs(P - 0.3) < 2e-6).any(0)
+            assert near[bad].all()
+        # the batched form (two clips through one encoder pass) gives the same per clip
+        outs = pipe.step_batch(torch.cat([frames, frames.flip(0)], 0), 2)
+        assert torch.equal(outs[0]["fg"], out["fg"]) and float((outs[0]["emb"] - out["emb"]).abs().max()) <= 1e-5
+    finally:
+        config.load_preset("defaults")
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("size", [(96, 160), (256, 448)])
 def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
