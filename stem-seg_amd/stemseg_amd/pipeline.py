@@ -441,7 +441,7 @@ class TorchComm(object):
         self.dist.all_gather(outs, t.contiguous(), group=self.group)
 
     def all_gather_into_tensor(self, out, t):
-        if t.is_cuda:
+        if t.is_cuda and self.dist.get_backend(self.group) == "nccl":
             self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         else:                                                          # (gloo: list form)
             parts = [torch.empty_like(t) for _ in range(self.world)]
