@@ -335,6 +335,17 @@ PRECISION_DTYPE = {"f32": "f32", "bf16x3": "f32 operands as bf16x3 split (3 bf16
                    "bf16x6": "f32 (every operand split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate: fp32-level results)"}
 
 
+PRECISION_NOTE = {
+    "f32": "v_mfma_f32_32x32x2_f32 on fp32 operands",
+    "bf16x3": "opt-in: two bf16 terms per operand, three products (~1e-4 on the maps; labels not identical on every input)",
+    "bf16x6": "every fp32 operand split EXACTLY into three bf16 terms (24 significand bits), the six products of weight >= 2^-16 on "
+              "v_mfma_f32_32x32x16_bf16, fp32 accumulation; the dropped products are <= 2^-23 |a*b|.  Evidence that this is fp32-level arithmetic, "
+              "not a reduced precision: max error vs an fp64 convolution = 0.78-1.56x that of the fp32-input MFMA kernel on every kernel class / "
+              "tile / epilogue (tests/test_gpu_bf16x6.py); labels identical to the reference's own CPU results on its flows (tests/test_gpu_parity.py) "
+              "and to the CPU oracle at full size in THIS run (cpu_baseline.parity_vs_hip_path); --precision f32 runs the fp32-input MFMA kernels",
+}
+
+
 def library_switches():
     """The A/B switches the library reads from the environment (csrc/conv_igemm.hip), as set for this run."""
     return {k: os.environ.get(k, "default") for k in ("STEMSEG_K3_DB", "STEMSEG_FLAT", "STEMSEG_PLANNER", "STEMSEG_T_FASTEST", "STEMSEG_GLDS", "STEMSEG_GN_EPILOGUE", "STEMSEG_TILE224", "STEMSEG_AUTOSPLIT")}
@@ -570,6 +581,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WL["name"], "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
+                       "precision": {"mode": args.precision, "note": PRECISION_NOTE[args.precision]},
                        "switches": library_switches()},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s"}[args.precision],
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s" if args.precision == "f32" else "TFLOP/s (fp32-equivalent: conv FLOPs / time; the MFMA pipe issues %d bf16 products per fp32 product)" % (3 if args.precision == "bf16x3" else 6),
