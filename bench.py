@@ -332,7 +332,12 @@ def stub_main(args, rank, world, use_dist):
 
 
 PRECISION_DTYPE = {"f32": "f32", "bf16x3": "f32 operands as bf16x3 split (3 bf16 MFMAs per product, fp32 accumulate; ~1e-4)",
-                   "bf16x6": "f32 (every operand split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate: fp32-level results)"}
+                   "bf16x6": "f32 (every operand split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate: fp32-level results)",
+                   "f16x3": "f32 (every operand scaled by a power of two and split into 2 fp16 terms = 22 significand bits, 3 fp16 MFMAs per product, "
+                            "fp32 accumulate: fp32-level results)"}
+
+
+PRODUCTS = {"bf16x3": 3.0, "bf16x6": 6.0, "f16x3": 3.0}
 
 
 PRECISION_NOTE = {
@@ -343,6 +348,14 @@ PRECISION_NOTE = {
               "not a reduced precision: max error vs an fp64 convolution = 0.78-1.56x that of the fp32-input MFMA kernel on every kernel class / "
               "tile / epilogue (tests/test_gpu_bf16x6.py); labels identical to the reference's own CPU results on its flows (tests/test_gpu_parity.py) "
               "and to the CPU oracle at full size in THIS run (cpu_baseline.parity_vs_hip_path); --precision f32 runs the fp32-input MFMA kernels",
+    "f16x3": "every fp32 operand is scaled by a power of two (activations 2^-2; a layer's weights so that the largest lands in [2^13, 2^14)) and "
+             "split into two fp16 terms (22 significand bits; the low activation term is stored as lo * 2^11 against a hi * 2^-11 weight plane, so "
+             "all stored terms are normal fp16 numbers for 2.4e-4 <= |a| < 2.6e5); lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 "
+             "accumulation, accumulators scaled back exactly.  The dropped lo*lo product and the split remainder are <= 2^-22 |a*b|: measured "
+             "against an fp64 convolution the error stays at the fp32-input MFMA kernel's own level on every kernel class / tile / epilogue and "
+             "over activation magnitudes of 1e-4 ... 2e4 (tests/test_gpu_bf16x6.py, both modes); labels are checked against the reference's CPU results (tests/test_gpu_parity.py) and the "
+             "CPU oracle at full size in THIS run (cpu_baseline.parity_vs_hip_path).  Half the matrix work of bf16x6; |activation| >= 2.6e5 "
+             "overflows to non-finite outputs -- --precision bf16x6 has fp32's full range",
 }
 
 
@@ -365,7 +378,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="MFMA mode of every convolution: bf16x6 (default, the library's default) = exact three-term bf16 split of every fp32 "
                          "operand, six products, fp32 accumulate (fp32-level results); f32 = fp32-input MFMA; bf16x3 = two-term split (~1e-4)")
     ap.add_argument("--no-graph", action="store_true",
@@ -539,7 +552,7 @@ def main():
     if rank == 0:
         clips_total = args.steps * world * NC
         # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes)
-        peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / (3.0 if args.precision == "bf16x3" else 6.0)
+        peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / PRODUCTS[args.precision]
         k3 = [prof[t] for t in hip.PROFILE_CONV_TAGS["conv3x3x3"] if t in prof]
         ms = sum(p[0] for p in k3)
         fl = sum(p[1] for p in k3)
@@ -583,8 +596,8 @@ def main():
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
                        "precision": {"mode": args.precision, "note": PRECISION_NOTE[args.precision]},
                        "switches": library_switches()},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s"}[args.precision],
-                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s" if args.precision == "f32" else "TFLOP/s (fp32-equivalent: conv FLOPs / time; the MFMA pipe issues %d bf16 products per fp32 product)" % (3 if args.precision == "bf16x3" else 6),
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s", "f16x3": "f16x3 on MFMA 32x32x16 f16; peak = 2500/3 fp32-equivalent TFLOP/s"}[args.precision],
+                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s" if args.precision == "f32" else "TFLOP/s (fp32-equivalent: conv FLOPs / time; the MFMA pipe issues %d 16-bit products per fp32 product)" % PRODUCTS.get(args.precision, 1),
                          "frac": round(ach / peak, 4), "achieved_vs_fp32_input_mfma_peak": round(ach / PEAK_MFMA_F32_TFLOPS, 3),
                          "traffic": traffic, "traffic_note": traffic_note,
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),

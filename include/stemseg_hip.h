@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 3
+#define STEMSEG_HIP_ABI_VERSION 4
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -103,16 +103,30 @@ typedef struct StemsegConvEpilogue {
                                       (hi + mid + lo, 24 significand bits) and a*b is the sum of the six products of weight
                                       >= 2^-16 on the bf16 matrix cores, fp32 accumulation: the dropped products are <= 2^-23
                                       |a*b|, below the rounding of the fp32 accumulation itself -- fp32-level results at 2.7x
-                                      the fp32-MFMA rate; packed_w from stemseg_hip_pack_conv_weight_split(..., planes = 3) */
+                                      the fp32-MFMA rate; packed_w from stemseg_hip_pack_conv_weight_split(..., planes = 3).
+                                      STEMSEG_PRECISION_F16X3: both operands are scaled by a power of two (activations by 2^-2,
+                                      a layer's weights so that the largest lands in [2^13, 2^14)) and split into two fp16
+                                      terms (hi + lo, 22 significand bits); the low activation term is stored as lo * 2^11
+                                      and meets a hi * 2^-11 plane of the weights, so every stored term is a normal fp16
+                                      number for 2.4e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a + hi_w*lo_a + hi_w*hi_a on the fp16
+                                      matrix cores, fp32 accumulation, accumulators scaled back exactly: the dropped lo*lo
+                                      product and the split remainder are <= 2^-22 |a*b| -- measured below the rounding
+                                      spread of fp32 accumulation orders -- at HALF the matrix work of bf16x6.  |a| >= 2.6e5
+                                      overflows (inf in, non-finite out); packed_w from
+                                      stemseg_hip_pack_conv_weight_prec(..., STEMSEG_PRECISION_F16X3) */
 } StemsegConvEpilogue;
 #define STEMSEG_PRECISION_F32    0
 #define STEMSEG_PRECISION_BF16X3 1
 #define STEMSEG_PRECISION_BF16X6 2
+#define STEMSEG_PRECISION_F16X3  3
 int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t Cin, int32_t taps);
 int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
 /* planes = 2: the bf16x3 packing above; planes = 3: the bf16x6 packing (hi | mid | lo planes per k-group). */
 int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes);
 int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream);
+/* By precision code (1, 2: the packings above; 3: three fp16 planes of the scaled weights + a 16-byte scale record). */
+int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision);
+int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t precision, void* stream);
 /* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).
  * epilogue may be NULL (plain conv + bias). */
 int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w, const float* bias, const StemsegVolume* out,
@@ -190,7 +204,7 @@ typedef struct StemsegDecoderDesc {
                                     streams and the call returns without joining; the caller must enqueue
                                     stemseg_hip_decoder_join(concurrency, stream) before it consumes `out` or re-uses the
                                     inputs / workspace.  Lets a twin decoder be enqueued in between (both fill the chip). */
-    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 for every convolution of the decoder
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 | _F16X3 for every convolution of the decoder
                                     (weights in StemsegDecoderWeights must be packed for the same mode)                    */
 } StemsegDecoderDesc;
 
@@ -230,7 +244,7 @@ typedef struct StemsegEncoderDesc {
     int32_t blocks[4];           /* bottleneck blocks per stage: R-50 {3,4,6,3}, R-101 {3,4,23,3}       */
     int32_t T, H, W;             /* frames per call and padded frame size (multiples of 32)              */
     int32_t out_channels;        /* 256                                                                  */
-    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 | _F16X3 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
     int32_t n_clips;             /* >= 1: the T frames are n_clips consecutive clips of T / n_clips frames; each clip's four maps
                                     go to their own output volumes (frames are independent in the encoder, so several clips
                                     share one pass: layer3 / layer4 launches grow from 0.4 to n_clips x 0.4 waves of the chip) */

@@ -37,6 +37,16 @@
 #include <cstdlib>
 #include <type_traits>
 
+// f16x3: activations are split as fp16 terms of x * 2^-2 (see split3)
+#define STEMSEG_F16X3_ACT_SCALE 0.25f
+
+#ifndef SS_X6_WMODE_SMALLG
+#define SS_X6_WMODE_SMALLG 2
+#endif
+#ifndef SS_X6_SPREAD
+#define SS_X6_SPREAD 1
+#endif
+
 namespace stemseg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -106,8 +116,12 @@ struct ConvKParams {
 template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, int BF_ = 0, bool DB_ = false,
           int PMAX_ = 0, bool GL_ = false>
 struct ConvCfg {
-    static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ == 2, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
-    static constexpr int NPL = X6 ? 3 : 2;                              // bf16 planes per operand
+    // X6 = the split-staged path (operands split once, when a chunk is staged): BF_ 2 = bf16x6 (three bf16 planes, six products),
+    // BF_ 3 = f16x3 (two fp16 planes of the SCALED operand, three products)
+    static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ >= 2, F16 = BF_ == 3, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
+    static constexpr int NPL = BF_ >= 2 ? 3 : 2;                        // 16-bit planes of the weights (f16x3: hi, lo, hi * 2^-11)
+    static constexpr int NPX = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged input tile (f16x3: hi, lo * 2^11)
+    static constexpr int NPROD = BF_ == 2 ? 6 : 3;                      // MFMAs per (A fragment, B fragment) pair
     static constexpr int PMAX = PMAX_;
     static constexpr int KT = KT_, KH = KH_, KW = KW_, CK = CK_, MI = MI_, NI = NI_, WM = WM_, WN = WN_, COLS = COLS_;
     static constexpr int TAPS = KT * KH * KW;
@@ -122,7 +136,7 @@ struct ConvCfg {
     static constexpr int IN_CH_STRIDE = FLAT ? KT * FL : KT * RH * XP;
     static constexpr int IN_PAIR_STRIDE = KT * RH * XP;                 // X6: words of one channel pair of one plane
     static constexpr int IN_PLANE_STRIDE = (CK / 2) * IN_PAIR_STRIDE;   // X6: words of one bf16 plane
-    static constexpr int IN_FLOATS = X6 ? 3 * IN_PLANE_STRIDE : CK * IN_CH_STRIDE;
+    static constexpr int IN_FLOATS = X6 ? NPX * IN_PLANE_STRIDE : CK * IN_CH_STRIDE;
     // bf16x3 grouping: taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
     static constexpr int TPG = TAPS >= 27 ? 4 : (TAPS >= 9 ? 2 : 1);
     static constexpr int CPH = 8 / TPG;
@@ -131,6 +145,10 @@ struct ConvCfg {
     static constexpr int G = NTG * NCG;                                 // 16-wide k-groups per chunk
     static constexpr int W_FLOATS = BF ? NPL * G * 2 * MT * 4 : CK * TAPS * MT;   // bf16x3: [hi|lo][G][half][MT] x 16 B; x6: [G][hi|mid|lo][half][MT]
     static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
+    // X6 weight staging of tiles with few k-groups per chunk (1x1 taps; a phase's MFMA stream is shorter than a global load):
+    // 0 two phases, registers refilled per phase; 1 one phase, whole slab in registers; 2 two phases, one chunk of lookahead
+    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? SS_X6_WMODE_SMALLG : 0;
+    static constexpr bool SP = WMODE == 1, LA = WMODE == 2;
     static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
     static constexpr int LDS_FLOATS = BUF_FLOATS * (DB ? 2 : 1);
     static_assert(!BF || CK % (2 * CPH) == 0, "bf16x3: chunk must hold whole k-groups");
@@ -144,7 +162,7 @@ struct ConvCfg {
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
     // (the second __launch_bounds__ argument is waves per SIMD: an eight-wave x6 workgroup alone on its CU is two per SIMD as well)
     static constexpr int NWAVES = WM * WN;
-    static constexpr int MIN_WG = X6 ? (LDS_FLOATS * 4 * 2 <= 160 * 1024 ? NWAVES / 2 : NWAVES / 4)      // x6: workgroups per CU by LDS x waves per SIMD of one
+    static constexpr int MIN_WG = X6 ? (NWAVES >= 8 ? 2 : (LDS_FLOATS * 4 * 2 <= 160 * 1024 ? NWAVES / 2 : NWAVES / 4))   // split-staged tiles: two waves per SIMD (256 registers) where LDS allows
                                      : ((GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2));
 };
 
@@ -346,13 +364,25 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     // ---- x6 staging --------------------------------------------------------------------------------------
     // exact three-way split of an fp32 value into bf16 terms (both remainders are exact fp32 subtractions)
     auto split3 = [](const float x, unsigned int& h, unsigned int& m, unsigned int& l) {
-        const __bf16 bh = (__bf16)x;
-        const float r1 = x - (float)bh;
-        const __bf16 bm = (__bf16)r1;
-        const __bf16 bl = (__bf16)(r1 - (float)bm);
-        h = *reinterpret_cast<const unsigned short*>(&bh);
-        m = *reinterpret_cast<const unsigned short*>(&bm);
-        l = *reinterpret_cast<const unsigned short*>(&bl);
+        if constexpr (C::F16) {
+            // f16x3: x * 2^-2 = hi + lo with the low term stored as lo * 2^11 (the weights carry a hi * 2^-11 plane for it): both
+            // stored terms are normal fp16 numbers for 2.4e-4 <= |x| < 2.6e5 -- 22 significand bits there, a 2^-36 absolute floor
+            // below, inf above (and the result says so).  The accumulators are scaled back once, after the chunk loop.
+            const float xs = x * STEMSEG_F16X3_ACT_SCALE;
+            const _Float16 fh = (_Float16)xs;
+            const _Float16 fl = (_Float16)((xs - (float)fh) * 2048.0f);
+            h = *reinterpret_cast<const unsigned short*>(&fh);
+            m = *reinterpret_cast<const unsigned short*>(&fl);
+            l = 0;
+        } else {
+            const __bf16 bh = (__bf16)x;
+            const float r1 = x - (float)bh;
+            const __bf16 bm = (__bf16)r1;
+            const __bf16 bl = (__bf16)(r1 - (float)bm);
+            h = *reinterpret_cast<const unsigned short*>(&bh);
+            m = *reinterpret_cast<const unsigned short*>(&bm);
+            l = *reinterpret_cast<const unsigned short*>(&bl);
+        }
     };
     constexpr int NQ6 = (C::CK / 2) * C::KT * C::RH * XQ;               // 16-B pieces of a channel PAIR's rows: [pair][dt][row][xq]
     constexpr int IN_PT6 = C::X6 ? (NQ6 + C::NTHREADS - 1) / C::NTHREADS : 1;
@@ -377,7 +407,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     // the same for the register prefetch inside the chunk loop: the per-thread part of the address is loop invariant (a 32-bit
     // byte offset, computed once), the chunk only moves the uniform base
     unsigned int in6_voff[IN_PT6];
-    int in6_c[IN_PT6];
+    int in6_clim[IN_PT6];                                             // the piece (channel c0 + its pair's first channel) is inside the volume iff c0 < clim
+    const int64_t in6_room = (p.in_limit - 4 - tile_base) * 4;        // last valid 16-B piece, as a byte offset from in_tile
     if constexpr (C::X6) {
 #pragma unroll
         for (int k = 0; k < IN_PT6; ++k) {
@@ -385,16 +416,20 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             int c = 0;
             const int64_t rel = q < NQ6 ? in6_rel(q, c) : 0;
             in6_voff[k] = (unsigned int)(rel * 4);
-            in6_c[k] = q < NQ6 ? c : (1 << 30);                         // (beyond the tile: never loaded)
+            const int64_t slack = in6_room - rel * 4;                   // c0 * cs * 4 <= slack
+            const int64_t by_room = slack < 0 ? 0 : slack / (p.in_cs * 4) + 1;
+            in6_clim[k] = q < NQ6 ? (int)min((int64_t)(p.Cin - c), by_room) : 0;
         }
     }
-    const int64_t in6_room = (p.in_limit - 4 - tile_base) * 4;        // last valid 16-B piece, as a byte offset from in_tile
-    auto fetch_in6_fast = [&](int c0, int k, float4& v0, float4& v1) __attribute__((always_inline)) {
-        const int64_t ub = (int64_t)c0 * p.in_cs * 4;                  // uniform
-        const char* base = reinterpret_cast<const char*>(in_tile) + ub;
-        v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + in6_c[k] < p.Cin && ub + in6_voff[k] <= in6_room) v0 = *reinterpret_cast<const float4*>(base + in6_voff[k]);
-        if (c0 + in6_c[k] + 1 < p.Cin && ub + p.in_cs * 4 + in6_voff[k] <= in6_room) v1 = *reinterpret_cast<const float4*>(base + p.in_cs * 4 + in6_voff[k]);
+    // branch-free (the loads are issued between the MFMAs of the running chunk): a lane whose piece lies outside the volume reads
+    // the tile origin instead and in6_mask() zeroes it when it is written to LDS.  (Second channel of the pair: the same test one
+    // channel further.)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));          // (a native vector: struct copies of float4 stay memcpys)
+    auto fetch_in6_fast = [&](int c0, int k, f32x4& v0, f32x4& v1) __attribute__((always_inline)) {
+        const char* base = reinterpret_cast<const char*>(in_tile) + (int64_t)c0 * p.in_cs * 4;
+        const unsigned int cs4 = (unsigned int)(p.in_cs * 4);          // (a chunk of channels spans < 4 GB: in6_voff already relies on it)
+        v0 = *reinterpret_cast<const f32x4*>(base + (c0 < in6_clim[k] ? in6_voff[k] : 0u));
+        v1 = *reinterpret_cast<const f32x4*>(base + (c0 + 1 < in6_clim[k] ? in6_voff[k] + cs4 : 0u));
     };
     auto store_in6 = [&](int q, const float4& v0, const float4& v1) { // split both channels, interleave, three 16-B stores
         unsigned int h0, m0, l0, h1, m1, l1;
@@ -406,7 +441,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
         *reinterpret_cast<uint4*>(d) = ph;
         *reinterpret_cast<uint4*>(d + C::IN_PLANE_STRIDE) = pm;
-        *reinterpret_cast<uint4*>(d + 2 * C::IN_PLANE_STRIDE) = pl;
+        if constexpr (C::NPX == 3) *reinterpret_cast<uint4*>(d + 2 * C::IN_PLANE_STRIDE) = pl;
+    };
+    auto store_in6_masked = [&](int c0, int k, const f32x4& r0, const f32x4& r1) __attribute__((always_inline)) {
+        const bool ok0 = c0 < in6_clim[k], ok1 = c0 + 1 < in6_clim[k];
+        float4 v0, v1;
+        v0.x = ok0 ? r0.x : 0.f; v0.y = ok0 ? r0.y : 0.f; v0.z = ok0 ? r0.z : 0.f; v0.w = ok0 ? r0.w : 0.f;
+        v1.x = ok1 ? r1.x : 0.f; v1.y = ok1 ? r1.y : 0.f; v1.z = ok1 ? r1.z : 0.f; v1.w = ok1 ? r1.w : 0.f;
+        store_in6(tid + k * C::NTHREADS, v0, v1);
     };
     auto stage_in6_direct = [&](int c0) {                             // global -> split -> LDS without overlap (prologue, odd strides)
         if (p.vec4) {
@@ -435,13 +477,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q;
                 d[0] = h0 | (h1 << 16);
                 d[C::IN_PLANE_STRIDE] = m0 | (m1 << 16);
-                d[2 * C::IN_PLANE_STRIDE] = l0 | (l1 << 16);
+                if constexpr (C::NPX == 3) d[2 * C::IN_PLANE_STRIDE] = l0 | (l1 << 16);
             }
         }
     };
     // weight pieces of chunk c0's slab (packed order [grp][plane][half][co] = the LDS image); columns past Cout are fetched from
     // the row's last valid channel (they feed rows never stored)
-    constexpr int W_PT6 = C::X6 ? (NWQ_A + C::NTHREADS - 1) / C::NTHREADS : 1;      // phase A is the larger phase
+    // (two-phase tiles hold one phase at a time -- phase A is the larger; single-phase tiles hold the whole slab)
+    constexpr int W_PT6 = C::X6 ? ((C::SP ? NWQ6 : NWQ_A) + C::NTHREADS - 1) / C::NTHREADS : 1;
     // address = uniform base (chunk, first row of the piece run, co0) + ONE loop-invariant 32-bit per-thread offset: NTHREADS and the
     // phase boundaries are multiples of MT, so a thread keeps its column and walks the rows in steps of NTHREADS / MT
     static_assert(C::NTHREADS % C::MT == 0 && NWQ_A % C::MT == 0, "weight pieces: a thread keeps its column");
@@ -452,16 +495,21 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         return base + w6_voff;
     };
     // MFMA stream over the k-groups [g0, g1) of the staged chunk: 3 x MI b128 (A) + 3 x NI x 4 b32 (B) per 6 x MI x NI MFMAs
-    auto compute6 = [&](auto g0c, auto g1c) __attribute__((always_inline)) {
+    // side(step) is called once per (k-group, mi) step, in front of its MFMAs: the chunk loop hangs the next chunk's global loads
+    // there, a few per step (all of them at the top of the chunk back the texture path up and the waves stall AT ISSUE, with the
+    // matrix pipe idle behind them: measured 17% of a 1x1 layer)
+    auto compute6 = [&](auto g0c, auto g1c, auto&& side) __attribute__((always_inline)) {
         constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        constexpr int NPL = C::NPL, NPX = C::NPX;
+        typedef typename std::conditional<C::F16, _Float16, __bf16>::type h16;
+        typedef h16 h16x8 __attribute__((ext_vector_type(8)));
         const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
-        auto ld_b = [&](const int grp, bf16x8 (&b)[3][C::NI]) __attribute__((always_inline)) {
+        auto ld_b = [&](const int grp, h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
             const int cg = grp / C::NTG, tg = grp % C::NTG;
 #pragma unroll
             for (int ni = 0; ni < C::NI; ++ni)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NPX; ++pl) {
                     uint4 w4;
                     unsigned int* wv = reinterpret_cast<unsigned int*>(&w4);
 #pragma unroll
@@ -473,39 +521,50 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                         const int off = pl * C::IN_PLANE_STRIDE + (cg * C::CPH + chl / 2) * C::IN_PAIR_STRIDE + (dt * C::RH + dy) * C::XP + dx;
                         wv[wd] = b_ptr6[ni][off];
                     }
-                    b[pl][ni] = __builtin_bit_cast(bf16x8, w4);
+                    b[pl][ni] = __builtin_bit_cast(h16x8, w4);
                 }
         };
-        auto ld_a = [&](const int grp, const int mi, bf16x8 (&a)[3]) __attribute__((always_inline)) {
+        auto ld_a = [&](const int grp, const int mi, h16x8 (&a)[NPL]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                a[pl] = *reinterpret_cast<const bf16x8*>(a_base + (((grp * 3 + pl) * 2) * C::MT + mi * 32) * 16);
+            for (int pl = 0; pl < NPL; ++pl)
+                a[pl] = *reinterpret_cast<const h16x8*>(a_base + (((grp * NPL + pl) * 2) * C::MT + mi * 32) * 16);
         };
-        // smallest products first (planes: 0 hi, 1 mid, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
-        auto mm = [&](const int mi, const bf16x8 (&a)[3], const bf16x8 (&b)[3][C::NI]) __attribute__((always_inline)) {
+        // smallest products first (planes: 0 hi, 1 mid / lo, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
+        auto mm = [&](const int mi, const h16x8 (&a)[NPL], const h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
+            if constexpr (C::F16) {
+#define SS_X6_TERM(PA, PB)                                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
+                SS_X6_TERM(1, 0) SS_X6_TERM(2, 1) SS_X6_TERM(0, 0)      // lo_w * hi_x, (hi_w 2^-11) * (lo_x 2^11), hi_w * hi_x
+#undef SS_X6_TERM
+            } else {
 #define SS_X6_TERM(PA, PB)                                                                                                     \
     _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
-            SS_X6_TERM(2, 0) SS_X6_TERM(0, 2) SS_X6_TERM(1, 1) SS_X6_TERM(1, 0) SS_X6_TERM(0, 1) SS_X6_TERM(0, 0)
+                SS_X6_TERM(2, 0) SS_X6_TERM(0, 2) SS_X6_TERM(1, 1) SS_X6_TERM(1, 0) SS_X6_TERM(0, 1) SS_X6_TERM(0, 0)
 #undef SS_X6_TERM
+            }
         };
         // software pipeline over the (k-group, mi) steps: the A fragments of step s + 1 are requested from LDS BEFORE the
         // 6 x NI MFMAs of step s are issued (two register sets), a group's B fragments right after the previous group's last
         // MFMAs -- left to itself the compiler reads each fragment right in front of the MFMAs that consume it and waits there
         constexpr int NSTEP = (g1 - g0) * C::MI;
-        bf16x8 bfr[3][C::NI], a0[3], a1[3];
+        h16x8 bfr[NPX][C::NI], a0[NPL], a1[NPL];
+        side(-1);                                          // (tiles that do not spread issue everything here, ahead of the fragments)
         ld_b(g0, bfr);
         ld_a(g0, 0, a0);
 #pragma unroll
         for (int st = 0; st < NSTEP; st += 2) {
             const int grp = g0 + st / C::MI, mi = st % C::MI;
             if (st + 1 < NSTEP) ld_a(g0 + (st + 1) / C::MI, (st + 1) % C::MI, a1);
+            side(st);
             __builtin_amdgcn_sched_barrier(0);
             mm(mi, a0, bfr);
             __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < NSTEP) {
                 if ((st + 1) % C::MI == 0) ld_b(g0 + (st + 1) / C::MI, bfr);
                 if (st + 2 < NSTEP) ld_a(g0 + (st + 2) / C::MI, (st + 2) % C::MI, a0);
+                side(st + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mm((st + 1) % C::MI, a1, bfr);
                 __builtin_amdgcn_sched_barrier(0);
@@ -609,58 +668,151 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     const int c_begin = blockIdx.z * p.chunks_per_split * C::CK;
     const int c_end = min(p.Cin, c_begin + p.chunks_per_split * C::CK);
     if constexpr (C::X6) {
-        // The weight slab is staged in two k-group phases that ping-pong with the MFMA stream: while phase A computes, the next
-        // chunk's phase-A weights and input tile wait in registers; they are written when phase A's slots fall idle, the
-        // registers then carry the next chunk's phase-B weights under phase B's MFMA stream.  Three barriers per chunk, no
-        // global-memory latency exposed.
+        // Register-staged software pipeline: the next chunk's 16-B pieces are loaded into registers between the MFMAs of the running
+        // chunk and written to LDS when the slots they replace fall idle (three schedules below, picked per tile by C::WMODE).
         typedef std::integral_constant<int, 0> Q0;
         typedef std::integral_constant<int, NWQ_A> QA;
         typedef std::integral_constant<int, NWQ6> QE;
-        float4 rin[2 * IN_PT6];
-        typedef float f32x4 __attribute__((ext_vector_type(4)));      // (a native vector: struct copies of float4 stay memcpys)
+        f32x4 rin[2 * IN_PT6];
         f32x4 rw6[W_PT6];
-        auto fetch_w6 = [&](int c0, auto q0c, auto q1c) __attribute__((always_inline)) {                             // pieces [q0, q1) -> registers
+        f32x4 rw6b[W_PT6];                                            // (lookahead tiles: phase B's own register set)
+        auto fetch_w6_k = [&](int c0, auto q0c, auto q1c, f32x4 (&r)[W_PT6], const int k) __attribute__((always_inline)) {      // piece k of [q0, q1)
+            constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+            if ((k + 1) * C::NTHREADS <= q1 - q0 || q0 + tid + k * C::NTHREADS < q1) r[k] = *reinterpret_cast<const f32x4*>(w6_src(c0, q0 + k * C::NTHREADS));
+        };
+        auto store_w6 = [&](auto q0c, auto q1c, const f32x4 (&r)[W_PT6]) __attribute__((always_inline)) {
             constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
     #pragma unroll
-            for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if (q < q1) rw6[k] = *reinterpret_cast<const f32x4*>(w6_src(c0, q0 + k * C::NTHREADS)); }
+            for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if ((k + 1) * C::NTHREADS <= q1 - q0 || (k * C::NTHREADS < q1 - q0 && q < q1)) *reinterpret_cast<f32x4*>(w_lds + q * 4) = r[k]; }
         };
-        auto store_w6 = [&](auto q0c, auto q1c) __attribute__((always_inline)) {
-            constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
-    #pragma unroll
-            for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if (q < q1) *reinterpret_cast<f32x4*>(w_lds + q * 4) = rw6[k]; }
+        auto store_in6_all = [&](int c0) __attribute__((always_inline)) {
+            if (p.vec4) {
+#pragma unroll
+                for (int k = 0; k < IN_PT6; ++k) {
+                    const int q = tid + k * C::NTHREADS;
+                    if ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1]);
+                }
+            } else stage_in6_direct(c0);
         };
+        // side loads of one phase: items [0, NI_) are input-tile piece pairs, [NI_, NI_ + NW) weight pieces; spread over the phase's
+        // first SPREAD steps (everything must have landed when the phase ends, unless the tile looks a chunk ahead)
+        auto side_items = [&](const int st, auto nspread_c, auto n_in_c, auto n_w_c, auto&& f_in, auto&& f_w) __attribute__((always_inline)) {
+            constexpr int nspread = decltype(nspread_c)::value, n_in = decltype(n_in_c)::value, n_w = decltype(n_w_c)::value, n = n_in + n_w;
+            if (st >= nspread || st < 0) return;
+#pragma unroll
+            for (int i = 0; i < n; ++i)
+                if (i >= st * n / nspread && i < (st + 1) * n / nspread) { if (i < n_in) f_in(i); else f_w(i - n_in); }
+        };
+        constexpr int NSA = C::GA * C::MI, NSB = (C::G - C::GA) * C::MI, NSALL = C::G * C::MI;
+        constexpr int NPA = (NWQ_A + C::NTHREADS - 1) / C::NTHREADS, NPB = (NWQ6 - NWQ_A + C::NTHREADS - 1) / C::NTHREADS;
+        constexpr int NPALL = (NWQ6 + C::NTHREADS - 1) / C::NTHREADS;
+        constexpr bool SPRD = SS_X6_SPREAD && (C::WMODE != 0 || SS_X6_SPREAD > 1);     // (many-k-group tiles: no registers to spare inside the stream)
+        typedef std::integral_constant<int, C::GA> GAc;
+        typedef std::integral_constant<int, C::G> Gc;
         if (c_begin < c_end) {
             for (int q = tid; q < NWQ6; q += C::NTHREADS) *reinterpret_cast<float4*>(w_lds + q * 4) = *reinterpret_cast<const float4*>(w6_src(c_begin, q - tid));
             stage_in6_direct(c_begin);
         }
         __syncthreads();
-        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
-            const bool more = c0 + C::CK < c_end;
-            if (more) {
-                fetch_w6(c0 + C::CK, Q0{}, QA{});
-                if (p.vec4) {
-#pragma unroll
-                    for (int k = 0; k < IN_PT6; ++k) fetch_in6_fast(c0 + C::CK, k, rin[2 * k], rin[2 * k + 1]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMA stream
-            compute6(Q0{}, std::integral_constant<int, C::GA>{});
-            __syncthreads();                                   // phase A's slots are idle
-            if (more) {
-                store_w6(Q0{}, QA{});
-                fetch_w6(c0 + C::CK, QA{}, QE{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            compute6(std::integral_constant<int, C::GA>{}, std::integral_constant<int, C::G>{});
-            __syncthreads();                                   // everyone is done with phase B's slots and this chunk's input tile
-            if (more) {
-                store_w6(QA{}, QE{});
-                if (p.vec4) {
-#pragma unroll
-                    for (int k = 0; k < IN_PT6; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ6) store_in6(q, rin[2 * k], rin[2 * k + 1]); }
-                } else stage_in6_direct(c0 + C::CK);
+        // The chunk bodies are instantiated per (another chunk follows, two more follow) instead of testing it at run time: with the
+        // fetches and the stores under separate run-time `if`s the waitcnt pass cannot pair them up, believes loads into the staging
+        // registers may still be in flight at the loop head, and guards the first address computation that reuses one with an
+        // in-order vmcnt wait -- which then waits for the loads just issued in front of it.
+        typedef std::true_type Yes;
+        typedef std::false_type No;
+        if constexpr (C::SP) {
+            // few k-groups per chunk (1x1 taps): one phase; the whole next chunk (weights + input tile) gathers in registers under
+            // the chunk's MFMA stream.  Two barriers per chunk.
+            auto chunk = [&](const int c0, auto more_c) __attribute__((always_inline)) {
+                constexpr bool more = decltype(more_c)::value;
+                const int cn = c0 + C::CK;
+                compute6(Q0{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + 1) / 2 : 1>{}, std::integral_constant<int, IN_PT6>{}, std::integral_constant<int, NPALL>{},
+                                         [&](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); },
+                                         [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
+                });
                 __syncthreads();
+                if constexpr (more) {
+                    store_w6(Q0{}, QE{}, rw6);
+                    store_in6_all(cn);
+                    __syncthreads();
+                }
+            };
+            int c0 = c_begin;
+            for (; c0 + C::CK < c_end; c0 += C::CK) chunk(c0, Yes{});
+            if (c0 < c_end) chunk(c0, No{});
+        } else if constexpr (C::LA) {
+            // two phases as below, with the weights one more chunk ahead and a register set per phase: phase A's set is refilled
+            // (chunk + 2) under phase B, phase B's set and the input tile under phase A -- every global load has at least half a
+            // chunk of MFMA stream to land, and phase A's LDS writes still hide under phase B.
+            if (c_begin + C::CK < c_end) {
+#pragma unroll
+                for (int k = 0; k < NPA; ++k) fetch_w6_k(c_begin + C::CK, Q0{}, QA{}, rw6, k);
             }
+            auto chunk = [&](const int c0, auto more_c, auto more2_c) __attribute__((always_inline)) {
+                constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+                const int cn = c0 + C::CK, cnn = c0 + 2 * C::CK;
+                compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSA : 1>{}, std::integral_constant<int, IN_PT6>{}, std::integral_constant<int, NPB>{},
+                                         [&](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); },
+                                         [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6b, k); });
+                });
+                __syncthreads();
+                if constexpr (more) store_w6(Q0{}, QA{}, rw6);
+                compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
+                    if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSB : 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NPA>{}, [](const int) {},
+                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cnn, Q0{}, QA{}, rw6, k); });
+                });
+                __syncthreads();
+                if constexpr (more) {
+                    store_w6(QA{}, QE{}, rw6b);
+                    store_in6_all(cn);
+                    __syncthreads();
+                }
+            };
+            int c0 = c_begin;
+            for (; c0 + 2 * C::CK < c_end; c0 += C::CK) chunk(c0, Yes{}, Yes{});
+            if (c0 + C::CK < c_end) { chunk(c0, Yes{}, No{}); c0 += C::CK; }
+            if (c0 < c_end) chunk(c0, No{}, No{});
+        } else {
+            // The weight slab is staged in two k-group phases that ping-pong with the MFMA stream: under phase A the next chunk's
+            // phase-A weights and input tile gather in registers; they are written when phase A's slots fall idle, the registers
+            // then collect the next chunk's phase-B weights under phase B's MFMA stream.  Three barriers per chunk.
+            auto chunk = [&](const int c0, auto more_c) __attribute__((always_inline)) {
+                constexpr bool more = decltype(more_c)::value;
+                const int cn = c0 + C::CK;
+                compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + 1) / 2 : 1>{}, std::integral_constant<int, IN_PT6>{}, std::integral_constant<int, NPA>{},
+                                         [&](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); },
+                                         [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QA{}, rw6, k); });
+                });
+                __syncthreads();                                   // phase A's slots are idle
+                if constexpr (more) store_w6(Q0{}, QA{}, rw6);
+                compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + 1) / 2 : 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NPB>{}, [](const int) {},
+                                         [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
+                });
+                __syncthreads();                                   // everyone is done with phase B's slots and this chunk's input tile
+                if constexpr (more) {
+                    store_w6(QA{}, QE{}, rw6);
+                    store_in6_all(cn);
+                    __syncthreads();
+                }
+            };
+            int c0 = c_begin;
+            for (; c0 + C::CK < c_end; c0 += C::CK) chunk(c0, Yes{});
+            if (c0 < c_end) chunk(c0, No{});
+        }
+        if constexpr (C::F16) {
+            // undo the operand scales (powers of two: exact): 1 / (weight scale x activation scale) sits behind the last weight slab
+            const float inv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wpk) +
+                                                              (int64_t)((p.Cin + C::CK - 1) / C::CK) * (C::NPL * C::G * 2) * p.Cout * 16);
+#pragma unroll
+            for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < C::NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
         }
     } else if constexpr (C::DB && C::GL) {
         // double-buffered LDS filled by LDS-DMA: chunk i+1 is enqueued into the idle buffer, chunk i's MFMA stream runs, and
@@ -1079,6 +1231,66 @@ __global__ void pack_conv_weight_bf16x6_kernel(const float* __restrict__ w, uint
     }
 }
 
+// f16x3 packing: the bf16x6 slab order with fp16 planes [G][hi|lo|hi * 2^-11][half][Cout][8 fp16] of w * S, S = 2^(13 -
+// floor(log2(max|w|))) -- the layer's largest weight lands in [2^13, 2^14), so all three terms of every weight within 2^-16 of it
+// are normal fp16 numbers (the third plane multiplies the input tile's lo * 2^11 term).  16 bytes behind the last slab:
+// { 1 / (S * activation scale), bits of max|w|, S, 0 }; the conv kernel multiplies its accumulators by the first.
+__global__ void absmax_bits_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ out) {
+    unsigned int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(fabsf(w[i])));               // (non-negative floats order like their bit patterns; NaN / inf end up on top)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__device__ __forceinline__ float f16x3_weight_scale(unsigned int max_bits) {
+    const int e = (int)((max_bits >> 23) & 0xff);               // biased exponent of max|w| (0: zero / subnormal weights only -> scale 1)
+    if (e == 0 || e == 0xff) return 1.0f;
+    return __uint_as_float((unsigned int)min(max(127 + 13 - (e - 127), 1), 254) << 23);
+}
+
+__global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int Cin, int taps,
+                                               int CK, int TPG) {
+    const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
+    const int nchunks = (Cin + CK - 1) / CK;
+    const int64_t n = (int64_t)nchunks * G * 3 * 2 * Cout;
+    unsigned int* tail = reinterpret_cast<unsigned int*>(packed + n);
+    const float S = f16x3_weight_scale(tail[1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tail[0] = __float_as_uint(1.0f / (S * STEMSEG_F16X3_ACT_SCALE));
+        tail[2] = __float_as_uint(S);
+        tail[3] = 0;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t r = i / Cout;
+        const int h = (int)(r & 1);
+        r >>= 1;
+        const int pl = (int)(r % 3);
+        r /= 3;
+        const int grp = (int)(r % G);
+        const int chunk = (int)(r / G);
+        const int cg = grp / NTG, tg = grp % NTG;
+        unsigned short v[8];
+        for (int j = 0; j < 8; ++j) {
+            const int tapi = j / CPH, chl = j % CPH;
+            const int tap = tg * TPG + tapi, ci = chunk * CK + cg * 2 * CPH + h * CPH + chl;
+            float x = 0.f;
+            if (tap < taps && ci < Cin) x = w[((int64_t)co * Cin + ci) * taps + tap] * S;
+            const _Float16 hi = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (float)hi);
+            const _Float16 his = (_Float16)((float)hi * (1.0f / 2048.0f));
+            const _Float16 pick = pl == 0 ? hi : (pl == 1 ? lo : his);
+            v[j] = *reinterpret_cast<const unsigned short*>(&pick);
+        }
+        uint4 o;
+        o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+        o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+        packed[i] = o;
+    }
+}
+
 // tile shapes --------------------------------------------------------------------------------------
 //                       KT KH KW  CK  MI NI WM WN COLS
 using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
@@ -1145,19 +1357,22 @@ using X2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true, true>;
 using X2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true, true>;
 using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
 
-// bf16x6 tiles.  3x3x3: eight waves share one 86 KB weight slab (one workgroup per CU, two waves per SIMD); 2-D and 1x1 tiles
-// keep four-wave shapes (two workgroups per CU) except the big 2-D tile
-using Y3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 1, false, 2>;   // 128 co x (16 rows x 32 cols), 512 threads
-using Y3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 4, 1, false, 2>;   // 128 co x ( 8 rows x 32 cols), 512 threads
-using Y3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 4, 1, false, 2>; // 128 co x ( 4 rows x 32 cols), 512 threads
-using Y2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 1, false, 2>;   // 128 co x (16 rows x 32 cols), 512 threads (the weight prefetch of a four-wave tile spills)
-using Y2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, false, 2>;   // 128 co x (4 rows x 32 cols)
-using Y2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, false, 2>; // 128 co x (2 rows x 32 cols)
-using Y2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, false, 2>;   //  64 co x (8 rows x 32 cols)
-using Y1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, 2>;  // 128 co x 256 voxels
-using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, 2>; // 128 co x 128 voxels
-using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, 2>;  //  64 co x 256 voxels
-using Y1Wide = ConvCfg<1, 1, 1, 32, 4, 2, 2, 4, 8, false, 2>; // 256 co x 256 voxels, 512 threads: an input element is split once per 256 output channels
+// Split-staged tiles (BFV 2 = bf16x6, 3 = f16x3).  3x3x3: eight waves share one weight slab (86 KB in bf16x6, 57 KB in f16x3; one
+// workgroup per CU, two waves per SIMD); 2-D and 1x1 tiles keep four-wave shapes (two workgroups per CU) except the big ones
+template <int BFV>
+struct SplitTiles {
+    using Y3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 1, false, BFV>;   // 128 co x (16 rows x 32 cols), 512 threads
+    using Y3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 4, 1, false, BFV>;   // 128 co x ( 8 rows x 32 cols), 512 threads
+    using Y3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 4, 1, false, BFV>; // 128 co x ( 4 rows x 32 cols), 512 threads
+    using Y2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 1, false, BFV>;   // 128 co x (16 rows x 32 cols), 512 threads (the weight prefetch of a four-wave tile spills)
+    using Y2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, false, BFV>;   // 128 co x (4 rows x 32 cols)
+    using Y2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, false, BFV>; // 128 co x (2 rows x 32 cols)
+    using Y2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, false, BFV>;   //  64 co x (8 rows x 32 cols)
+    using Y1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, BFV>;  // 128 co x 256 voxels
+    using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, BFV>; // 128 co x 128 voxels
+    using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, BFV>;  //  64 co x 256 voxels
+    using Y1Wide = ConvCfg<1, 1, 1, 32, 4, 2, 2, 4, 8, false, BFV>; // 256 co x 256 voxels, 512 threads: an input element is split once per 256 output channels
+};
 
 // sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
 // MFMA peak)
@@ -1373,12 +1588,62 @@ static int64_t num_workgroups(int Cout, int T, int H, int W) {
     return ceil_div(W, C::COLS * 32) * ceil_div(H, C::ROWS) * T * ceil_div(Cout, C::MT);
 }
 
+// split-staged precisions: the weights were packed with stemseg_hip_pack_conv_weight_prec(..., precision).  Tile = the largest whose
+// launch (with split-K where scratch is given) still covers the chip; tile_cfg 1 / 2 / 3 force big / medium / small.
+template <int BFV>
+static int launch_split_family(ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, int tile_cfg, bool k3, bool k2, bool k1) {
+    typedef SplitTiles<BFV> F;
+    using Y3Big = typename F::Y3Big; using Y3Med = typename F::Y3Med; using Y3Small = typename F::Y3Small;
+    using Y2Big = typename F::Y2Big; using Y2Med = typename F::Y2Med; using Y2Small = typename F::Y2Small; using Y2M64 = typename F::Y2M64;
+    using Y1Big = typename F::Y1Big; using Y1Small = typename F::Y1Small; using Y1M64 = typename F::Y1M64; using Y1Wide = typename F::Y1Wide;
+    int cfg = tile_cfg;
+    // STEMSEG_X6_TILES (debug / A-B): bit 0 no big 3x3x3 tile, bit 1 no big 2-D tile, bit 2 no big 1x1 tile, bit 3 no split-K
+    static const int x6_off = [] { const char* e = getenv("STEMSEG_X6_TILES"); return e ? atoi(e) : 0; }();
+    if (x6_off & 8) { scratch = nullptr; scratch_floats = 0; }
+    if (cfg <= 0 || cfg > 3) {
+        if (k3 && (x6_off & 1)) cfg = 2;
+        if (k2 && (x6_off & 2) && p.Cout > 64) cfg = 2;
+        if (k1 && (x6_off & 4) && p.Cout > 64) cfg = 2;
+    }
+    if (k3) {
+        if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
+        // big launches: the row planner (whole rows + split-K rows, see plan_rows) with one eight-wave workgroup per CU
+        static const bool plan6 = [] { const char* e = getenv("STEMSEG_X6_PLANNER"); return e && e[0] == '1'; }();   // (measured: 63.6 clips/s with, 64.7 without)
+        if (cfg == 1 && plan6 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<Y3Big, Y3Med>(p, s, scratch, scratch_floats, 1, 1, CU_FLOPS_X6);
+        if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats);
+        if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats);
+        return launch_cfg<Y3Small>(p, s, scratch, scratch_floats);
+    }
+    if (k2) {
+        if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats);
+        if (cfg <= 0 || cfg > 3) {
+            const int64_t need = scratch ? 96 : 384;
+            cfg = num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= need ? 1 : (num_workgroups<Y2Med>(p.Cout, p.T, p.H, p.W) >= need ? 2 : 3);
+        }
+        if (cfg == 1) return launch_cfg<Y2Big>(p, s, scratch, scratch_floats);
+        if (cfg == 2) return launch_cfg<Y2Med>(p, s, scratch, scratch_floats);
+        return launch_cfg<Y2Small>(p, s, scratch, scratch_floats);
+    }
+    if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats);
+    if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats);
+    // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
+    // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
+    if ((tile_cfg <= 0 || tile_cfg > 3) && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(p.Cout, p.T, p.H, p.W) >= 128)
+        return launch_cfg<Y1Wide>(p, s, nullptr, 0);
+    if (cfg <= 0 || cfg > 2) {
+        cfg = (num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
+        if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
+    }
+    if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats);
+    return launch_cfg<Y1Small>(p, s, scratch, scratch_floats);
+}
+
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats, const ConvEpilogue* epi) {
     SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
     const bool bf = epi && epi->precision == 1;
-    const bool x6 = epi && epi->precision == 2;
-    SS_CHECK_ARG(!epi || (epi->precision >= 0 && epi->precision <= 2), "conv3d: precision %d (0 f32, 1 bf16x3, 2 bf16x6)", epi ? epi->precision : 0);
+    const bool x6 = epi && epi->precision == 2, f16x3 = epi && epi->precision == 3;
+    SS_CHECK_ARG(!epi || (epi->precision >= 0 && epi->precision <= 3), "conv3d: precision %d (0 f32, 1 bf16x3, 2 bf16x6, 3 f16x3)", epi ? epi->precision : 0);
     const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1), k2 = (kt == 1 && kh == 3 && kw == 3);
     SS_CHECK_ARG(k3 || k1 || k2, "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3 or 1x1x1)", kt, kh, kw);
     const bool flat = epi && epi->dec_W > 0;
@@ -1417,50 +1682,8 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
     p.vec4 = aligned ? 1 : 0;
     SS_CHECK_ARG(reinterpret_cast<uintptr_t>(packed_w) % 16 == 0, "conv3d: packed weights must be 16-byte aligned");
-    if (x6) {
-        // bf16x6: the weights were packed with stemseg_hip_pack_conv_weight_split(..., planes = 3).  Tile = the largest whose
-        // launch (with split-K where scratch is given) still covers the chip; tile_cfg 1 / 2 / 3 force big / medium / small.
-        int cfg = tile_cfg;
-        // STEMSEG_X6_TILES (debug / A-B): bit 0 no big 3x3x3 tile, bit 1 no big 2-D tile, bit 2 no big 1x1 tile, bit 3 no split-K
-        static const int x6_off = [] { const char* e = getenv("STEMSEG_X6_TILES"); return e ? atoi(e) : 0; }();
-        if (x6_off & 8) { scratch = nullptr; scratch_floats = 0; }
-        if (cfg <= 0 || cfg > 3) {
-            if (k3 && (x6_off & 1)) cfg = 2;
-            if (k2 && (x6_off & 2) && p.Cout > 64) cfg = 2;
-            if (k1 && (x6_off & 4) && p.Cout > 64) cfg = 2;
-        }
-        if (k3) {
-            if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
-            // big launches: the row planner (whole rows + split-K rows, see plan_rows) with one eight-wave workgroup per CU
-            static const bool plan6 = [] { const char* e = getenv("STEMSEG_X6_PLANNER"); return e && e[0] == '1'; }();   // (measured: 63.6 clips/s with, 64.7 without)
-            if (cfg == 1 && plan6 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<Y3Big, Y3Med>(p, s, scratch, scratch_floats, 1, 1, CU_FLOPS_X6);
-            if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats);
-            if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats);
-            return launch_cfg<Y3Small>(p, s, scratch, scratch_floats);
-        }
-        if (k2) {
-            if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats);
-            if (cfg <= 0 || cfg > 3) {
-                const int64_t need = scratch ? 96 : 384;
-                cfg = num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= need ? 1 : (num_workgroups<Y2Med>(p.Cout, p.T, p.H, p.W) >= need ? 2 : 3);
-            }
-            if (cfg == 1) return launch_cfg<Y2Big>(p, s, scratch, scratch_floats);
-            if (cfg == 2) return launch_cfg<Y2Med>(p, s, scratch, scratch_floats);
-            return launch_cfg<Y2Small>(p, s, scratch, scratch_floats);
-        }
-        if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats);
-        if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats);
-        // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
-        // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
-        if ((tile_cfg <= 0 || tile_cfg > 3) && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(p.Cout, p.T, p.H, p.W) >= 128)
-            return launch_cfg<Y1Wide>(p, s, nullptr, 0);
-        if (cfg <= 0 || cfg > 2) {
-            cfg = (num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
-            if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
-        }
-        if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats);
-        return launch_cfg<Y1Small>(p, s, scratch, scratch_floats);
-    }
+    if (x6) return launch_split_family<2>(p, s, scratch, scratch_floats, tile_cfg, k3, k2, k1);
+    if (f16x3) return launch_split_family<3>(p, s, scratch, scratch_floats, tile_cfg, k3, k2, k1);
     if (k3) {
         int cfg = tile_cfg;
         if (cfg <= 0 || cfg > 3) {
@@ -1649,6 +1872,35 @@ extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, 
     const int64_t n = stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) / 16;
     const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(pack_conv_weight_bf16x6_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
+                       taps, CK, TPG);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
+    if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2);
+    if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3);
+    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) + 16;      // three planes + the scale record
+    return 0;
+}
+
+extern "C" int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t precision, void* stream) {
+    using namespace stemseg;
+    if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_pack_conv_weight_split(w, packed, Cout, Cin, taps, 2, stream);
+    if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_pack_conv_weight_split(w, packed, Cout, Cin, taps, 3, stream);
+    SS_CHECK_ARG(precision == STEMSEG_PRECISION_F16X3, "pack_conv_weight_prec: precision must be 1 (bf16x3), 2 (bf16x6) or 3 (f16x3)");
+    SS_CHECK_ARG(w && packed, "pack_conv_weight_prec: null pointer");
+    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_prec: taps must be 27, 9 or 1");
+    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
+    SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_prec: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
+    const int64_t n = (stemseg_hip_packed_weight_bytes_prec(Cout, Cin, taps, precision) - 16) / 16;
+    unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<uint4*>(packed) + n);
+    SS_HIP(hipMemsetAsync(tail, 0, 16, as_stream(stream)));
+    const int64_t nw = (int64_t)Cout * Cin * taps;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3((int)std::min<int64_t>(ceil_div(nw, 256), 1024)), dim3(256), 0, as_stream(stream), w, nw, tail + 1);
+    SS_LAUNCH_CHECK();
+    const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(pack_conv_weight_f16x3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
                        taps, CK, TPG);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;

@@ -262,7 +262,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
 
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
-    SS_CHECK_ARG(desc->precision >= 0 && desc->precision <= 2, "decoder: precision must be 0 (f32), 1 (bf16x3) or 2 (bf16x6)");
+    SS_CHECK_ARG(desc->precision >= 0 && desc->precision <= 3, "decoder: precision must be 0 (f32), 1 (bf16x3), 2 (bf16x6) or 3 (f16x3)");
     ConvEpilogue fuse_epi;
     fuse_epi.precision = desc->precision;
     const float eps = desc->gn_eps;

@@ -301,7 +301,7 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         SS_CHECK_ARG(wts->fpn_inner_w[i] && wts->fpn_inner_b[i] && wts->fpn_layer_w[i] && wts->fpn_layer_b[i], "encoder_forward: null FPN weights %d", i);
     }
     SS_CHECK_ARG(desc->out_channels == 256, "encoder: out_channels must be 256");
-    SS_CHECK_ARG(desc->precision >= 0 && desc->precision <= 2, "encoder: precision must be 0 (f32), 1 (bf16x3) or 2 (bf16x6)");
+    SS_CHECK_ARG(desc->precision >= 0 && desc->precision <= 3, "encoder: precision must be 0 (f32), 1 (bf16x3), 2 (bf16x6) or 3 (f16x3)");
     const int prec = desc->precision;
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstemseg_hip.so")
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Volume(C.Structure):
@@ -86,6 +86,8 @@ SIGNATURES = {
     "stemseg_hip_pack_conv_weight_bf16x3": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_packed_weight_bytes_split": (C.c_int64, [_I32, _I32, _I32, _I32]),
     "stemseg_hip_pack_conv_weight_split": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "stemseg_hip_packed_weight_bytes_prec": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "stemseg_hip_pack_conv_weight_prec": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
     "stemseg_hip_conv3d_gn_scratch_doubles": (C.c_int64, [_I32, _I32]),
     "stemseg_hip_conv3d_gn": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
@@ -243,7 +245,7 @@ def pack_conv_weight(w):
     return out
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 # MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision): "bf16x6" (default) =
 # every fp32 operand split EXACTLY into three bf16 terms, six products, fp32 accumulation -- fp32-level results (error vs an
 # fp64 convolution = that of the fp32-input MFMA kernel, tests/test_gpu_bf16x6.py; labels identical on every reference flow)
@@ -254,18 +256,21 @@ assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
 
 
 def pack_conv_weight_any(w, precision="f32"):
-    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA), 'bf16x3' (two bf16 terms per operand, 3 products) or 'bf16x6'
-    (exact three-term split, 6 products: fp32-level results); fp32 accumulate throughout."""
+    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA), 'bf16x3' (two bf16 terms per operand, 3 products), 'bf16x6'
+    (exact three-term split, 6 products: fp32-level results) or 'f16x3' (two fp16 terms of the power-of-two-scaled operands, 3
+    products: fp32-level results for |activation| < 2.6e5); fp32 accumulate throughout."""
     if precision == "f32":
         return pack_conv_weight(w)
-    assert precision in ("bf16x3", "bf16x6"), precision
-    planes = 2 if precision == "bf16x3" else 3
+    assert precision in ("bf16x3", "bf16x6", "f16x3"), precision
+    code = PRECISIONS[precision]
     w = w.contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     taps = w[0, 0].numel()
-    nbytes = lib().stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, planes)
+    nbytes = lib().stemseg_hip_packed_weight_bytes_prec(Cout, Cin, taps, code)
+    if nbytes <= 0:
+        raise ValueError("pack_conv_weight_any: unsupported shape / precision (%s, Cout %d, Cin %d, taps %d)" % (precision, Cout, Cin, taps))
     out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)      # opaque 16-B-aligned blob
-    check(lib().stemseg_hip_pack_conv_weight_split(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, planes, stream()))
+    check(lib().stemseg_hip_pack_conv_weight_prec(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, code, stream()))
     return out
 
 

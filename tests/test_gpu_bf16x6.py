@@ -1,13 +1,25 @@
-"""bf16x6 convolution mode (STEMSEG_PRECISION_BF16X6): every fp32 operand split EXACTLY into three bf16 terms, six products on
-the bf16 matrix cores, fp32 accumulation.  The claim under test is "fp32-level results": against an fp64 convolution of the
-same inputs the x6 kernel's error must be of the order of the exact-fp32-MFMA kernel's own error (both are dominated by the
-rounding of the fp32 accumulation), on every kernel class, tile shape, split-K, ragged / unaligned shapes and fused epilogue."""
+"""The split-staged convolution modes.  bf16x6 (STEMSEG_PRECISION_BF16X6): every fp32 operand split EXACTLY into three bf16
+terms, six products on the bf16 matrix cores; f16x3 (STEMSEG_PRECISION_F16X3): operands scaled by powers of two, split into two
+fp16 terms, three products on the fp16 matrix cores; fp32 accumulation in both.  The claim under test is "fp32-level results":
+against an fp64 convolution of the same inputs the split kernel's error must be of the order of the exact-fp32-MFMA kernel's
+own error (both are dominated by the rounding of the fp32 accumulation), on every kernel class, tile shape, split-K, ragged /
+unaligned shapes and fused epilogue -- every test below runs once per mode."""
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+
+SP = "bf16x6"
+
+
+@pytest.fixture(params=["bf16x6", "f16x3"], autouse=True)
+def split_mode(request):
+    global SP
+    SP = request.param
+    yield SP
 
 
 @pytest.fixture(scope="module")
@@ -46,7 +58,7 @@ def _haloed(hip, x, kt):
 
 def _both(hip, vin, w, b, out_shape, k, cfg, scratch_floats=0, flat=False):
     res = {}
-    for prec in ("f32", "bf16x6"):
+    for prec in ("f32", SP):
         out = torch.full(out_shape, float("nan"), device="cuda")
         vout = hip.flat_volume(out) if flat else hip.dense_volume(out)
         scratch = torch.full((scratch_floats,), float("nan"), device="cuda") if scratch_floats else None
@@ -58,12 +70,12 @@ def _both(hip, vin, w, b, out_shape, k, cfg, scratch_floats=0, flat=False):
 
 def _check(name, res, ref):
     e32 = float(np.abs(res["f32"] - ref).max())
-    e6 = float(np.abs(res["bf16x6"] - ref).max())
+    e6 = float(np.abs(res[SP] - ref).max())
     scale = float(np.abs(ref).max())
-    print("[bf16x6] %-46s max|err| vs fp64: fp32-MFMA %.3e, bf16x6 %.3e (ratio %.2f; max|ref| %.3g); x6 vs fp32-MFMA %.3e"
-          % (name, e32, e6, e6 / max(e32, 1e-30), scale, float(np.abs(res["bf16x6"] - res["f32"]).max())))
-    assert np.isfinite(res["bf16x6"]).all()
-    assert e6 <= max(3.0 * e32, 4e-7 * scale), "bf16x6 is not at the fp32 error level"
+    print("[%s] %-46s max|err| vs fp64: fp32-MFMA %.3e, split %.3e (ratio %.2f; max|ref| %.3g); split vs fp32-MFMA %.3e"
+          % (SP, name, e32, e6, e6 / max(e32, 1e-30), scale, float(np.abs(res[SP] - res["f32"]).max())))
+    assert np.isfinite(res[SP]).all()
+    assert e6 <= max(3.0 * e32, 4e-7 * scale), "%s is not at the fp32 error level" % SP
     return e32, e6
 
 
@@ -103,7 +115,7 @@ def test_bf16x6_ragged_shapes_and_splitk(hip, case):
     r1 = _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), 0, scratch_floats=16 * Cout * T * H * W)
     r2 = _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), 0, scratch_floats=16 * Cout * T * H * W)
     _check("%s %s split-K" % (kind, case[1:]), r1, ref)
-    assert np.array_equal(r1["bf16x6"], r2["bf16x6"])
+    assert np.array_equal(r1[SP], r2[SP])
 
 
 def test_bf16x6_unaligned_input_rows(hip):
@@ -125,7 +137,7 @@ def test_bf16x6_1x1_decode_residual_relu(hip, shape):
     ref = np.maximum(w.reshape(Cout, Cin).astype(np.float64) @ x.astype(np.float64) + b.astype(np.float64)[:, None] + r, 0.0)
     xd, rd = dev(x), dev(r)
     res = {}
-    for prec in ("f32", "bf16x6"):
+    for prec in ("f32", SP):
         pitch = (W + 2 + 3) // 4 * 4
         buf = torch.zeros(Cout, T, H + 2, pitch, device="cuda")
         vout = hip.Volume(buf.data_ptr() + 4 * (pitch + 1), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cout, T, H, W, buf.numel() - (pitch + 1))
@@ -146,7 +158,7 @@ def test_bf16x6_conv_with_groupnorm_statistics(hip, case):
     for scratch_floats in (0, 8 * Cout * T * H * W):
         out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
         scratch = torch.empty(scratch_floats, device="cuda") if scratch_floats else None
-        stats = hip.conv3d_gn(vin, hip.pack_conv_weight_any(dev(w), "bf16x6"), dev(b), hip.dense_volume(out), 3, 32, 1e-5, 0, scratch, "bf16x6")
+        stats = hip.conv3d_gn(vin, hip.pack_conv_weight_any(dev(w), SP), dev(b), hip.dense_volume(out), 3, 32, 1e-5, 0, scratch, SP)
         torch.cuda.synchronize()
         o = out.cpu().numpy().astype(np.float64).reshape(32, -1)
         mean, var = o.mean(1), o.var(1)
@@ -165,6 +177,34 @@ def test_bf16x6_block4x_shape_is_fp32_accurate_and_deterministic(hip):
     buf, vin = _haloed(hip, x, 3)
     r1 = _both(hip, vin, w, b, (Cout, T, H, W), 3, 0, scratch_floats=4 * Cout * T * H * W)
     r2 = _both(hip, vin, w, b, (Cout, T, H, W), 3, 0, scratch_floats=4 * Cout * T * H * W)
-    assert np.array_equal(r1["bf16x6"], r2["bf16x6"])
+    assert np.array_equal(r1[SP], r2[SP])
     sl = {k: v[:, 1, :39] for k, v in r1.items()}
     _check("block_4x 256->128 T=8 120x216", sl, ref[:, :39])
+
+
+@pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (1e-2, 1.0), (1e-4, 1.0), (100.0, 1.0), (2e4, 1.0), (1.0, 1e-3), (1.0, 50.0), (1e-3, 1e-3), (3e3, 1e-2)])
+def test_split_modes_keep_fp32_level_across_operand_magnitudes(hip, xscale, wscale):
+    """The f16x3 mode scales its operands by powers of two to sit inside fp16's exponent range: activations of 1e-4 ... 2e4 times
+    unit scale (pixel-scale inputs of an un-normalised backbone included) and weights of 1e-3 ... 50 times He scale must all stay
+    at the fp32-MFMA error level (bf16x6 has fp32's range and passes trivially)."""
+    Cin, Cout, T, H, W = 64, 128, 2, 17, 40
+    x = _rand((Cin, T, H, W), 51, xscale)
+    w, b = _rand((Cout, Cin, 3, 3, 3), 52, wscale / np.sqrt(Cin * 27)), _rand((Cout,), 53, xscale * wscale)
+    ref = _ref64(x, w, b, 3)
+    buf, vin = _haloed(hip, x, 3)
+    _check("k3 x*%g w*%g" % (xscale, wscale), _both(hip, vin, w, b, (Cout, T, H, W), 3, 0), ref)
+
+
+def test_f16x3_overflowing_activation_is_not_silent(hip):
+    """|activation| >= 2.6e5 leaves the fp16 range of the scaled operand: the affected outputs must come back non-finite, never
+    as plausible numbers."""
+    Cin, Cout, V = 64, 128, 512
+    x, w = _rand((Cin, V), 61), _rand((Cout, Cin, 1, 1, 1), 62, 1.0 / 8)
+    x[3, 100] = 3.0e5
+    xd = dev(x)
+    out = torch.zeros(Cout, V, device="cuda")
+    hip.conv3d(hip.flat_volume(xd), hip.pack_conv_weight_any(dev(w), "f16x3"), None, hip.flat_volume(out), 1, 0, None, dict(precision="f16x3"))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert not np.isfinite(o[:, 100]).any()
+    assert np.isfinite(np.delete(o, 100, axis=1)).all()

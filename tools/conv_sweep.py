@@ -42,7 +42,7 @@ def k1(name, cin, cout, h, w, residual):
         epi.update(residual=res, res_strides=(V, 0, 0))
     fl = 2.0 * cin * cout * V
     row = []
-    for cfg in ((1, 2, 3) if PREC == "bf16x6" and cout % 256 == 0 else (1, 2)):
+    for cfg in ((1, 2, 3) if PREC in ("bf16x6", "f16x3") and cout % 256 == 0 else (1, 2)):
         for sc in (None, scratch):
             us = timeit(lambda: hip.conv3d(hip.flat_volume(x), wt, b, hip.flat_volume(out), 1, cfg, sc, epi))
             row.append("cfg%d%s %7.1f us %5.1f TF" % (cfg, "+sk" if sc is not None else "   ", us, fl / us / 1e6))
