@@ -119,7 +119,8 @@ struct ConvCfg {
     // X6 = the split-staged path (operands split once, when a chunk is staged): BF_ 2 = bf16x6 (three bf16 planes, six products),
     // BF_ 3 = f16x3 (two fp16 planes of the SCALED operand, three products)
     static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ >= 2, F16 = BF_ == 3, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
-    static constexpr int NPL = BF_ >= 2 ? 3 : 2;                        // 16-bit planes of the weights (f16x3: hi, lo, hi * 2^-11)
+    static constexpr int NPL = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged weights (f16x3: hi, lo; hi * 2^-11 is made in registers)
+    static constexpr int NPA = BF_ >= 2 ? 3 : 2;                        // A operands of a k-group step
     static constexpr int NPX = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged input tile (f16x3: hi, lo * 2^11)
     static constexpr int NPROD = BF_ == 2 ? 6 : 3;                      // MFMAs per (A fragment, B fragment) pair
     static constexpr int PMAX = PMAX_;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     // matrix pipe idle behind them: measured 17% of a 1x1 layer)
     auto compute6 = [&](auto g0c, auto g1c, auto&& side) __attribute__((always_inline)) {
         constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
-        constexpr int NPL = C::NPL, NPX = C::NPX;
+        constexpr int NPL = C::NPL, NPX = C::NPX, NPA = C::NPA;
         typedef typename std::conditional<C::F16, _Float16, __bf16>::type h16;
         typedef h16 h16x8 __attribute__((ext_vector_type(8)));
         const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
@@ -524,14 +525,17 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     b[pl][ni] = __builtin_bit_cast(h16x8, w4);
                 }
         };
-        auto ld_a = [&](const int grp, const int mi, h16x8 (&a)[NPL]) __attribute__((always_inline)) {
+        auto ld_a = [&](const int grp, const int mi, h16x8 (&a)[NPA]) __attribute__((always_inline)) {
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
                 a[pl] = *reinterpret_cast<const h16x8*>(a_base + (((grp * NPL + pl) * 2) * C::MT + mi * 32) * 16);
         };
         // smallest products first (planes: 0 hi, 1 mid / lo, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
-        auto mm = [&](const int mi, const h16x8 (&a)[NPL], const h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
+        auto mm = [&](const int mi, h16x8 (&a)[NPA], const h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
             if constexpr (C::F16) {
+                // the weights' hi * 2^-11 operand (it meets the input tile's lo * 2^11 plane) is made here: four packed multiplies in the
+                // shadow of the MFMAs instead of a third plane in LDS (a third of the A reads, of the slab and of its staging traffic)
+                a[2] = a[0] * (h16)(1.0f / 2048.0f);
 #define SS_X6_TERM(PA, PB)                                                                                                     \
     _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         // 6 x NI MFMAs of step s are issued (two register sets), a group's B fragments right after the previous group's last
         // MFMAs -- left to itself the compiler reads each fragment right in front of the MFMAs that consume it and waits there
         constexpr int NSTEP = (g1 - g0) * C::MI;
-        h16x8 bfr[NPX][C::NI], a0[NPL], a1[NPL];
+        h16x8 bfr[NPX][C::NI], a0[NPA], a1[NPA];
         side(-1);                                          // (tiles that do not spread issue everything here, ahead of the fragments)
         ld_b(g0, bfr);
         ld_a(g0, 0, a0);
@@ -1231,10 +1235,10 @@ __global__ void pack_conv_weight_bf16x6_kernel(const float* __restrict__ w, uint
     }
 }
 
-// f16x3 packing: the bf16x6 slab order with fp16 planes [G][hi|lo|hi * 2^-11][half][Cout][8 fp16] of w * S, S = 2^(13 -
-// floor(log2(max|w|))) -- the layer's largest weight lands in [2^13, 2^14), so all three terms of every weight within 2^-16 of it
-// are normal fp16 numbers (the third plane multiplies the input tile's lo * 2^11 term).  16 bytes behind the last slab:
-// { 1 / (S * activation scale), bits of max|w|, S, 0 }; the conv kernel multiplies its accumulators by the first.
+// f16x3 packing: the split slab order with two fp16 planes, [G][hi|lo][half][Cout][8 fp16] of w * S, S = 2^(13 -
+// floor(log2(max|w|))) -- the layer's largest weight lands in [2^13, 2^14), so both terms (and the hi * 2^-11 operand the kernel
+// derives for the input tile's lo * 2^11 plane) of every weight within 2^-16 of it are normal fp16 numbers.  16 bytes behind the
+// last slab: { 1 / (S * activation scale), bits of max|w|, S, 0 }; the conv kernel multiplies its accumulators by the first.
 __global__ void absmax_bits_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ out) {
     unsigned int m = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -1254,7 +1258,7 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
                                                int CK, int TPG) {
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
     const int nchunks = (Cin + CK - 1) / CK;
-    const int64_t n = (int64_t)nchunks * G * 3 * 2 * Cout;
+    const int64_t n = (int64_t)nchunks * G * 2 * 2 * Cout;
     unsigned int* tail = reinterpret_cast<unsigned int*>(packed + n);
     const float S = f16x3_weight_scale(tail[1]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1267,8 +1271,8 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
         int64_t r = i / Cout;
         const int h = (int)(r & 1);
         r >>= 1;
-        const int pl = (int)(r % 3);
-        r /= 3;
+        const int pl = (int)(r & 1);
+        r >>= 1;
         const int grp = (int)(r % G);
         const int chunk = (int)(r / G);
         const int cg = grp / NTG, tg = grp % NTG;
@@ -1280,8 +1284,7 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
             if (tap < taps && ci < Cin) x = w[((int64_t)co * Cin + ci) * taps + tap] * S;
             const _Float16 hi = (_Float16)x;
             const _Float16 lo = (_Float16)(x - (float)hi);
-            const _Float16 his = (_Float16)((float)hi * (1.0f / 2048.0f));
-            const _Float16 pick = pl == 0 ? hi : (pl == 1 ? lo : his);
+            const _Float16 pick = pl == 0 ? hi : lo;
             v[j] = *reinterpret_cast<const unsigned short*>(&pick);
         }
         uint4 o;
@@ -1880,7 +1883,7 @@ extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
     if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2);
     if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3);
-    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) + 16;      // three planes + the scale record
+    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2) + 16;      // two planes + the scale record
     return 0;
 }
 
