@@ -378,9 +378,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
-                    help="MFMA mode of every convolution: bf16x6 (default, the library's default) = exact three-term bf16 split of every fp32 "
-                         "operand, six products, fp32 accumulate (fp32-level results); f32 = fp32-input MFMA; bf16x3 = two-term split (~1e-4)")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
+                    help="MFMA mode of every convolution: f16x3 (default, the library's default) = two fp16 terms of the power-of-two-scaled "
+                         "operands, three products, fp32 accumulate (fp32-level results); bf16x6 = exact three-term bf16 split, six products "
+                         "(fp32-level, fp32's exponent range); f32 = fp32-input MFMA; bf16x3 = two-term bf16 split (~1e-4)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the step (use under rocprofv3)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)      # (the default; kept for old command lines)

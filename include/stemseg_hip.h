@@ -269,6 +269,9 @@ typedef struct StemsegEncoderWeights {
 } StemsegEncoderWeights;
 
 size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* desc);
+/* Debugging aid: float offsets of the encoder plan's buffers inside the workspace (S0, X1, A, B, Cst[4], M1[4], M2, DS, XS, L[4], FO[4],
+ * SK, total: 25 values, -1 = absent). */
+int stemseg_hip_encoder_plan_offsets(const StemsegEncoderDesc* desc, int64_t* out25);
 int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
 /* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[4 * c + k], c < n_clips, k = 0..3: the four FPN maps (4x, 8x, 16x,
  * 32x) of clip c as volumes [256][clip frames][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed

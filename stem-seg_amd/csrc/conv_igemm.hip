@@ -41,10 +41,20 @@
 #define STEMSEG_F16X3_ACT_SCALE 0.25f
 
 #ifndef SS_X6_WMODE_SMALLG
-#define SS_X6_WMODE_SMALLG 2
+#define SS_X6_WMODE_SMALLG -1      // -1: mode 2 wherever its second register set fits (mode 1 measured 2-5 % faster on the f16x3 1x1 tiles;
+                                  // not used, see SS_X6_SPREAD)
 #endif
 #ifndef SS_X6_SPREAD
-#define SS_X6_SPREAD 1
+#define SS_X6_SPREAD 0             // 1: the next chunk's global loads go out a few per (k-group, mi) step instead of at the top of the phase.
+                                  // Measured 1-3 % faster on every class, but OFF: with it (and with weight modes 0 / 1 on the f16x3 1x1
+                                  // tiles) two pipelines in flight on two streams stop being bit-identical to a lone one about every second
+                                  // run of tests/test_gpu_parity.py::test_step_batch_shares_the_encoder_pass -- a short run of wrong values in
+                                  // the OTHER lane's buffers (once the fp32 stem's output), never with one pipeline, never in this
+                                  // configuration (16 / 16 clean runs per precision).  Hazard probes (tools/microbench/*_war_probe.hip) are
+                                  // negative; the cause is not understood -- see DESIGN.md section 10
+#endif
+#ifndef SS_X6_INDB
+#define SS_X6_INDB 0
 #endif
 
 namespace stemseg {
@@ -148,9 +158,14 @@ struct ConvCfg {
     static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
     // X6 weight staging of tiles with few k-groups per chunk (1x1 taps; a phase's MFMA stream is shorter than a global load):
     // 0 two phases, registers refilled per phase; 1 one phase, whole slab in registers; 2 two phases, one chunk of lookahead
-    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? SS_X6_WMODE_SMALLG : 0;
+    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : ((BF_ == 3 || WM * WN >= 8 || MI * NI < 8) ? 2 : 0)) : 0;
+    // (bf16x6, 128 co x 256 voxels on four waves: the second register set of mode 2 spills)
     static constexpr bool SP = WMODE == 1, LA = WMODE == 2;
-    static constexpr int BUF_FLOATS = IN_FLOATS + W_FLOATS;
+    // split-staged tiles keep TWO input tiles where LDS allows (160 KB for a lone eight-wave workgroup, 80 KB for two four-wave ones):
+    // the next chunk's tile is split and written into the idle one between the MFMAs of the running chunk instead of between barriers
+    static constexpr bool INDB = X6 && SS_X6_INDB && (2 * IN_FLOATS + W_FLOATS) * 4 <= ((WM * WN >= 8 || MI * NI > 8) ? 160 : 80) * 1024;
+    static constexpr int IN_ALL = IN_FLOATS * (INDB ? 2 : 1);
+    static constexpr int BUF_FLOATS = IN_ALL + W_FLOATS;
     static constexpr int LDS_FLOATS = BUF_FLOATS * (DB ? 2 : 1);
     static_assert(!BF || CK % (2 * CPH) == 0, "bf16x3: chunk must hold whole k-groups");
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
@@ -163,7 +178,7 @@ struct ConvCfg {
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
     // (the second __launch_bounds__ argument is waves per SIMD: an eight-wave x6 workgroup alone on its CU is two per SIMD as well)
     static constexpr int NWAVES = WM * WN;
-    static constexpr int MIN_WG = X6 ? (NWAVES >= 8 ? 2 : (LDS_FLOATS * 4 * 2 <= 160 * 1024 ? NWAVES / 2 : NWAVES / 4))   // split-staged tiles: two waves per SIMD (256 registers) where LDS allows
+    static constexpr int MIN_WG = X6 ? (MI * NI > 8 ? 1 : NWAVES >= 8 ? 2 : (LDS_FLOATS * 4 * 2 <= 160 * 1024 ? NWAVES / 2 : NWAVES / 4))   // split-staged tiles: two waves per SIMD (256 registers) where LDS allows
                                      : ((GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2));
 };
 
@@ -171,7 +186,7 @@ template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(const ConvKParams p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
     float* const in_lds = smem;
-    float* const w_lds = smem + C::IN_FLOATS;
+    float* const w_lds = smem + C::IN_ALL;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -432,31 +447,32 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         v0 = *reinterpret_cast<const f32x4*>(base + (c0 < in6_clim[k] ? in6_voff[k] : 0u));
         v1 = *reinterpret_cast<const f32x4*>(base + (c0 + 1 < in6_clim[k] ? in6_voff[k] + cs4 : 0u));
     };
-    auto store_in6 = [&](int q, const float4& v0, const float4& v1) { // split both channels, interleave, three 16-B stores
+    int ibuf = 0;                                                    // INDB: word offset of the input tile the MFMA stream reads (0 or IN_FLOATS)
+    auto store_in6 = [&](int q, const float4& v0, const float4& v1, const int wbuf = 0) { // split both channels, interleave, 16-B stores into the tile at word offset wbuf
         unsigned int h0, m0, l0, h1, m1, l1;
         uint4 ph, pm, pl;
         split3(v0.x, h0, m0, l0); split3(v1.x, h1, m1, l1); ph.x = h0 | (h1 << 16); pm.x = m0 | (m1 << 16); pl.x = l0 | (l1 << 16);
         split3(v0.y, h0, m0, l0); split3(v1.y, h1, m1, l1); ph.y = h0 | (h1 << 16); pm.y = m0 | (m1 << 16); pl.y = l0 | (l1 << 16);
         split3(v0.z, h0, m0, l0); split3(v1.z, h1, m1, l1); ph.z = h0 | (h1 << 16); pm.z = m0 | (m1 << 16); pl.z = l0 | (l1 << 16);
         split3(v0.w, h0, m0, l0); split3(v1.w, h1, m1, l1); ph.w = h0 | (h1 << 16); pm.w = m0 | (m1 << 16); pl.w = l0 | (l1 << 16);
-        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
+        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + wbuf + q * 4;
         *reinterpret_cast<uint4*>(d) = ph;
         *reinterpret_cast<uint4*>(d + C::IN_PLANE_STRIDE) = pm;
         if constexpr (C::NPX == 3) *reinterpret_cast<uint4*>(d + 2 * C::IN_PLANE_STRIDE) = pl;
     };
-    auto store_in6_masked = [&](int c0, int k, const f32x4& r0, const f32x4& r1) __attribute__((always_inline)) {
+    auto store_in6_masked = [&](int c0, int k, const f32x4& r0, const f32x4& r1, const int wbuf = 0) __attribute__((always_inline)) {
         const bool ok0 = c0 < in6_clim[k], ok1 = c0 + 1 < in6_clim[k];
         float4 v0, v1;
         v0.x = ok0 ? r0.x : 0.f; v0.y = ok0 ? r0.y : 0.f; v0.z = ok0 ? r0.z : 0.f; v0.w = ok0 ? r0.w : 0.f;
         v1.x = ok1 ? r1.x : 0.f; v1.y = ok1 ? r1.y : 0.f; v1.z = ok1 ? r1.z : 0.f; v1.w = ok1 ? r1.w : 0.f;
-        store_in6(tid + k * C::NTHREADS, v0, v1);
+        store_in6(tid + k * C::NTHREADS, v0, v1, wbuf);
     };
-    auto stage_in6_direct = [&](int c0) {                             // global -> split -> LDS without overlap (prologue, odd strides)
+    auto stage_in6_direct = [&](int c0, const int wbuf = 0) {        // global -> split -> LDS without overlap (prologue, odd strides)
         if (p.vec4) {
             for (int q = tid; q < NQ6; q += C::NTHREADS) {
                 float4 v0, v1;
                 fetch_in6(c0, q, v0, v1);
-                store_in6(q, v0, v1);
+                store_in6(q, v0, v1, wbuf);
             }
         } else {
             constexpr int NE6 = (C::CK / 2) * C::KT * C::RH * C::XP;     // one word (pair, position) per iteration
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 unsigned int h0, m0, l0, h1, m1, l1;
                 split3(a0, h0, m0, l0);
                 split3(a1, h1, m1, l1);
-                unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q;
+                unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + wbuf + q;
                 d[0] = h0 | (h1 << 16);
                 d[C::IN_PLANE_STRIDE] = m0 | (m1 << 16);
                 if constexpr (C::NPX == 3) d[2 * C::IN_PLANE_STRIDE] = l0 | (l1 << 16);
@@ -689,17 +705,33 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     #pragma unroll
             for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if ((k + 1) * C::NTHREADS <= q1 - q0 || (k * C::NTHREADS < q1 - q0 && q < q1)) *reinterpret_cast<f32x4*>(w_lds + q * 4) = r[k]; }
         };
+        // the tile the next chunk's input goes to: the idle one of two (INDB), else the only one (then only between barriers)
         auto store_in6_all = [&](int c0) __attribute__((always_inline)) {
+            const int wbuf = C::INDB ? C::IN_FLOATS - ibuf : 0;
             if (p.vec4) {
+                if constexpr (!C::INDB) {
 #pragma unroll
-                for (int k = 0; k < IN_PT6; ++k) {
-                    const int q = tid + k * C::NTHREADS;
-                    if ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1]);
+                    for (int k = 0; k < IN_PT6; ++k) {
+                        const int q = tid + k * C::NTHREADS;
+                        if ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1], wbuf);
+                    }
                 }
-            } else stage_in6_direct(c0);
+            } else stage_in6_direct(c0, wbuf);
         };
-        // side loads of one phase: items [0, NI_) are input-tile piece pairs, [NI_, NI_ + NW) weight pieces; spread over the phase's
-        // first SPREAD steps (everything must have landed when the phase ends, unless the tile looks a chunk ahead)
+        auto store_in6_k = [&](int c0, const int k) __attribute__((always_inline)) {      // INDB: piece k, inside the MFMA stream
+            const int q = tid + k * C::NTHREADS;
+            if (p.vec4 && ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6)) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1], C::IN_FLOATS - ibuf);
+        };
+        auto swap_in6 = [&]() __attribute__((always_inline)) {
+            if constexpr (C::INDB) {
+                const int nb = C::IN_FLOATS - ibuf;
+#pragma unroll
+                for (int ni = 0; ni < C::NI; ++ni) b_ptr6[ni] += nb - ibuf;
+                ibuf = nb;
+            }
+        };
+        // side work of one phase, spread over its (k-group, mi) steps: global loads of the next chunk (input-tile piece pairs, then
+        // weight pieces) over the steps [0, NL), then (INDB) the split + LDS writes of the input pieces over the steps [NL, NS)
         auto side_items = [&](const int st, auto nspread_c, auto n_in_c, auto n_w_c, auto&& f_in, auto&& f_w) __attribute__((always_inline)) {
             constexpr int nspread = decltype(nspread_c)::value, n_in = decltype(n_in_c)::value, n_w = decltype(n_w_c)::value, n = n_in + n_w;
             if (st >= nspread || st < 0) return;
@@ -710,9 +742,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         constexpr int NSA = C::GA * C::MI, NSB = (C::G - C::GA) * C::MI, NSALL = C::G * C::MI;
         constexpr int NPA = (NWQ_A + C::NTHREADS - 1) / C::NTHREADS, NPB = (NWQ6 - NWQ_A + C::NTHREADS - 1) / C::NTHREADS;
         constexpr int NPALL = (NWQ6 + C::NTHREADS - 1) / C::NTHREADS;
-        constexpr bool SPRD = SS_X6_SPREAD && (C::WMODE != 0 || SS_X6_SPREAD > 1);     // (many-k-group tiles: no registers to spare inside the stream)
+        constexpr bool SPRD = SS_X6_SPREAD && (C::WMODE != 0 || C::F16 || SS_X6_SPREAD > 1);     // (bf16x6 many-k-group tiles: no registers to spare inside the stream)
         typedef std::integral_constant<int, C::GA> GAc;
         typedef std::integral_constant<int, C::G> Gc;
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, IN_PT6> INc;
         if (c_begin < c_end) {
             for (int q = tid; q < NWQ6; q += C::NTHREADS) *reinterpret_cast<float4*>(w_lds + q * 4) = *reinterpret_cast<const float4*>(w6_src(c_begin, q - tid));
             stage_in6_direct(c_begin);
@@ -724,6 +758,17 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         // in-order vmcnt wait -- which then waits for the loads just issued in front of it.
         typedef std::true_type Yes;
         typedef std::false_type No;
+        auto f_in_at = [&](const int cn) { return [&, cn](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); }; };
+        // INDB: the input pieces are split and written over the LAST steps of the chunk's last phase (their loads went out in its first)
+        auto in_stores = [&](const int st, const int ns, const int cn) __attribute__((always_inline)) {
+            if constexpr (C::INDB) {
+                constexpr int n = IN_PT6;
+                const int s0 = ns - min(ns, n);                        // one piece per step over the last min(ns, n) steps; the rest at the last one
+#pragma unroll
+                for (int k = 0; k < n; ++k)
+                    if (st == min(s0 + k, ns - 1)) store_in6_k(cn, k);
+            }
+        };
         if constexpr (C::SP) {
             // few k-groups per chunk (1x1 taps): one phase; the whole next chunk (weights + input tile) gathers in registers under
             // the chunk's MFMA stream.  Two barriers per chunk.
@@ -731,15 +776,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 constexpr bool more = decltype(more_c)::value;
                 const int cn = c0 + C::CK;
                 compute6(Q0{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + 1) / 2 : 1>{}, std::integral_constant<int, IN_PT6>{}, std::integral_constant<int, NPALL>{},
-                                         [&](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); },
-                                         [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
+                    if constexpr (more) {
+                        side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + 1) / 2 : 1>{}, INc{}, std::integral_constant<int, NPALL>{}, f_in_at(cn),
+                                   [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
+                        in_stores(st, NSALL, cn);
+                    }
                 });
                 __syncthreads();
                 if constexpr (more) {
                     store_w6(Q0{}, QE{}, rw6);
                     store_in6_all(cn);
                     __syncthreads();
+                    swap_in6();
                 }
             };
             int c0 = c_begin;
@@ -757,21 +805,22 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
                 const int cn = c0 + C::CK, cnn = c0 + 2 * C::CK;
                 compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSA : 1>{}, std::integral_constant<int, IN_PT6>{}, std::integral_constant<int, NPB>{},
-                                         [&](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); },
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSA : 1>{}, INc{}, std::integral_constant<int, NPB>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6b, k); });
                 });
                 __syncthreads();
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSB : 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NPA>{}, [](const int) {},
+                    if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + 1) / 2 : 1>{}, I0{}, std::integral_constant<int, NPA>{}, [](const int) {},
                                           [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cnn, Q0{}, QA{}, rw6, k); });
+                    if constexpr (more) in_stores(st, NSB, cn);
                 });
                 __syncthreads();
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6b);
                     store_in6_all(cn);
                     __syncthreads();
+                    swap_in6();
                 }
             };
             int c0 = c_begin;
@@ -786,21 +835,24 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 constexpr bool more = decltype(more_c)::value;
                 const int cn = c0 + C::CK;
                 compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + 1) / 2 : 1>{}, std::integral_constant<int, IN_PT6>{}, std::integral_constant<int, NPA>{},
-                                         [&](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); },
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + 1) / 2 : 1>{}, INc{}, std::integral_constant<int, NPA>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QA{}, rw6, k); });
                 });
                 __syncthreads();                                   // phase A's slots are idle
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + 1) / 2 : 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NPB>{}, [](const int) {},
-                                         [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
+                    if constexpr (more) {
+                        side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + 1) / 2 : 1>{}, I0{}, std::integral_constant<int, NPB>{}, [](const int) {},
+                                   [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
+                        in_stores(st, NSB, cn);
+                    }
                 });
                 __syncthreads();                                   // everyone is done with phase B's slots and this chunk's input tile
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6);
                     store_in6_all(cn);
                     __syncthreads();
+                    swap_in6();
                 }
             };
             int c0 = c_begin;
@@ -1636,6 +1688,9 @@ static int launch_split_family(ConvKParams& p, hipStream_t s, float* scratch, in
     if (cfg <= 0 || cfg > 2) {
         cfg = (num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
         if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
+        // f16x3 (tools/conv_sweep.py, T = 32): every x4 expansion of the encoder is ~10 % faster on the 128-voxel tile (64 -> 256 444 ->
+        // 403 us, 128 -> 512 263 -> 236, 512 -> 2048 128 -> 115)
+        if (BFV == 3 && p.Cout >= 4 * p.Cin) cfg = 2;
     }
     if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats);
     return launch_cfg<Y1Small>(p, s, scratch, scratch_floats);

@@ -266,6 +266,24 @@ extern "C" size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* 
     return (size_t)p.total * sizeof(float);
 }
 
+// Debugging aid (tests, tools): float offsets of the plan's buffers inside the workspace, in the order S0, X1, A, B, Cst[4], M1[4], M2, DS,
+// XS, L[4], FO[4], SK, total (25 values; -1 = not present).
+extern "C" int stemseg_hip_encoder_plan_offsets(const StemsegEncoderDesc* desc, int64_t* out25) {
+    EncoderPlan p;
+    int rc = make_encoder_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(out25, "encoder_plan_offsets: null pointer");
+    int n = 0;
+    out25[n++] = p.S0; out25[n++] = p.X1; out25[n++] = p.A; out25[n++] = p.B;
+    for (int i = 0; i < 4; ++i) out25[n++] = p.Cst[i];
+    for (int i = 0; i < 4; ++i) out25[n++] = p.M1[i];
+    out25[n++] = p.M2; out25[n++] = p.DS; out25[n++] = p.XS;
+    for (int i = 0; i < 4; ++i) out25[n++] = p.L[i];
+    for (int i = 0; i < 4; ++i) out25[n++] = p.FO[i];
+    out25[n++] = p.SK; out25[n++] = p.total;
+    return STEMSEG_OK;
+}
+
 extern "C" int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream) {
     EncoderPlan p;
     int rc = make_encoder_plan(desc, p);

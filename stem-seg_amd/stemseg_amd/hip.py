@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstemseg_hip.so")
+LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libstemseg_hip.so")      # (override: A/B builds of the library, tools/)
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
@@ -86,6 +86,7 @@ SIGNATURES = {
     "stemseg_hip_pack_conv_weight_bf16x3": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_packed_weight_bytes_split": (C.c_int64, [_I32, _I32, _I32, _I32]),
     "stemseg_hip_pack_conv_weight_split": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "stemseg_hip_encoder_plan_offsets": (C.c_int, [_P, _P]),
     "stemseg_hip_packed_weight_bytes_prec": (C.c_int64, [_I32, _I32, _I32, _I32]),
     "stemseg_hip_pack_conv_weight_prec": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
@@ -246,12 +247,13 @@ def pack_conv_weight(w):
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
-# MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision): "bf16x6" (default) =
-# every fp32 operand split EXACTLY into three bf16 terms, six products, fp32 accumulation -- fp32-level results (error vs an
-# fp64 convolution = that of the fp32-input MFMA kernel, tests/test_gpu_bf16x6.py; labels identical on every reference flow)
-# at ~1.5x the end-to-end rate; "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands; "bf16x3" = two-term split (~1e-4, opt-in).
-# STEMSEG_PRECISION overrides the default.
-DEFAULT_PRECISION = os.environ.get("STEMSEG_PRECISION", "bf16x6")
+# MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision).  "f16x3" (default) =
+# operands scaled by powers of two and split into two fp16 terms, three products, fp32 accumulation; "bf16x6" = every fp32 operand
+# split EXACTLY into three bf16 terms, six products (fp32's full exponent range, twice the matrix work).  Both give fp32-level
+# results: error vs an fp64 convolution = that of the fp32-input MFMA kernel on every kernel class (tests/test_gpu_bf16x6.py),
+# labels identical on every reference flow.  "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands; "bf16x3" = two-term bf16 split
+# (~1e-4, opt-in).  STEMSEG_PRECISION overrides the default.
+DEFAULT_PRECISION = os.environ.get("STEMSEG_PRECISION", "f16x3")
 assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
 
 

@@ -2,6 +2,7 @@
 the CPU oracle on the same seeded inputs, the reference-generated golden fixtures, and size-independent properties
 at BASELINE sizes.  Tolerances: float stages <= 1e-3 absolute (BASELINE.json north_star), most far tighter;
 integer outputs exact."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -258,7 +259,7 @@ def test_encoder_vs_golden(hip, golden, btype):
         assert report("encoder %s 1/%d (rel to max %.3g)" % (btype, s, scale), got / scale, ref / scale) <= 1e-4
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 def test_encoder_batch_of_8_odd_size_vs_oracle(hip, precision):
     """T = 8 frames, 96 x 160 (w32 = 5: ragged 32-column tiles everywhere), R-50, vs the CPU oracle."""
     from stemseg_amd.modeling.backbone import ResNetFPN
@@ -487,7 +488,7 @@ def test_seediness_decoder_vs_golden(hip, golden, T):
     assert np.array_equal(a, b), "decoder is not run-to-run deterministic"
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 def test_decoder_full_size_480x864_vs_oracle(hip, precision):
     """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle, both MFMA modes."""
     T, h32, w32 = 8, 15, 27
@@ -569,9 +570,15 @@ def test_step_batch_shares_the_encoder_pass(hip):
         for o, r in zip(outs2, outs):
             assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
         # two lanes: independent workspaces and streams, both steps in flight at once, results identical to one lane
-        g1 = pipe.capture(torch.cat(clips, 0), n_clips=3, lane=1)
+        pipe1 = pipe
+        if os.environ.get("STEMSEG_TEST_LANE1_PREC"):        # diagnostic: lane 1 on its own model instance in another conv precision
+            model1 = InferenceModel()
+            model1._model.load_state_dict(new)
+            model1.set_precision(os.environ["STEMSEG_TEST_LANE1_PREC"])
+            pipe1 = ClipPipeline(model1, seediness_thresh=0.5)
+        g1 = pipe1.capture(torch.cat(clips, 0), n_clips=3, lane=1)
         rev = torch.cat(clips[::-1], 0)
-        ref_rev = [{k: v.clone() for k, v in o.items() if torch.is_tensor(v)} for o in g.run(rev)]
+        ref_rev = [{k: v.clone() for k, v in o.items() if torch.is_tensor(v)} for o in (g.run(rev) if pipe1 is pipe else g1.run(rev))]
         torch.cuda.synchronize()
         for rep in range(3):
             a = g.run_async(torch.cat(clips, 0))
@@ -579,10 +586,46 @@ def test_step_batch_shares_the_encoder_pass(hip):
             g.wait()
             g1.wait()
             torch.cuda.synchronize()
-            for o, r in zip(a, outs):
-                assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
-            for o, r in zip(b, ref_rev):
-                assert torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"])
+            for (name, graph, inp, got, want, lane) in (("lane 0", g, torch.cat(clips, 0), a, outs, 0), ("lane 1", g1, rev, b, ref_rev, 1)):
+                same = all(torch.equal(o["emb"], r["emb"]) and torch.equal(o["labels"], r["labels"]) for o, r in zip(got, want))
+                if not same and pipe1 is pipe:            # localise: the encoder's outputs (the lane's zero-haloed FPN buffers) of this replay vs a lone replay
+                    conc = {k: [bf.clone() for bf, _ in v] for k, v in pipe.model._pads.items() if k[-1] == lane}
+                    bb = pipe.model._model.backbone
+                    ws_conc = {k: v.clone() for k, v in bb._ws.items() if k[4] == lane}
+                    graph.run(inp)
+                    torch.cuda.synchronize()
+                    ws_ref = {k: v.clone() for k, v in bb._ws.items() if k[4] == lane}
+                    other = torch.cat(clips, 0) if lane == 1 else rev          # the input this lane saw before (capture warm-up / other order)
+                    graph.run(other)
+                    torch.cuda.synchronize()
+                    ws_other = {k: v.clone() for k, v in bb._ws.items() if k[4] == lane}
+                    graph.run(inp)
+                    torch.cuda.synchronize()
+                    import ctypes as C
+                    names = ["S0", "X1", "A", "B"] + ["Cst%d" % i for i in range(4)] + ["M1_%d" % i for i in range(4)] + ["M2", "DS", "XS"] + \
+                            ["L%d" % i for i in range(4)] + ["FO%d" % i for i in range(4)] + ["SK", "total"]
+                    for k, v in bb._ws.items():
+                        if k[4] != lane:
+                            continue
+                        offs = (C.c_int64 * 25)()
+                        hip.check(hip.lib().stemseg_hip_encoder_plan_offsets(C.byref(bb._desc(k[0], k[1], k[2], 3)), offs))
+                        order = sorted((o, n) for o, n in zip(list(offs), names) if o >= 0)
+                        a32, b32 = v.view(torch.float32), ws_conc[k].view(torch.float32)
+                        for (o, n), (o2, _) in zip(order[:-1], order[1:]):
+                            d = (a32[o:o2] - b32[o:o2]).abs()
+                            nd = int((d > 0).sum())
+                            if nd:
+                                idx = torch.nonzero(d > 0).flatten()
+                                c32 = ws_other[k].view(torch.float32)[o:o2]
+                                stale = int(((b32[o:o2] == c32) & (d > 0)).sum())
+                                print("[lanes] rep %d %s encoder buffer %-5s: %d of %d floats differ (max %.3e), first at +%d, last at +%d; %d of them equal the "
+                                      "values of this lane's OTHER input order (stale data)" % (rep, name, n, nd, o2 - o, float(d.max()), int(idx[0]), int(idx[-1]), stale))
+                    for k, v in sorted(pipe.model._pads.items()):
+                        if k[-1] == lane:
+                            for lvl, ((bf, _), c) in enumerate(zip(v, conc[k])):
+                                d = (bf - c).abs()
+                                print("[lanes] rep %d %s slot %d FPN level %d: %d elements differ (max %.3e)" % (rep, name, k[4], lvl, int((d > 0).sum()), float(d.max())))
+                assert same, "%s: two pipelines in flight changed the result (rep %d)" % (name, rep)
     finally:
         config.load_preset("defaults")
 
@@ -596,7 +639,7 @@ def _semseg_head(ncls, fg, ws, inter=(128, 128, 64, 64)):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("name", ["sem_bin", "sem_kitti", "sem_ytvis"])
 def test_semseg_decoder_vs_golden(hip, golden, name, precision):
     """2 / 3+1 channels go through the fused heads kernel, 40+1 through the 1x1x1 MFMA conv (zero-padded to 64 rows)."""
@@ -1005,7 +1048,7 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 def test_config0_vs_reference_cpu_path(hip, golden, precision):
     """BASELINE configs[0] -- one synthetic 8 x 256 x 448 clip, random-init ResNet-50 -- through the whole HIP path (uint8 frames
     -> pre-processing -> encoder -> decoders -> fg mask -> gather -> clustering -> chainer) against what the REFERENCE itself
@@ -1027,7 +1070,7 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         model._model.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])).reshape(msd[k].shape) for k in msd})
         model = model.cuda()
         model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
-        exact = precision in ("f32", "bf16x6")        # bf16x6 = exact three-term split, six products: held to the fp32 standard
+        exact = precision in ("f32", "bf16x6", "f16x3")        # the split modes with fp32-level error are held to the fp32 standard
         tg = TrackGenerator(model, "davis", seediness_thresh=thr, frame_overlap=4)
         embeddings, fg, _ = tg.do_inference([f for f in frames])
         e = embeddings[0]
@@ -1057,7 +1100,7 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 def test_ytvis_flow_vs_reference(hip, golden, precision):
     """BASELINE configs[2] flow (reduced size) vs the REFERENCE's own CPU result (tests/golden/model_ytvis.npz): YouTube-VIS preset
     -- 7-channel embedding head with in-head seediness, 40+1-channel semseg head (inter [256]*4, wide head on the MFMA conv),
@@ -1079,7 +1122,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         model._model.load_state_dict(new)
         model = model.cuda()
         model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
-        exact = precision in ("f32", "bf16x6")        # bf16x6 = exact three-term split, six products: held to the fp32 standard
+        exact = precision in ("f32", "bf16x6", "f16x3")        # the split modes with fp32-level error are held to the fp32 standard
         frames = synth.synth_frames(12, 96, 128, seed=81)
         tg = TrackGenerator(model, "ytvis", resize_scale=4.0, frame_overlap=4)
         out = model([f for f in frames], g["subseqs"].tolist())
@@ -1125,7 +1168,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 def test_kitti_flow_vs_reference(hip, golden, precision):
     """KITTI-MOTS preset ('xyt' embeddings: the time coordinate is an embedding dimension, no free dims; in-head seediness; 3+1
     channel semseg head through the fused heads kernel) at a reduced wide-aspect size, 14 frames as three overlapping clips, vs
@@ -1146,7 +1189,7 @@ def test_kitti_flow_vs_reference(hip, golden, precision):
         model._model.load_state_dict(new)
         model = model.cuda()
         model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
-        exact = precision in ("f32", "bf16x6")        # bf16x6 = exact three-term split, six products: held to the fp32 standard
+        exact = precision in ("f32", "bf16x6", "f16x3")        # the split modes with fp32-level error are held to the fp32 standard
         frames = synth.synth_frames(14, 60, 190, seed=91)
         tg = TrackGenerator(model, "kittimots", frame_overlap=4)
         out = model([f for f in frames], g["subseqs"].tolist())
@@ -1347,7 +1390,7 @@ def test_clip_pipeline_step_on_semseg_presets(hip, preset):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("size", [(96, 160), (256, 448)])
 def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
     """One clip through ClipPipeline.step (the bench's unit of work) vs the oracle pipeline -- at a reduced size and at
