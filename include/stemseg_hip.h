@@ -107,8 +107,8 @@ typedef struct StemsegConvEpilogue {
                                       STEMSEG_PRECISION_F16X3: both operands are scaled by a power of two (activations by 2^-2,
                                       a layer's weights so that the largest lands in [2^13, 2^14)) and split into two fp16
                                       terms (hi + lo, 22 significand bits); the low activation term is stored as lo * 2^11
-                                      and meets hi_w * 2^-11 (made in registers), so every stored term is a normal fp16
-                                      number for 2.4e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a + hi_w*lo_a + hi_w*hi_a on the fp16
+                                      and meets hi_w * 2^-11 (made in registers), so hi is a normal fp16 number and the
+                                      pair keeps 22 bits (or 2^-36 absolute) for 2.5e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a + hi_w*lo_a + hi_w*hi_a on the fp16
                                       matrix cores, fp32 accumulation, accumulators scaled back exactly: the dropped lo*lo
                                       product and the split remainder are <= 2^-22 |a*b| -- measured below the rounding
                                       spread of fp32 accumulation orders -- at HALF the matrix work of bf16x6.  |a| >= 2.6e5

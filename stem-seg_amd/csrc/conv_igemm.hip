@@ -381,9 +381,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     // exact three-way split of an fp32 value into bf16 terms (both remainders are exact fp32 subtractions)
     auto split3 = [](const float x, unsigned int& h, unsigned int& m, unsigned int& l) {
         if constexpr (C::F16) {
-            // f16x3: x * 2^-2 = hi + lo with the low term stored as lo * 2^11 (the weights carry a hi * 2^-11 plane for it): both
-            // stored terms are normal fp16 numbers for 2.4e-4 <= |x| < 2.6e5 -- 22 significand bits there, a 2^-36 absolute floor
-            // below, inf above (and the result says so).  The accumulators are scaled back once, after the chunk loop.
+            // f16x3: x * 2^-2 = hi + lo with the low term stored as lo * 2^11 (the weights supply hi_w * 2^-11 for it): hi is a
+            // normal fp16 number for 2.5e-4 <= |x| < 2.6e5 and the pair keeps 22 significand bits there (2^-36 absolute when the low
+            // term is tiny, and below the range), inf above (and the result says so).  The accumulators are scaled back once, after the chunk loop.
             const float xs = x * STEMSEG_F16X3_ACT_SCALE;
             const _Float16 fh = (_Float16)xs;
             const _Float16 fl = (_Float16)((xs - (float)fh) * 2048.0f);
