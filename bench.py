@@ -390,7 +390,8 @@ def main():
                          "its small-map launches); decoders, fg gather and clustering run per clip.  1 = one clip per step")
     ap.add_argument("--lanes", type=int, default=3,
                     help="captured steps in flight on one GPU, each with its own workspaces and stream (graph mode): the kernels of "
-                         "one step fill the tail rounds and memory-bound phases of the other")
+                         "one step fill the tail rounds and memory-bound phases of the other (config.determinism reports whether every clip result of the run "
+                         "was bit-identical to the first one of its input batch)")
     ap.add_argument("--sequence", action="store_true",
                     help="BASELINE configs[3]: one long sequence, clips sharded over the ranks in contiguous blocks, RCCL all-gather of the head "
                          "outputs inside the timed region, replicated stitching (see the module docstring)")
@@ -456,7 +457,14 @@ def main():
     NC = max(1, args.clips_per_step)
     clips = [torch.cat([make_clip(1000 + rank * 97 + i * NC + c, device) for c in range(NC)], 0) for i in range(2)]
 
-    def read_back(outs):                               # the consumer's read-back (K, centres): one small D2H per clip
+    # Determinism monitor: the steps alternate between two clip batches, so every result of a batch must be bit-identical to the
+    # batch's first one, whichever lane produced it and whatever else was in flight.  Per clip one tiny device-side reduction (int64
+    # sum of the fp32 BIT PATTERNS of the embedding map: exact, order-independent), compared once after the timed region.
+    bitsums = {0: [], 1: []}
+
+    def read_back(outs, batch=None):                   # the consumer's read-back (K, centres): one small D2H per clip
+        if batch is not None:
+            bitsums[batch].append(torch.stack([o["emb"].view(torch.int32).sum(dtype=torch.int64) for o in outs]))
         return [hip.read_cluster_meta(o["meta"]) for o in outs][-1]
 
     def step(i):
@@ -493,6 +501,7 @@ def main():
             torch.cuda.synchronize()
 
     pending = [None] * len(lanes)
+    pending_batch = [None] * len(lanes)
 
     def step_graph(i):
         """Step i goes to lane i % L: first consume (read back) what that lane produced L steps ago, then enqueue the new
@@ -501,8 +510,9 @@ def main():
         m = None
         if pending[k] is not None:
             with torch.cuda.stream(lanes[k].stream):
-                m = read_back(pending[k])
+                m = read_back(pending[k], pending_batch[k])
         pending[k] = lanes[k].run_async(clips[i % len(clips)])
+        pending_batch[k] = i % len(clips)
         return m
 
     def drain():
@@ -510,7 +520,7 @@ def main():
         for k in range(len(lanes)):
             if pending[k] is not None:
                 with torch.cuda.stream(lanes[k].stream):
-                    m = read_back(pending[k])
+                    m = read_back(pending[k], pending_batch[k])
                 pending[k] = None
         return m
 
@@ -528,6 +538,19 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     mark("timed region done")
+    determinism = None
+    if graph is not None:
+        checked = mismatching = 0
+        for b, rows in bitsums.items():
+            if rows:
+                t = torch.stack([r.to(device) for r in rows]).cpu()
+                checked += int(t.numel())
+                mismatching += int((t != t[0:1]).sum())
+        determinism = {"clip_results_checked": checked, "mismatching": mismatching,
+                       "what": "int64 sum of the fp32 bit patterns of every clip's embedding map, every step since the first replay (pre-runs and "
+                               "timed region, %d lanes in flight), against the first result of the same input batch" % len(lanes)}
+        if mismatching:
+            print("[bench] WARNING: %d of %d clip results differ bitwise from the first result of their batch" % (mismatching, checked), file=sys.stderr)
     hip.profile_enable(True)
     prof_concurrent = hip.profile_read()
     # Roofline pass: under stream concurrency the per-launch elapsed times overlap and are not additive, so the dominant
@@ -594,7 +617,7 @@ def main():
             "dtype": PRECISION_DTYPE[args.precision],
             "data": "synthetic",
             "config": {"workload": WL["name"], "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
-                       "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)},
+                       "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}, "determinism": determinism,
                        "precision": {"mode": args.precision, "note": PRECISION_NOTE[args.precision]},
                        "switches": library_switches()},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s", "f16x3": "f16x3 on MFMA 32x32x16 f16; peak = 2500/3 fp32-equivalent TFLOP/s"}[args.precision],

@@ -129,8 +129,8 @@ struct ConvCfg {
     // X6 = the split-staged path (operands split once, when a chunk is staged): BF_ 2 = bf16x6 (three bf16 planes, six products),
     // BF_ 3 = f16x3 (two fp16 planes of the SCALED operand, three products)
     static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ >= 2, F16 = BF_ == 3, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
-    static constexpr int NPL = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged weights (f16x3: hi, lo; hi * 2^-11 is made in registers)
-    static constexpr int NPA = BF_ >= 2 ? 3 : 2;                        // A operands of a k-group step
+    static constexpr int NPL = BF_ >= 2 ? 3 : 2;                        // 16-bit planes of the staged weights (f16x3: hi, lo, hi * 2^-11)
+    static constexpr int NPA = NPL;                                     // A operands of a k-group step
     static constexpr int NPX = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged input tile (f16x3: hi, lo * 2^11)
     static constexpr int NPROD = BF_ == 2 ? 6 : 3;                      // MFMAs per (A fragment, B fragment) pair
     static constexpr int PMAX = PMAX_;
@@ -158,7 +158,7 @@ struct ConvCfg {
     static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
     // X6 weight staging of tiles with few k-groups per chunk (1x1 taps; a phase's MFMA stream is shorter than a global load):
     // 0 two phases, registers refilled per phase; 1 one phase, whole slab in registers; 2 two phases, one chunk of lookahead
-    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : ((BF_ == 3 || WM * WN >= 8 || MI * NI < 8) ? 2 : 0)) : 0;
+    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : ((WM * WN >= 8 || MI * NI < 8) ? 2 : 0)) : 0;
     // (bf16x6, 128 co x 256 voxels on four waves: the second register set of mode 2 spills)
     static constexpr bool SP = WMODE == 1, LA = WMODE == 2;
     // split-staged tiles keep TWO input tiles where LDS allows (160 KB for a lone eight-wave workgroup, 80 KB for two four-wave ones):
@@ -549,9 +549,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         // smallest products first (planes: 0 hi, 1 mid / lo, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
         auto mm = [&](const int mi, h16x8 (&a)[NPA], const h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
             if constexpr (C::F16) {
-                // the weights' hi * 2^-11 operand (it meets the input tile's lo * 2^11 plane) is made here: four packed multiplies in the
-                // shadow of the MFMAs instead of a third plane in LDS (a third of the A reads, of the slab and of its staging traffic)
-                a[2] = a[0] * (h16)(1.0f / 2048.0f);
+                // (every MFMA operand comes straight from LDS.  Making hi_w * 2^-11 here with four v_pk_mul_f16 per step saved a third
+                // of the slab and 5 % of the step, but a VALU write into a register quad that MFMAs issued two or three instructions
+                // earlier still read is a hazard neither the hardware nor the compiler covers: with two or three pipelines in flight
+                // 1 % of the clip results stopped being bit-identical run to run, 20 % with the multiplies moved one MFMA closer --
+                // bench.py's determinism monitor)
 #define SS_X6_TERM(PA, PB)                                                                                                     \
     _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
@@ -1287,10 +1289,10 @@ __global__ void pack_conv_weight_bf16x6_kernel(const float* __restrict__ w, uint
     }
 }
 
-// f16x3 packing: the split slab order with two fp16 planes, [G][hi|lo][half][Cout][8 fp16] of w * S, S = 2^(13 -
-// floor(log2(max|w|))) -- the layer's largest weight lands in [2^13, 2^14), so both terms (and the hi * 2^-11 operand the kernel
-// derives for the input tile's lo * 2^11 plane) of every weight within 2^-16 of it are normal fp16 numbers.  16 bytes behind the
-// last slab: { 1 / (S * activation scale), bits of max|w|, S, 0 }; the conv kernel multiplies its accumulators by the first.
+// f16x3 packing: the bf16x6 slab order with fp16 planes [G][hi|lo|hi * 2^-11][half][Cout][8 fp16] of w * S, S = 2^(13 -
+// floor(log2(max|w|))) -- the layer's largest weight lands in [2^13, 2^14), so all three terms of every weight within 2^-16 of it
+// are normal fp16 numbers (the third plane multiplies the input tile's lo * 2^11 term).  16 bytes behind the last slab:
+// { 1 / (S * activation scale), bits of max|w|, S, 0 }; the conv kernel multiplies its accumulators by the first.
 __global__ void absmax_bits_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ out) {
     unsigned int m = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -1310,7 +1312,7 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
                                                int CK, int TPG) {
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
     const int nchunks = (Cin + CK - 1) / CK;
-    const int64_t n = (int64_t)nchunks * G * 2 * 2 * Cout;
+    const int64_t n = (int64_t)nchunks * G * 3 * 2 * Cout;
     unsigned int* tail = reinterpret_cast<unsigned int*>(packed + n);
     const float S = f16x3_weight_scale(tail[1]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1323,8 +1325,8 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
         int64_t r = i / Cout;
         const int h = (int)(r & 1);
         r >>= 1;
-        const int pl = (int)(r & 1);
-        r >>= 1;
+        const int pl = (int)(r % 3);
+        r /= 3;
         const int grp = (int)(r % G);
         const int chunk = (int)(r / G);
         const int cg = grp / NTG, tg = grp % NTG;
@@ -1336,7 +1338,8 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
             if (tap < taps && ci < Cin) x = w[((int64_t)co * Cin + ci) * taps + tap] * S;
             const _Float16 hi = (_Float16)x;
             const _Float16 lo = (_Float16)(x - (float)hi);
-            const _Float16 pick = pl == 0 ? hi : lo;
+            const _Float16 his = (_Float16)((float)hi * (1.0f / 2048.0f));
+            const _Float16 pick = pl == 0 ? hi : (pl == 1 ? lo : his);
             v[j] = *reinterpret_cast<const unsigned short*>(&pick);
         }
         uint4 o;
@@ -1938,7 +1941,7 @@ extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
     if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2);
     if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3);
-    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2) + 16;      // two planes + the scale record
+    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) + 16;      // three planes + the scale record
     return 0;
 }
 
