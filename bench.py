@@ -349,7 +349,7 @@ PRECISION_NOTE = {
               "tile / epilogue (tests/test_gpu_bf16x6.py); labels identical to the reference's own CPU results on its flows (tests/test_gpu_parity.py) "
               "and to the CPU oracle at full size in THIS run (cpu_baseline.parity_vs_hip_path); --precision f32 runs the fp32-input MFMA kernels",
     "f16x3": "every fp32 operand is scaled by a power of two (activations 2^-2; a layer's weights so that the largest lands in [2^13, 2^14)) and "
-             "split into two fp16 terms (22 significand bits; the low activation term is stored as lo * 2^11 against a hi * 2^-11 weight plane, so "
+             "split into two fp16 terms (22 significand bits; the low activation term is stored as lo * 2^11 against a hi * 2^-11 weight plane (all MFMA operands straight from LDS), so "
              "the pair keeps 22 bits, or 2^-36 absolute, for 2.5e-4 <= |a| < 2.6e5); lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 "
              "accumulation, accumulators scaled back exactly.  The dropped lo*lo product and the split remainder are <= 2^-22 |a*b|: measured "
              "against an fp64 convolution the error stays at the fp32-input MFMA kernel's own level on every kernel class / tile / epilogue and "

@@ -107,7 +107,7 @@ typedef struct StemsegConvEpilogue {
                                       STEMSEG_PRECISION_F16X3: both operands are scaled by a power of two (activations by 2^-2,
                                       a layer's weights so that the largest lands in [2^13, 2^14)) and split into two fp16
                                       terms (hi + lo, 22 significand bits); the low activation term is stored as lo * 2^11
-                                      and meets hi_w * 2^-11 (made in registers), so hi is a normal fp16 number and the
+                                      and meets a third weight plane, hi_w * 2^-11, so hi is a normal fp16 number and the
                                       pair keeps 22 bits (or 2^-36 absolute) for 2.5e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a + hi_w*lo_a + hi_w*hi_a on the fp16
                                       matrix cores, fp32 accumulation, accumulators scaled back exactly: the dropped lo*lo
                                       product and the split remainder are <= 2^-22 |a*b| -- measured below the rounding
@@ -124,7 +124,7 @@ int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Co
 /* planes = 2: the bf16x3 packing above; planes = 3: the bf16x6 packing (hi | mid | lo planes per k-group). */
 int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes);
 int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream);
-/* By precision code (1, 2: the packings above; 3: two fp16 planes of the scaled weights + a 16-byte scale record). */
+/* By precision code (1, 2: the packings above; 3: three fp16 planes of the scaled weights (hi, lo, hi * 2^-11) + a 16-byte scale record). */
 int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision);
 int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t precision, void* stream);
 /* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).

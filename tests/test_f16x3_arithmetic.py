@@ -27,7 +27,7 @@ def f16x3_matmul(w, x):
     ws = w * S
     wh = f16(ws)
     wl = f16(ws - wh)
-    whs = f16(wh * np.float32(2.0 ** -11))                  # made in registers by v_pk_mul_f16
+    whs = f16(wh * np.float32(2.0 ** -11))                  # the third packed weight plane
     xs = x * np.float32(ACT_SCALE)
     xh = f16(xs)
     xl = f16((xs - xh) * np.float32(2048.0))
