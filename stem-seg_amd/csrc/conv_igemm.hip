@@ -41,20 +41,20 @@
 #define STEMSEG_F16X3_ACT_SCALE 0.25f
 
 #ifndef SS_X6_WMODE_SMALLG
-#define SS_X6_WMODE_SMALLG -1      // -1: mode 2 wherever its second register set fits (mode 1 measured 2-5 % faster on the f16x3 1x1 tiles;
-                                  // not used, see SS_X6_SPREAD)
+#define SS_X6_WMODE_SMALLG -1      // -1: mode 2 wherever its second register set fits (mode 1 measured 2-5 % faster on the f16x3 1x1 tiles when
+                                  // that kernel still made an operand in registers; not re-measured since, see SS_X6_SPREAD)
 #endif
 #ifndef SS_X6_SPREAD
 #define SS_X6_SPREAD 0             // 1: the next chunk's global loads go out a few per (k-group, mi) step instead of at the top of the phase.
-                                  // Measured 1-3 % faster on every class, but OFF: with it (and with weight modes 0 / 1 on the f16x3 1x1
-                                  // tiles) two pipelines in flight on two streams stop being bit-identical to a lone one about every second
-                                  // run of tests/test_gpu_parity.py::test_step_batch_shares_the_encoder_pass -- a short run of wrong values in
-                                  // the OTHER lane's buffers (once the fp32 stem's output), never with one pipeline, never in this
-                                  // configuration (16 / 16 clean runs per precision).  Hazard probes (tools/microbench/*_war_probe.hip) are
-                                  // negative; the cause is not understood -- see DESIGN.md section 10
+                                  // Measured 1-3 % faster on every class, but OFF: the loads' address arithmetic is VALU inside the MFMA
+                                  // stream, the register allocator hands it fragment registers the MFMAs issued just before still read,
+                                  // and nothing orders a VALU write behind an issued MFMA's operand read -- with several pipelines in flight
+                                  // results stopped being bit-identical run to run (DESIGN.md sections 5c / 10).  Rule: no VALU in the k-loop.
 #endif
 #ifndef SS_X6_INDB
-#define SS_X6_INDB 0
+#define SS_X6_INDB 0               // 1: two input tiles in LDS, the next chunk's split + ds_writes between the MFMAs of the running one.  Measured
+                                  // 0 ... -4 % (the store section between the barriers is not what the kernel waits for) -- and it is VALU
+                                  // inside the MFMA stream (see SS_X6_SPREAD): off, kept for the record
 #endif
 
 namespace stemseg {
