@@ -65,6 +65,21 @@ def test_cabi_struct_sizes_and_argument_errors():
     assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0 and b"whole clips" in l.stemseg_hip_last_error()
     e.n_clips, e.W = 4, 850                                           # frame size must be padded to multiples of 32
     assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0
+    # packed weight sizes per precision (pure host arithmetic): chunks x k-groups x planes x [half][Cout] 16-B pieces (+ the f16x3 scale record)
+    split2, split3 = l.stemseg_hip_packed_weight_bytes_split(128, 256, 27, 2), l.stemseg_hip_packed_weight_bytes_split(128, 256, 27, 3)
+    assert split3 == 64 * 7 * 3 * 2 * 128 * 16 and split2 * 3 == split3 * 2
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x3"]) == split2
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x6"]) == split3
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) == split3 + 16
+    assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) == 32 * 2 * 3 * 2 * 256 * 16 + 16
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f32"]) == 0 and l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 7) == 0
+    # encoder plan offsets (debugging aid): distinct offsets, the first buffer at 0, the last value = the workspace size in floats
+    e.n_clips, e.W = 4, 864
+    offs = (ctypes.c_int64 * 25)()
+    assert l.stemseg_hip_encoder_plan_offsets(ctypes.byref(e), offs) == 0
+    present = [o for o in offs if o >= 0]
+    assert len(set(present)) == len(present) == 21 and min(present) == 0 and offs[24] == max(present) and \
+        offs[24] * 4 == l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e))            # (no FO buffers: the clips of this pass do not overlap)
     # mask materialisation: the crop must fit the up-sampled mask (davis.py:91-96 raises the same way)
     rc = l.stemseg_hip_resample_instance_masks(ctypes.c_void_p(16), 24, 32, ctypes.c_float(4.0), 97, 128, 70, 100, ctypes.c_void_p(16), None)
     assert rc != 0 and b"should be <= padded dims" in l.stemseg_hip_last_error()
