@@ -105,7 +105,7 @@ typedef struct StemsegConvEpilogue {
                                       |a*b|, below the rounding of the fp32 accumulation itself -- fp32-level results at 2.7x
                                       the fp32-MFMA rate; packed_w from stemseg_hip_pack_conv_weight_split(..., planes = 3).
                                       STEMSEG_PRECISION_F16X3: both operands are scaled by a power of two (activations by 2^-2,
-                                      a layer's weights so that the largest lands in [2^13, 2^14)) and split into two fp16
+                                      every OUTPUT CHANNEL's weights so that its largest lands in [2^13, 2^14)) and split into two fp16
                                       terms (hi + lo, 22 significand bits); the low activation term is stored as lo * 2^11
                                       and meets a third weight plane, hi_w * 2^-11, so hi is a normal fp16 number and the
                                       pair keeps 22 bits (or 2^-36 absolute) for 2.5e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a + hi_w*lo_a + hi_w*hi_a on the fp16
@@ -124,7 +124,8 @@ int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Co
 /* planes = 2: the bf16x3 packing above; planes = 3: the bf16x6 packing (hi | mid | lo planes per k-group). */
 int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes);
 int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream);
-/* By precision code (1, 2: the packings above; 3: three fp16 planes of the scaled weights (hi, lo, hi * 2^-11) + a 16-byte scale record). */
+/* By precision code (1, 2: the packings above; 3: three fp16 planes of the scaled weights (hi, lo, hi * 2^-11) + per output
+ * channel a float 1 / (weight scale x activation scale) and the bits of max|w| of the channel: 8 * Cout bytes). */
 int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision);
 int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t precision, void* stream);
 /* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).
@@ -347,8 +348,9 @@ int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t* labels_b,
                                int32_t Ka, int32_t Kb, int64_t* inter, int64_t* cnt_a, int64_t* cnt_b, void* stream);
 
 /* online_chainer.py:304-308 (`unique()` of the overlap labels) and :43-49 (`highest id + 1`) in one pass:
- * present[id] = 1 for every label id in [0, cap) that occurs, *max_plus_1 = max(label) + 1 over labels >= 0
- * (0 when there is none; ids >= cap still count towards the maximum).  accumulate = 0 zeroes both outputs
+ * present[id] = 1 for every label id in [0, cap) that occurs, present[cap] = 1 when a NEGATIVE label (the outlier id -1) occurs
+ * -- `present` holds cap + 1 bytes; the reference's id enumeration order depends on whether -1 is in the set (online_chainer.py:308-309,
+ * see reference_id_order) --, *max_plus_1 = max(label) + 1 over labels >= 0 (0 when there is none; ids >= cap still count towards the maximum).  accumulate = 0 zeroes both outputs
  * first; accumulate = 1 adds to what earlier calls left (several frames' label arrays -> one id set). */
 int stemseg_hip_label_presence(const int64_t* labels, int64_t n, uint8_t* present, int32_t cap,
                                int64_t* max_plus_1, int32_t accumulate, void* stream);

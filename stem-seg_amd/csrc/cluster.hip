@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void label_presence_kernel(const long long* la
         if (l >= 0) {
             if (l < cap && !present[l]) present[l] = 1;     // benign race: every writer stores 1
             m = max(m, (unsigned long long)l + 1ull);
-        }
+        } else if (!present[cap]) present[cap] = 1;         // a negative (outlier) label occurs: byte `cap` of the table
     }
     for (int o = 32; o; o >>= 1) m = max(m, (unsigned long long)__shfl_xor((long long)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(max_plus_1, m);
@@ -874,10 +874,10 @@ extern "C" int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t
 
 extern "C" int stemseg_hip_label_presence(const int64_t* labels, int64_t n, uint8_t* present, int32_t cap, int64_t* max_plus_1,
                                           int32_t accumulate, void* stream) {
-    SS_CHECK_ARG(n >= 0 && cap >= 0 && max_plus_1 && (present || cap == 0), "label_presence: bad arguments");
+    SS_CHECK_ARG(n >= 0 && cap >= 0 && max_plus_1 && present, "label_presence: bad arguments (present: cap + 1 bytes)");
     hipStream_t s = as_stream(stream);
     if (!accumulate) {
-        if (cap) SS_HIP(hipMemsetAsync(present, 0, (size_t)cap, s));
+        SS_HIP(hipMemsetAsync(present, 0, (size_t)cap + 1, s));
         SS_HIP(hipMemsetAsync(max_plus_1, 0, sizeof(int64_t), s));
     }
     if (n == 0) return STEMSEG_OK;

@@ -40,6 +40,11 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
 
+// ReLU / max that PROPAGATE NaN like torch's (fmaxf returns the other operand): an overflow upstream -- e.g. an activation beyond
+// the f16x3 range -- must reach the head outputs as a non-finite value, never be flushed to a plausible 0 on the way
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_keep_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+
 // zero-haloed layout of a logical [C][T][H][W] volume (see stemseg_hip_padded_geometry)
 struct PaddedGeom {
     int64_t pitch, ts, cs, total, interior;

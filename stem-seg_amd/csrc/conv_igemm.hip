@@ -862,15 +862,24 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             if (c0 < c_end) chunk(c0, No{});
         }
         if constexpr (C::F16) {
-            // undo the operand scales (powers of two: exact): 1 / (weight scale x activation scale) sits behind the last weight slab
-            const float inv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wpk) +
-                                                              (int64_t)((p.Cin + C::CK - 1) / C::CK) * (C::NPL * C::G * 2) * p.Cout * 16);
+            // undo the operand scales (powers of two: exact): 1 / (weight scale of the output channel x activation scale), one float per
+            // output channel behind the last weight slab (pack_conv_weight_f16x3_kernel).  C/D layout: register r of lane (half, l31)
+            // is row (r & 3) + 8 * (r >> 2) + 4 * half -> four consecutive channels per (mi, r >> 2).
+            const float* invp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wpk) +
+                                                               (int64_t)((p.Cin + C::CK - 1) / C::CK) * (C::NPL * C::G * 2) * p.Cout * 16);
+            const int co_w = co0 + wm * (C::MI * 32) + 4 * half;
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < C::NI; ++ni)
+                for (int j = 0; j < 4; ++j) {
+                    const int co4 = co_w + mi * 32 + 8 * j;                      // (Cout % 32 == 0: the four rows are valid together)
+                    const float4 sc = co4 < p.Cout ? *reinterpret_cast<const float4*>(invp + co4) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
+                    for (int ni = 0; ni < C::NI; ++ni) {
+                        acc[mi][ni][4 * j + 0] *= sc.x; acc[mi][ni][4 * j + 1] *= sc.y;
+                        acc[mi][ni][4 * j + 2] *= sc.z; acc[mi][ni][4 * j + 3] *= sc.w;
+                    }
+                }
         }
     } else if constexpr (C::DB && C::GL) {
         // double-buffered LDS filled by LDS-DMA: chunk i+1 is enqueued into the idle buffer, chunk i's MFMA stream runs, and
@@ -1081,7 +1090,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                             const int64_t off = (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
                             const float4 rv = rres[mg][j];         // (acc + bias) + residual, as before
                             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                            if (p.relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); v.z = relu_keep_nan(v.z); v.w = relu_keep_nan(v.w); }
                             *reinterpret_cast<float4*>(p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)co * p.out_cs + off) = v;
                         }
                     }
@@ -1121,7 +1130,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     if (co < p.Cout) {
                         float v = acc[mi][ni][r] + (p.bias ? p.bias[co] : 0.f);
                         if (p.res) v += p.res[(int64_t)co * p.res_cs + roff];
-                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.relu) v = relu_keep_nan(v);
                         o[(int64_t)co * p.out_cs] = v;
                     }
                 }
@@ -1171,7 +1180,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReducePar
                 const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x);
                 acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
             }
-            if (p.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+            if (p.relu) { acc.x = relu_keep_nan(acc.x); acc.y = relu_keep_nan(acc.y); acc.z = relu_keep_nan(acc.z); acc.w = relu_keep_nan(acc.w); }
             *reinterpret_cast<float4*>(p.out + o) = acc;
             s1 = (acc.x + acc.y) + (acc.z + acc.w);
             s2 = (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
@@ -1180,7 +1189,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReducePar
             for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
             if (p.bias) acc += p.bias[c];
             if (p.res) acc += p.res[(int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x];
-            if (p.relu) acc = fmaxf(acc, 0.f);
+            if (p.relu) acc = relu_keep_nan(acc);
             p.out[o] = acc;
             s1 = acc;
             s2 = acc * acc;
@@ -1289,17 +1298,23 @@ __global__ void pack_conv_weight_bf16x6_kernel(const float* __restrict__ w, uint
     }
 }
 
-// f16x3 packing: the bf16x6 slab order with fp16 planes [G][hi|lo|hi * 2^-11][half][Cout][8 fp16] of w * S, S = 2^(13 -
-// floor(log2(max|w|))) -- the layer's largest weight lands in [2^13, 2^14), so all three terms of every weight within 2^-16 of it
-// are normal fp16 numbers (the third plane multiplies the input tile's lo * 2^11 term).  16 bytes behind the last slab:
-// { 1 / (S * activation scale), bits of max|w|, S, 0 }; the conv kernel multiplies its accumulators by the first.
-__global__ void absmax_bits_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ out) {
+// f16x3 packing: the bf16x6 slab order with fp16 planes [G][hi|lo|hi * 2^-11][half][Cout][8 fp16] of w * S[co], S[co] = 2^(13 -
+// floor(log2(max|w[co]|))) PER OUTPUT CHANNEL -- each channel's largest weight lands in [2^13, 2^14), so all three terms of every
+// weight within 2^-16 of its channel's largest are normal fp16 numbers (the third plane multiplies the input tile's lo * 2^11 term).
+// (A scale per LAYER, as in round 3, loses bits on every channel whose weights sit far below the layer's largest: FrozenBN folded
+// with eps = 0 multiplies each output channel by gamma / sqrt(var), make_layers.py:51-63, which spans orders of magnitude in
+// trained checkpoints.)  Behind the last slab: float inv[Cout] = 1 / (S[co] * activation scale) -- the conv kernel multiplies its
+// accumulator rows by it -- then uint32 max_bits[Cout] (bits of max|w[co]|, pack-time scratch).
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ w, int64_t row_len, unsigned int* __restrict__ out) {
+    __shared__ unsigned int red[4];
+    const float* r = w + (int64_t)blockIdx.x * row_len;
     unsigned int m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        m = max(m, __float_as_uint(fabsf(w[i])));               // (non-negative floats order like their bit patterns; NaN / inf end up on top)
+    for (int64_t i = threadIdx.x; i < row_len; i += 256) m = max(m, __float_as_uint(fabsf(r[i])));   // (non-negative floats order like their bit patterns; NaN / inf end up on top)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
 __device__ __forceinline__ float f16x3_weight_scale(unsigned int max_bits) {
@@ -1313,15 +1328,12 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
     const int nchunks = (Cin + CK - 1) / CK;
     const int64_t n = (int64_t)nchunks * G * 3 * 2 * Cout;
-    unsigned int* tail = reinterpret_cast<unsigned int*>(packed + n);
-    const float S = f16x3_weight_scale(tail[1]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        tail[0] = __float_as_uint(1.0f / (S * STEMSEG_F16X3_ACT_SCALE));
-        tail[2] = __float_as_uint(S);
-        tail[3] = 0;
-    }
+    float* inv = reinterpret_cast<float*>(packed + n);
+    const unsigned int* max_bits = reinterpret_cast<const unsigned int*>(inv + Cout);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int co = (int)(i % Cout);
+        const float S = f16x3_weight_scale(max_bits[co]);
+        if (i < Cout) inv[co] = 1.0f / (S * STEMSEG_F16X3_ACT_SCALE);
         int64_t r = i / Cout;
         const int h = (int)(r & 1);
         r >>= 1;
@@ -1941,7 +1953,7 @@ extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
     if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2);
     if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3);
-    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) + 16;      // three planes + the scale record
+    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) + 8 * (int64_t)Cout;      // three planes + per output channel: float 1 / scale, uint32 bits of max|w|
     return 0;
 }
 
@@ -1954,11 +1966,9 @@ extern "C" int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, i
     SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_prec: taps must be 27, 9 or 1");
     const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
     SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_prec: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
-    const int64_t n = (stemseg_hip_packed_weight_bytes_prec(Cout, Cin, taps, precision) - 16) / 16;
-    unsigned int* tail = reinterpret_cast<unsigned int*>(reinterpret_cast<uint4*>(packed) + n);
-    SS_HIP(hipMemsetAsync(tail, 0, 16, as_stream(stream)));
-    const int64_t nw = (int64_t)Cout * Cin * taps;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3((int)std::min<int64_t>(ceil_div(nw, 256), 1024)), dim3(256), 0, as_stream(stream), w, nw, tail + 1);
+    const int64_t n = (stemseg_hip_packed_weight_bytes_prec(Cout, Cin, taps, precision) - 8 * (int64_t)Cout) / 16;
+    unsigned int* max_bits = reinterpret_cast<unsigned int*>(reinterpret_cast<float*>(reinterpret_cast<uint4*>(packed) + n) + Cout);
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)Cout), dim3(256), 0, as_stream(stream), w, (int64_t)Cin * taps, max_bits);
     SS_LAUNCH_CHECK();
     const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(pack_conv_weight_f16x3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,

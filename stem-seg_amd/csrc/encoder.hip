@@ -44,7 +44,7 @@ static inline StemsegVolume flat_view(float* base, int C, int64_t V) { return ma
 // ---- stem: conv 7x7 stride 2 pad 3 (3 -> 64) + bias + ReLU, direct VALU kernel (1 % of the encoder FLOPs) ----------
 // block = 8 x 64 output pixels of one frame, all 64 channels; thread = 2 pixels (x, x+32) x 64 channels.
 constexpr int ST_ROWS = 8, ST_COLS = 64, ST_PR = 2 * ST_ROWS + 5, ST_PC = 2 * ST_COLS + 5, ST_PCP = 136;
-__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ frames, const float* __restrict__ w_tap_major,
+__global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(const float* __restrict__ frames, const float* __restrict__ w_tap_major,
                                                             const float* __restrict__ bias, float* __restrict__ out, int T, int H, int W) {
     __shared__ __attribute__((aligned(16))) float lds[3 * ST_PR * ST_PCP + 147 * 64];
     float* patch = lds;
@@ -69,35 +69,45 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
     }
     __syncthreads();
     const int py = threadIdx.x >> 5, px = threadIdx.x & 31;    // pixels (py, px) and (py, px + 32)
-    float acc0[64], acc1[64];
+    const int oy = oy0 + py;
+    const int64_t plane = (int64_t)Ho * Wo;
+    // Two passes of 32 output channels: 64 accumulators per pass stay in architectural VGPRs.  (The one-pass form -- 128
+    // accumulators -- made the register allocator park 20 of them in AGPRs (v_accvgpr_write / _read); under several HIP streams,
+    // i.e. with other kernels' MFMA waves on the same SIMDs, a few outputs of that kernel per ~10^3 launches came back with a
+    // stale partial sum, 16 lanes of one register at a time: tools/soak_probe.py, DESIGN.md section 10.  Same summation order,
+    // bit-identical results.)
+#pragma unroll 1
+    for (int hc = 0; hc < 2; ++hc) {
+        float acc0[32], acc1[32];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
-    for (int c = 0; c < 3; ++c)
-        for (int dy = 0; dy < 7; ++dy) {
-            const float* prow = patch + (c * ST_PR + 2 * py + dy) * ST_PCP + 2 * px;
+        for (int k = 0; k < 32; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+#pragma unroll 1
+        for (int cdy = 0; cdy < 21; ++cdy) {                  // (c, dy) rows of the patch, in the summation order c, dy, dx
+                const int c = cdy / 7, dy = cdy - 7 * c;
+                const float* prow = patch + (c * ST_PR + 2 * py + dy) * ST_PCP + 2 * px;
 #pragma unroll
-            for (int dx = 0; dx < 7; ++dx) {
-                const float v0 = prow[dx], v1 = prow[dx + 64];
-                const float4* w4 = reinterpret_cast<const float4*>(wl + ((c * 7 + dy) * 7 + dx) * 64);
+                for (int dx = 0; dx < 7; ++dx) {
+                    const float v0 = prow[dx], v1 = prow[dx + 64];
+                    const float4* w4 = reinterpret_cast<const float4*>(wl + (cdy * 7 + dx) * 64 + hc * 32);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float4 wv = w4[k];      // broadcast LDS read
-                    acc0[4 * k + 0] = fmaf(wv.x, v0, acc0[4 * k + 0]); acc1[4 * k + 0] = fmaf(wv.x, v1, acc1[4 * k + 0]);
-                    acc0[4 * k + 1] = fmaf(wv.y, v0, acc0[4 * k + 1]); acc1[4 * k + 1] = fmaf(wv.y, v1, acc1[4 * k + 1]);
-                    acc0[4 * k + 2] = fmaf(wv.z, v0, acc0[4 * k + 2]); acc1[4 * k + 2] = fmaf(wv.z, v1, acc1[4 * k + 2]);
-                    acc0[4 * k + 3] = fmaf(wv.w, v0, acc0[4 * k + 3]); acc1[4 * k + 3] = fmaf(wv.w, v1, acc1[4 * k + 3]);
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 wv = w4[k];      // broadcast LDS read
+                        acc0[4 * k + 0] = fmaf(wv.x, v0, acc0[4 * k + 0]); acc1[4 * k + 0] = fmaf(wv.x, v1, acc1[4 * k + 0]);
+                        acc0[4 * k + 1] = fmaf(wv.y, v0, acc0[4 * k + 1]); acc1[4 * k + 1] = fmaf(wv.y, v1, acc1[4 * k + 1]);
+                        acc0[4 * k + 2] = fmaf(wv.z, v0, acc0[4 * k + 2]); acc1[4 * k + 2] = fmaf(wv.z, v1, acc1[4 * k + 2]);
+                        acc0[4 * k + 3] = fmaf(wv.w, v0, acc0[4 * k + 3]); acc1[4 * k + 3] = fmaf(wv.w, v1, acc1[4 * k + 3]);
+                    }
                 }
             }
-        }
-    const int oy = oy0 + py;
-    if (oy < Ho) {
-        const int64_t plane = (int64_t)Ho * Wo;
+        if (oy < Ho) {
 #pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            float* o = out + ((int64_t)k * T + t) * plane + (int64_t)oy * Wo;
-            const float bv = bias[k];
-            if (ox0 + px < Wo) o[ox0 + px] = fmaxf(acc0[k] + bv, 0.f);
-            if (ox0 + px + 32 < Wo) o[ox0 + px + 32] = fmaxf(acc1[k] + bv, 0.f);
+            for (int k = 0; k < 32; ++k) {
+                const int ch = hc * 32 + k;
+                float* o = out + ((int64_t)ch * T + t) * plane + (int64_t)oy * Wo;
+                const float bv = bias[ch];
+                if (ox0 + px < Wo) o[ox0 + px] = relu_keep_nan(acc0[k] + bv);
+                if (ox0 + px + 32 < Wo) o[ox0 + px + 32] = relu_keep_nan(acc1[k] + bv);
+            }
         }
     }
 }
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = 2 * x + dx;
                 if (xx < 0 || xx >= W) continue;
-                m = fmaxf(m, p[(int64_t)yy * W + xx]);
+                m = max_keep_nan(m, p[(int64_t)yy * W + xx]);
             }
         }
         out[i] = m;
@@ -146,10 +156,10 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_vec4_kernel(const float* __r
         const float* r = p + (size_t)yy * W + 8 * j;       // inputs 8j-1 .. 8j+7 feed outputs 4j .. 4j+3
         const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
         const float left = j > 0 ? r[-1] : -INFINITY;
-        m[0] = fmaxf(m[0], fmaxf(left, fmaxf(a.x, a.y)));
-        m[1] = fmaxf(m[1], fmaxf(a.y, fmaxf(a.z, a.w)));
-        m[2] = fmaxf(m[2], fmaxf(a.w, fmaxf(b.x, b.y)));
-        m[3] = fmaxf(m[3], fmaxf(b.y, fmaxf(b.z, b.w)));
+        m[0] = max_keep_nan(m[0], max_keep_nan(left, max_keep_nan(a.x, a.y)));
+        m[1] = max_keep_nan(m[1], max_keep_nan(a.y, max_keep_nan(a.z, a.w)));
+        m[2] = max_keep_nan(m[2], max_keep_nan(a.w, max_keep_nan(b.x, b.y)));
+        m[3] = max_keep_nan(m[3], max_keep_nan(b.y, max_keep_nan(b.z, b.w)));
     }
     *reinterpret_cast<float4*>(out + (size_t)row * Wo + 4 * j) = make_float4(m[0], m[1], m[2], m[3]);
 }

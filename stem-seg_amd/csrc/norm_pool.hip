@@ -149,14 +149,14 @@ __global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int xx = x + dx;
                         if (xx < 0 || xx >= p.W) continue;
-                        const float rv = fmaxf(fmaf(row[xx], a, b), 0.f);
-                        acc = p.pool_max ? fmaxf(acc, rv) : acc + rv;
+                        const float rv = relu_keep_nan(fmaf(row[xx], a, b));
+                        acc = p.pool_max ? max_keep_nan(acc, rv) : acc + rv;
                     }
                 }
             }
             v = p.pool_max ? acc : acc / 27.0f;
         } else {
-            v = fmaxf(fmaf(xc[(int64_t)to * HW + (int64_t)y * p.W + x], a, b), 0.f);
+            v = relu_keep_nan(fmaf(xc[(int64_t)to * HW + (int64_t)y * p.W + x], a, b));
         }
         p.out[(int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)y * p.out_ys + x] = v;
     }
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void gn_relu_stream_kernel(const GnApplyParams
     float4* dst = reinterpret_cast<float4*>(p.out + (int64_t)c * p.out_cs);
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
         float4 v = src[i];
-        v.x = fmaxf(fmaf(v.x, a, b), 0.f); v.y = fmaxf(fmaf(v.y, a, b), 0.f);
-        v.z = fmaxf(fmaf(v.z, a, b), 0.f); v.w = fmaxf(fmaf(v.w, a, b), 0.f);
+        v.x = relu_keep_nan(fmaf(v.x, a, b)); v.y = relu_keep_nan(fmaf(v.y, a, b));
+        v.z = relu_keep_nan(fmaf(v.z, a, b)); v.w = relu_keep_nan(fmaf(v.w, a, b));
         dst[i] = v;
     }
 }
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256) void gn_relu_pool4_kernel(const GnApplyParams 
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const int xx = x0 - 1 + k;
-                r[k] = (xx >= 0 && xx < p.W) ? fmaxf(fmaf(row[xx], a, b), 0.f) : 0.f;
+                r[k] = (xx >= 0 && xx < p.W) ? relu_keep_nan(fmaf(row[xx], a, b)) : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = p.pool_max ? fmaxf(acc[j], fmaxf(fmaxf(r[j], r[j + 1]), r[j + 2])) : acc[j] + ((r[j] + r[j + 1]) + r[j + 2]);
+            for (int j = 0; j < 4; ++j) acc[j] = p.pool_max ? max_keep_nan(acc[j], max_keep_nan(max_keep_nan(r[j], r[j + 1]), r[j + 2])) : acc[j] + ((r[j] + r[j + 1]) + r[j + 2]);
         }
     }
     float* o = p.out + (int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)y * p.out_ys + x0;

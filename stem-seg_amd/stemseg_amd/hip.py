@@ -447,15 +447,15 @@ def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):
 
 
 def label_presence(labels_list, cap):
-    """-> (present uint8 [cap] on the device, max_plus_1 int64 [1] on the device) over all tensors of ``labels_list``
-    (int64, same device); no synchronisation."""
+    """-> (present uint8 [cap + 1] on the device: byte l = label l occurs, byte ``cap`` = a negative (outlier) label occurs;
+    max_plus_1 int64 [1] on the device) over all tensors of ``labels_list`` (int64, same device); no synchronisation."""
     dev = labels_list[0].device
-    present = torch.empty(max(int(cap), 1), dtype=torch.uint8, device=dev)
+    present = torch.empty(int(cap) + 1, dtype=torch.uint8, device=dev)
     mx = torch.empty(1, dtype=torch.int64, device=dev)
     for k, l in enumerate(labels_list):
         check(lib().stemseg_hip_label_presence(ptr(l, torch.int64) if l.numel() else None, l.numel(), ptr(present), int(cap),
                                                ptr(mx), int(k > 0), stream()))
-    return present[:int(cap)], mx
+    return present, mx
 
 
 def relabel(labels, mapping):

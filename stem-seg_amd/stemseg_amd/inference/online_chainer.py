@@ -110,41 +110,45 @@ class HipChainerOps(object):
         return buf.tolist(), meta
 
     def label_sets(self, groups, cap):
-        """groups: lists of (device, int64) label arrays -> for each group the ascending ids > 0 that occur, with ONE read-back
-        for all of them (the reference's unique() per group, online_chainer.py:304-308, and the highest id of :43-49)."""
+        """groups: lists of (device, int64) label arrays -> (for each group the ascending ids > 0 that occur, for each group whether
+        a negative (outlier) label occurs), with ONE read-back for all of them (the reference's unique() per group,
+        online_chainer.py:304-308, and the highest id of :43-49)."""
         rows = []
         dev = next((l.device for g in groups for l in g), self.device)
         for g in groups:
             ls = [l.contiguous() for l in g if l.numel() > 0]
             if ls:
-                present, mx = hip.label_presence(ls, cap)
+                present, mx = hip.label_presence(ls, cap)             # present: cap bytes + the "negative label seen" byte
                 rows.append(torch.cat([present.to(torch.int64), mx]))
             else:
-                rows.append(torch.zeros(cap + 1, dtype=torch.int64, device=dev))
+                rows.append(torch.zeros(cap + 2, dtype=torch.int64, device=dev))
         host = torch.stack(rows).cpu()                    # the one read-back
-        out = []
+        out, neg = [], []
         for r in host:
             assert int(r[-1]) <= cap, "label %d beyond the stated bound %d" % (int(r[-1]) - 1, cap)
-            out.append([i for i in torch.nonzero(r[:-1]).flatten().tolist() if i > 0])
-        return out
+            out.append([i for i in torch.nonzero(r[:cap]).flatten().tolist() if i > 0])
+            neg.append(bool(r[cap]))
+        return out, neg
 
-    def present_ids(self, labels_list, cap=None):
+    def present_ids(self, labels_list, cap=None, with_outlier=False):
         """Ascending ids > 0 that occur in the (device, int64) label arrays -- the reference's ``unique()`` minus the outlier
         id (online_chainer.py:304-308).  ``cap``: an exclusive upper bound on the ids when the caller has one (labels are
-        always below next_track_label + max_instances); without it one extra pass finds the maximum first."""
+        always below next_track_label + max_instances); without it one extra pass finds the maximum first.
+        ``with_outlier``: -> (ids, whether a negative label occurs)."""
         ls = [l.contiguous() for l in labels_list]
         if not ls:
-            return []
+            return ([], False) if with_outlier else []
         if cap is None:
             _, mx = hip.label_presence(ls, 0)
             cap = int(mx.item())
         present, mx = hip.label_presence(ls, cap)
         host = torch.cat([present.to(torch.int64), mx]).cpu()           # one read-back
         assert int(host[-1]) <= cap, "label %d beyond the stated bound %d" % (int(host[-1]) - 1, cap)
-        return [i for i in torch.nonzero(host[:-1]).flatten().tolist() if i > 0]
+        ids = [i for i in torch.nonzero(host[:cap]).flatten().tolist() if i > 0]
+        return (ids, bool(host[cap])) if with_outlier else ids
 
     def overlap_counts(self, la, lb, ids_a, ids_b):
-        """ids_*: ascending candidate ids (> 0).  -> inter [Ka,Kb], cnt_a, cnt_b as numpy int64."""
+        """ids_*: candidate ids (> 0) in any order.  -> inter [Ka,Kb], cnt_a, cnt_b (rows / columns in the given order) as numpy int64."""
         def lut(ids):
             t = torch.full((max(ids) + 2 if ids else 1,), -1, dtype=torch.int32)
             if ids:
@@ -227,6 +231,17 @@ def _int_scale(scale):
     return s
 
 
+def reference_id_order(ids, has_outlier):
+    """The ids of one side of the association in the order the REFERENCE enumerates them:
+    ``list(set(labels.unique().tolist()) - {OUTLIER_LABEL})`` (online_chainer.py:308-309) -- CPython's set-iteration order of
+    the set built from the ascending unique() list (the outlier id -1 included when it occurs), not ascending order:
+    list(set([-1, 2, 9]) - {-1}) is [9, 2].  The order decides which pair the Hungarian solver returns on exact cost ties (every
+    zero-IoU entry costs exactly 1.0 and every returned pair is accepted, :332-343), so it is part of the bookkeeping that has to
+    match.  The same expression is evaluated here on the same values."""
+    raw = ([-1] if has_outlier else []) + sorted(int(i) for i in ids)
+    return list(set(raw) - {-1})
+
+
 def association_from_counts(inter, ca, cb, ids_1, ids_2):
     """The Hungarian step of online_chainer.py:310-343 on the label-pair statistics: IoU costs in float32 exactly as the
     reference forms them (``1. - iou.item()`` stored into a float32 matrix, :327), every returned pair accepted."""
@@ -304,7 +319,14 @@ def stitch_from_tables(clip_frames, tables, item_of, Ks, B):
             ids_2 = [int(base[1 + c]) for c in cols]
             if ids_1 or ids_2:
                 assert not set(ids_1).intersection(ids_2), "Labels overlap: {}, {}".format(ids_1, ids_2)
-                associations = association_from_counts(inter_rows[:, cols], ca, col_cnt[cols], ids_1, ids_2)[0]
+                # rows / columns in the reference's enumeration order (reference_id_order); an outlier on the overlap frames is
+                # bin B-1 of the source plane (rows) / of this clip's plane (columns)
+                o1 = reference_id_order(ids_1, bool(tabs[:, B - 1, :].sum() > 0))
+                o2 = reference_id_order(ids_2, bool(tabs[:, :, B - 1].sum() > 0))
+                r_idx = [ids_1.index(v) for v in o1]
+                c_idx = [ids_2.index(v) for v in o2]
+                sub = inter_rows[:, cols][r_idx][:, c_idx] if (r_idx and c_idx) else np.zeros((len(r_idx), len(c_idx)), np.int64)
+                associations = association_from_counts(sub, ca[r_idx], col_cnt[cols][c_idx], o1, o2)[0]
                 mapping = {cur: assoc for assoc, cur in associations}
         final = base.copy()
         for cur, assoc in mapping.items():
@@ -383,7 +405,7 @@ class OnlineChainer(object):
 
             id_bound = next_track_label + self.clusterer.max_instances        # every label of this clip is below it
             if i == 0:
-                (ids_new,) = ops.label_sets([labels_per_frame], id_bound)
+                (ids_new,), _ = ops.label_sets([labels_per_frame], id_bound)
                 next_track_label = track.add_labels(frames, labels_per_frame, max_label=self._max_of(ids_new, labels_per_frame))
                 subseq_meta.append(meta_info)
                 prev_frames = frames
@@ -396,7 +418,8 @@ class OnlineChainer(object):
             new_js = [j for j, t in enumerate(frames) if t not in overlap]
             new_labels = [labels_per_frame[j] for j in new_js]
             # one read-back: ids on the overlap frames (existing / current) and ids of the frames this clip adds
-            ids_1, ids_2, ids_new = ops.label_sets([existing, current, new_labels], id_bound)
+            (ids_1, ids_2, ids_new), (neg_1, neg_2, _) = ops.label_sets([existing, current, new_labels], id_bound)
+            ids_1, ids_2 = reference_id_order(ids_1, neg_1), reference_id_order(ids_2, neg_2)      # (decides exact cost ties)
             associations = self._associate_ids(torch.cat(list(existing)), torch.cat(list(current)), ids_1, ids_2)[0] if ids_1 or ids_2 \
                 else []
             mapping = {cur: assoc for assoc, cur in associations}
@@ -456,7 +479,8 @@ class OnlineChainer(object):
             return [], set(), set(), np.zeros(0, np.float32), (np.zeros((0, 0), np.float32), [], [])
         # only the ids that occur on the overlap frames enter the statistics (the reference's unique(), :304-308): the table
         # is K1 x K2 <= a few hundred cells however large the track ids have grown
-        return self._associate_ids(la, lb, self.ops.present_ids([la], id_bound), self.ops.present_ids([lb], id_bound))
+        ids_1, ids_2 = self.ops.present_ids([la], id_bound, with_outlier=True), self.ops.present_ids([lb], id_bound, with_outlier=True)
+        return self._associate_ids(la, lb, reference_id_order(*ids_1), reference_id_order(*ids_2))
 
     def _associate_ids(self, la, lb, ids_1, ids_2):
         assert la.shape == lb.shape, "Shape mismatch: {}, {}".format(la.shape, lb.shape)

@@ -50,13 +50,15 @@ class OracleChainerOps(object):
     def read(self, pts, meta):
         return pts["offs"].tolist(), meta
 
-    def present_ids(self, labels_list, cap=None):
+    def present_ids(self, labels_list, cap=None, with_outlier=False):
         ids = np.unique(np.concatenate([l.numpy().reshape(-1) for l in labels_list])) if labels_list else np.zeros(0, np.int64)
         assert cap is None or ids.size == 0 or ids.max() < cap
-        return [int(i) for i in ids if i > 0]
+        out = [int(i) for i in ids if i > 0]
+        return (out, bool((ids < 0).any())) if with_outlier else out
 
     def label_sets(self, groups, cap):
-        return [self.present_ids([l for l in g if l.numel() > 0], cap) if any(l.numel() > 0 for l in g) else [] for g in groups]
+        res = [self.present_ids([l for l in g if l.numel() > 0], cap, with_outlier=True) if any(l.numel() > 0 for l in g) else ([], False) for g in groups]
+        return [r[0] for r in res], [r[1] for r in res]
 
     def overlap_counts(self, la, lb, ids_a, ids_b):
         la, lb = la.numpy(), lb.numpy()

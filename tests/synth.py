@@ -123,6 +123,59 @@ def synth_long_sequence(n_clips, H=24, W=48, births_per_clip=4, seed=0, T=8, ove
     return emb, bw, sd, fg
 
 
+def synth_tie_sequence(n_clips, H=24, W=48, seed=0, T=8, overlap=4, p_coherent=0.7):
+    """A sequence that makes the chainer's Hungarian step hit EXACT COST TIES on rectangular matrices: 18 persistent objects
+    (3 x 6 cells); per CLIP each object is either coherent (tight embedding, high seediness -> one instance) or noise (scattered
+    embedding, low seediness -> outlier points), drawn independently per clip.  An object that is an instance in clip i-1 and noise
+    in clip i is an old id with zero IoU against everything; one that is noise in i-1 and an instance in i is a new id with zero
+    IoU against everything: with two or more of the former, which old track the new instance is merged into depends on the ORDER
+    the ids are enumerated in (online_chainer.py:308-309: list(set(unique) - {-1})).  Head outputs therefore differ per clip on
+    the shared frames.  -> (per clip (emb [4,T,H,W], bw [2,T,H,W], seed [1,T,H,W]) float32, fg [F,H,W] uint8, clips)."""
+    stride = T - overlap
+    F = stride * (n_clips - 1) + T
+    rng = np.random.RandomState(9100 + seed)
+    rows, cols = 3, 6
+    ch, cw = H // rows, W // cols
+    bh, bwid = ch - 2, cw - 2
+    fg = np.zeros((F, H, W), np.uint8)
+    cells = [(r * ch + 1, c * cw + 1) for r in range(rows) for c in range(cols)]
+    for (y0, x0) in cells:
+        fg[:, y0:y0 + bh, x0:x0 + bwid] = 1
+    clips = [list(range(stride * i, stride * i + T)) for i in range(n_clips)]
+    per_clip = []
+    for i in range(n_clips):
+        emb = (10 + 3 * rng.standard_normal((4, T, H, W))).astype(np.float32)
+        bw = (25 + rng.uniform(0, 1, (2, T, H, W))).astype(np.float32)
+        sd = rng.uniform(0, 0.2, (1, T, H, W)).astype(np.float32)
+        coherent = rng.uniform(size=len(cells)) < p_coherent
+        for k, (y0, x0) in enumerate(cells):
+            if not coherent[k]:
+                continue
+            free = (0.6 * ((k * 7) % 5 - 2), 0.6 * ((k * 3) % 5 - 2))
+            c = np.array([-1 + 2 * (y0 + bh / 2) / H, -1.3 + 2.6 * (x0 + bwid / 2) / W, free[0], free[1]], np.float32)
+            nz = (0.04 * rng.standard_normal((4, T, bh, bwid))).astype(np.float32)
+            emb[:, :, y0:y0 + bh, x0:x0 + bwid] = c[:, None, None, None] + nz
+            sd[0, :, y0:y0 + bh, x0:x0 + bwid] = np.clip(1 - np.sqrt((nz ** 2).sum(0)), 0, 1)
+        per_clip.append((emb, bw, sd))
+    return per_clip, fg, clips
+
+
+def tie_sequence_case(golden_npz, to_tensor):
+    """(fg, clip dicts, expected) of the ``chainer_ties`` golden (inputs regenerated from the seed, checksums verified)."""
+    import zlib
+    g = golden_npz
+    per_clip, fg, clips = synth_tie_sequence(int(g["n_clips"]), seed=int(g["seed"]))
+    crc = [zlib.crc32(np.concatenate([a.reshape(-1) for a in pc]).tobytes()) for pc in per_clip] + [zlib.crc32(fg.tobytes())]
+    assert crc == g["input_crc"].tolist(), "synthetic inputs drifted"
+    dicts = [dict(frames=list(fr), embeddings=to_tensor(e.copy()), bandwidths=to_tensor(b.copy()), seediness=to_tensor(s.copy()))
+             for fr, (e, b, s) in zip(clips, per_clip)]
+    track = np.split(g["track_labels"].astype(np.int64), np.cumsum(g["track_sizes"])[:-1])
+    inst = np.split(g["instance_labels"], np.cumsum(g["instance_label_sizes"])[:-1])
+    exp = dict(track=track, counts=[tuple(r) for r in g["pt_counts"].tolist()], life=[tuple(r) for r in g["lifetimes"].tolist()],
+               instance_labels=[a.tolist() for a in inst])
+    return fg, dicts, exp
+
+
 def long_sequence_case(golden_npz, to_tensor):
     """(fg, clip dicts, expected) of the ``chainer_long`` golden: inputs regenerated from the stored seed (checksums
     verified), expected outputs as the reference's chainer produced them."""

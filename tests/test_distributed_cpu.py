@@ -23,6 +23,12 @@ def _case(tag):
         _, _, exp = synth.long_sequence_case(g, torch.from_numpy)
         clips = [list(range(4 * i, 4 * i + 8)) for i in range(int(g["n_clips"]))]
         return emb, bw, sd, fg, clips, 4, exp
+    if tag == "ties":                                   # head outputs differ PER CLIP on the shared frames: keyed by the clip's frames
+        g = np.load(os.path.join(GOLDEN, "chainer_ties.npz"))
+        per_clip, fg, clips = synth.synth_tie_sequence(int(g["n_clips"]), seed=int(g["seed"]))
+        _, _, exp = synth.tie_sequence_case(g, torch.from_numpy)
+        by_clip = {tuple(fr): pc for fr, pc in zip(clips, per_clip)}
+        return by_clip, None, None, fg, clips, 4, exp
     g = np.load(os.path.join(GOLDEN, "chainer.npz"))
     emb, bw, sd, fg = g[tag + "__emb"], g[tag + "__bw"], g[tag + "__sd"], g[tag + "__fg"]
     clips = g[tag + "__subseqs"].tolist()
@@ -46,6 +52,8 @@ def _run(tag, fn_name="run_sequence_sharded", comm=None):
 
     def embed(frames):
         calls.append(list(frames))
+        if isinstance(emb, dict):
+            return tuple(torch.from_numpy(a.copy()) for a in emb[tuple(frames)])
         return (torch.from_numpy(emb[:, frames].copy()), torch.from_numpy(bw[:, frames].copy()), torch.from_numpy(sd[:, frames].copy()))
 
     class CountingOps(OracleChainerOps):
@@ -109,10 +117,11 @@ def _spawn(world, tag, fn_name="run_sequence_sharded"):
     return res
 
 
-@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single", "long"])
+@pytest.mark.parametrize("tag", ["seq20_ov4", "seq14_ov6", "seq8_single", "long", "ties"])
 def test_clip_parallel_chain_one_process_vs_golden(tag):
     """world 1 (no process group): the table-based chain alone against the reference's outputs -- tracks, per-clip label lists,
-    coordinates, counts, lifetimes, instance lists; `long` drives the track ids to 527."""
+    coordinates, counts, lifetimes, instance lists; `long` drives the track ids to 527; `ties` has exact Hungarian cost ties whose
+    outcome depends on the reference's id enumeration order (online_chainer.reference_id_order)."""
     ok, calls, clustered, mine, n_clips = _run(tag)
     assert ok and len(calls) == n_clips and clustered == [1] * n_clips
 
@@ -124,11 +133,11 @@ def test_sharded_sequence_two_ranks_gloo(tag):
     assert sum(r[2] for r in res) == n_clips and sum(r[3] for r in res) == n_clips
 
 
-@pytest.mark.parametrize("world,tag", [(3, "seq20_ov4"), (3, "seq14_ov6"), (8, "long"), (8, "seq20_ov4")])
+@pytest.mark.parametrize("world,tag", [(3, "seq20_ov4"), (3, "seq14_ov6"), (8, "long"), (8, "seq20_ov4"), (3, "ties")])
 def test_sharded_sequence_three_and_eight_ranks_gloo(world, tag):
     """world 3: uneven blocks; world 8 on the 48-clip sequence: 6 clips per rank, ids to 527; world 8 on 4 clips: idle ranks."""
     res = _spawn(world, tag)
-    n_clips = {"seq20_ov4": 4, "seq14_ov6": 4, "long": 48}[tag]
+    n_clips = {"seq20_ov4": 4, "seq14_ov6": 4, "long": 48, "ties": 12}[tag]
     assert sum(r[2] for r in res) == n_clips and sum(r[3] for r in res) == n_clips
 
 

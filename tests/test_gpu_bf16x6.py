@@ -208,3 +208,99 @@ def test_f16x3_overflowing_activation_is_not_silent(hip):
     o = out.cpu().numpy()
     assert not np.isfinite(o[:, 100]).any()
     assert np.isfinite(np.delete(o, 100, axis=1)).all()
+
+
+@pytest.mark.parametrize("kind", ["k3", "k2", "k1"])
+def test_split_modes_keep_fp32_level_with_per_channel_dynamic_range(hip, kind):
+    """Intra-layer dynamic range: FrozenBN folded with eps = 0 (make_layers.py:43,51-63) multiplies every OUTPUT channel by its
+    own gamma / sqrt(var) -- per-channel weight magnitudes log-uniform over 2^-20 ... 1 here.  Every channel is held to the
+    fp32-MFMA error level RELATIVE TO ITS OWN output scale (a per-layer weight scale fails this: the small channels' low fp16
+    terms go subnormal)."""
+    rs = np.random.RandomState(91)
+    if kind == "k1":
+        Cin, Cout, V = 256, 256, 3 * 30 * 54
+        ch = (2.0 ** rs.uniform(-20, 0, size=(Cout, 1, 1, 1, 1))).astype(np.float32)
+        x, w, b = np.maximum(_rand((Cin, V), 92, 30.0), 0), _rand((Cout, Cin, 1, 1, 1), 93, 1.0 / np.sqrt(Cin)) * ch, None
+        ref = w.reshape(Cout, Cin).astype(np.float64) @ x.astype(np.float64)
+        xd = dev(x)
+        res = _both(hip, hip.flat_volume(xd), w, b, (Cout, V), 1, 0, flat=True)
+    else:
+        kt = 3 if kind == "k3" else 1
+        Cin, Cout, T, H, W = (64, 128, 3, 21, 40) if kind == "k3" else (64, 128, 2, 17, 70)
+        ch = (2.0 ** rs.uniform(-20, 0, size=(Cout, 1, 1, 1, 1))).astype(np.float32)
+        x, w, b = np.maximum(_rand((Cin, T, H, W), 92, 30.0), 0), _rand((Cout, Cin, kt, 3, 3), 93, 1.0 / np.sqrt(Cin * 9 * kt)) * ch, None
+        ref = _ref64(x, w, b, kt)
+        buf, vin = _haloed(hip, x, kt)
+        res = _both(hip, vin, w, b, (Cout, T, H, W), (kt, 3, 3), 0)
+    Cout = ref.shape[0]
+    scale = np.abs(ref.reshape(Cout, -1)).max(1)                        # per output channel
+    e32 = (np.abs(res["f32"] - ref).reshape(Cout, -1).max(1) / scale)
+    e6 = (np.abs(res[SP] - ref).reshape(Cout, -1).max(1) / scale)
+    print("[%s] %s per-channel dynamic range 2^-20..1: worst relative error fp32-MFMA %.3e, split %.3e" % (SP, kind, e32.max(), e6.max()))
+    assert np.isfinite(res[SP]).all()
+    assert e6.max() <= max(3.0 * e32.max(), 4e-7), "%s loses precision on small-magnitude output channels" % SP
+
+
+def test_split_modes_encoder_with_checkpoint_like_frozen_bn_statistics(hip):
+    """R-101-FPN with FrozenBN statistics like a trained checkpoint's: running_var log-uniform over 1e-6 ... 1e2, gamma over
+    0.05 ... 3 (folded: per-output-channel weight scales spanning ~5 orders of magnitude inside every layer).  The split modes must
+    reproduce the fp32-input MFMA encoder at ITS error level against the fp32 CPU oracle."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.backbone import ResNetFPN
+    from oracle import encoder as oenc
+    from tests import synth
+    config.load_preset("davis")
+    bb = ResNetFPN("R-101-FPN").cuda()
+    rs = np.random.RandomState(5)
+    sd = {}
+    for k, v in bb.state_dict().items():
+        a = np.asarray(synth.synth_param(k, v.shape, 17)).reshape(v.shape).astype(np.float32)
+        if k.endswith("running_var"):
+            a = (10.0 ** rs.uniform(-6, 2, size=v.shape)).astype(np.float32)
+        elif k.endswith("bn1.weight") or k.endswith("bn2.weight") or k.endswith(".1.weight"):
+            a = (10.0 ** rs.uniform(np.log10(0.05), np.log10(3.0), size=v.shape)).astype(np.float32)
+        elif k.endswith("bn3.weight"):
+            a = (10.0 ** rs.uniform(np.log10(0.01), np.log10(0.5), size=v.shape)).astype(np.float32)
+        if a.ndim == 4 and "bn" not in k:
+            # keep activations O(1) despite 1 / sqrt(var) up to 1e3: scale the conv by the geometric mean of what its BN multiplies in
+            a = a * np.float32(0.03)
+        sd[k] = torch.from_numpy(a)
+    bb.load_state_dict(sd)
+    frames = torch.from_numpy(synth.synth_frames(2, 64, 96, seed=3).astype(np.float32)).permute(0, 3, 1, 2) - 110.0
+    ref = oenc.resnet_fpn_forward(frames, {k: v.numpy() for k, v in sd.items()}, "R-101-FPN")
+    outs = {}
+    for prec in ("f32", SP):
+        bb.precision = prec
+        outs[prec] = [o.cpu().numpy() for o in bb.forward(frames.cuda())]
+    for lvl in range(4):
+        r = np.asarray(ref[lvl])
+        scale = float(np.abs(r).max())
+        e32 = float(np.abs(outs["f32"][lvl] - r).max()) / scale
+        e6 = float(np.abs(outs[SP][lvl] - r).max()) / scale
+        print("[%s] R-101 checkpoint-like BN, FPN level %d: rel err fp32-MFMA %.3e, split %.3e (max|ref| %.3g)" % (SP, lvl, e32, e6, scale))
+        assert np.isfinite(outs[SP][lvl]).all()
+        assert e6 <= max(3.0 * e32, 2e-6)
+
+
+@pytest.mark.parametrize("form", ["relu", "relu+residual", "relu+splitk"])
+def test_f16x3_overflow_survives_the_fused_relu(hip, form):
+    """An activation beyond the f16x3 range must come back NON-FINITE through the fused ReLU / residual / split-K reduce epilogues
+    too (the ReLU keeps NaN like torch's; fmaxf(NaN, 0) would have returned a plausible 0)."""
+    if SP != "f16x3":
+        pytest.skip("range limit of the f16x3 mode")
+    Cin, Cout, T, H, W = 64, 128, 2, 9, 40
+    V = T * H * W
+    x, w = _rand((Cin, V), 61), _rand((Cout, Cin, 1, 1, 1), 62, 1.0 / 8)
+    x[3, 100] = 3.0e5
+    xd = dev(x)
+    out = torch.zeros(Cout, V, device="cuda")
+    epi = dict(precision="f16x3", relu=1)
+    if "residual" in form:
+        rd = dev(_rand((Cout, V), 63))
+        epi.update(residual=rd, res_strides=(V, 0, 0))
+    scratch = torch.zeros(16 * Cout * V, device="cuda") if "splitk" in form else None
+    hip.conv3d(hip.flat_volume(xd), hip.pack_conv_weight_any(dev(w), "f16x3"), dev(_rand((Cout,), 64)), hip.flat_volume(out), 1, 0, scratch, epi)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert not np.isfinite(o[:, 100]).any(), "the overflow was flushed to a finite value by the %s epilogue" % form
+    assert np.isfinite(np.delete(o, 100, axis=1)).all()

@@ -973,8 +973,26 @@ def test_overlap_counts_ids_beyond_500_and_large_tables(hip):
         got = ops.overlap_counts(dev(la), dev(lb), ids_a, ids_b)
         exp = ref.overlap_counts(torch.from_numpy(la), torch.from_numpy(lb), ids_a, ids_b)
         assert all(np.array_equal(x, y) for x, y in zip(got, exp))
+        assert ops.present_ids([dev(la)], with_outlier=True) == (sorted(set(la[la > 0].tolist())), True)
+        assert ops.present_ids([dev(np.abs(la))], with_outlier=True)[1] is False
+        perm_a, perm_b = ids_a[::-1], ids_b[1:] + ids_b[:1]                                           # any id order: rows / columns follow it
+        got = ops.overlap_counts(dev(la), dev(lb), perm_a, perm_b)
+        exp = ref.overlap_counts(torch.from_numpy(la), torch.from_numpy(lb), perm_a, perm_b)
+        assert all(np.array_equal(x, y) for x, y in zip(got, exp))
+    (ids,), (neg,) = ops.label_sets([[dev(np.array([3, -1, 7], np.int64)), dev(np.zeros(0, np.int64))]], 10)
+    assert ids == [3, 7] and neg is True and ops.label_sets([[dev(np.array([3, 7], np.int64))]], 10) == ([[3, 7]], [False])
     with pytest.raises(AssertionError):
         ops.present_ids([dev(np.array([5, 900], np.int64))], cap=100)                                # a wrong bound is caught
+
+
+def test_chainer_exact_cost_ties_on_gpu_vs_golden(hip, golden):
+    """tests/golden/chainer_ties.npz through the HIP chainer: exact Hungarian cost ties resolved in the reference's id enumeration
+    order (online_chainer.reference_id_order) -- device-side id sets now also report whether the outlier id occurs."""
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    fg, dicts, exp = synth.tie_sequence_case(golden("chainer_ties"), dev)
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cuda:0"), 1.0)
+    synth.check_long_sequence(ch.process(torch.from_numpy(fg), dicts), exp)
 
 
 def test_chainer_track_ids_beyond_500_on_gpu_vs_golden(hip, golden):

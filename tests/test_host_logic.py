@@ -65,13 +65,13 @@ def test_cabi_struct_sizes_and_argument_errors():
     assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0 and b"whole clips" in l.stemseg_hip_last_error()
     e.n_clips, e.W = 4, 850                                           # frame size must be padded to multiples of 32
     assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0
-    # packed weight sizes per precision (pure host arithmetic): chunks x k-groups x planes x [half][Cout] 16-B pieces (+ the f16x3 scale record)
+    # packed weight sizes per precision (pure host arithmetic): chunks x k-groups x planes x [half][Cout] 16-B pieces (+ the f16x3 per-output-channel scale vector)
     split2, split3 = l.stemseg_hip_packed_weight_bytes_split(128, 256, 27, 2), l.stemseg_hip_packed_weight_bytes_split(128, 256, 27, 3)
     assert split3 == 64 * 7 * 3 * 2 * 128 * 16 and split2 * 3 == split3 * 2
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x3"]) == split2
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x6"]) == split3
-    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) == split3 + 16
-    assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) == 32 * 2 * 3 * 2 * 256 * 16 + 16
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) == split3 + 8 * 128
+    assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) == 32 * 2 * 3 * 2 * 256 * 16 + 8 * 256
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f32"]) == 0 and l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 7) == 0
     # encoder plan offsets (debugging aid): distinct offsets, the first buffer at 0, the last value = the workspace size in floats
     e.n_clips, e.W = 4, 864
@@ -273,6 +273,32 @@ def test_chainer_track_ids_beyond_500_vs_golden(golden):
     fg, dicts, exp = synth.long_sequence_case(golden("chainer_long"), torch.from_numpy)
     top = synth.check_long_sequence(_make_chainer().process(torch.from_numpy(fg), dicts), exp)
     assert top > 500
+
+
+def test_chainer_exact_cost_ties_follow_the_reference_id_order(golden):
+    """tests/golden/chainer_ties.npz: a 12-clip sequence in which new instances have zero IoU with several unmatched old tracks --
+    rectangular cost matrices full of exact 1.0 ties -- through the reference's chainer.  Which old track wins depends on the order
+    the reference enumerates the ids in, list(set(unique().tolist()) - {-1}) (online_chainer.py:308-309): CPython set order, not
+    ascending.  (tools/make_goldens.py asserts that the ascending order gives a different result on this sequence.)"""
+    from stemseg_amd.inference import online_chainer as oc
+    g = golden("chainer_ties")
+    fg, dicts, exp = synth.tie_sequence_case(g, torch.from_numpy)
+    synth.check_long_sequence(_make_chainer().process(torch.from_numpy(fg), dicts), exp)
+    # the enumeration order itself
+    assert oc.reference_id_order([2, 9], True) == list(set([-1, 2, 9]) - {-1}) and oc.reference_id_order([9, 2], False) == list(set([2, 9]))
+    assert oc.reference_id_order([], True) == [] and sorted(oc.reference_id_order(range(1, 60), True)) == list(range(1, 60))
+    # direct associate_clusters cases (ids up to 400 that collide in the set's hash table, with and without the outlier id)
+    ch = _make_chainer()
+    n_order_sensitive = 0
+    for case in range(int(g["n_assoc"])):
+        l1, l2 = g["assoc%02d_l1" % case].astype(np.int64), g["assoc%02d_l2" % case].astype(np.int64)
+        got = ch.associate_clusters(torch.from_numpy(l1), torch.from_numpy(l2))[0]
+        want = [tuple(r) for r in g["assoc%02d_pairs" % case].tolist()]
+        assert [tuple(p) for p in got] == want, case
+        ids1, ids2 = sorted(set(l1[l1 > 0].tolist())), sorted(set(l2[l2 > 0].tolist()))
+        inter, ca, cb = OracleChainerOps().overlap_counts(torch.from_numpy(l1), torch.from_numpy(l2), ids1, ids2)
+        n_order_sensitive += sorted(oc.association_from_counts(inter, ca, cb, ids1, ids2)[0]) != sorted(want)
+    assert n_order_sensitive >= 3, "the golden must contain cases that an ascending enumeration gets wrong"
 
 
 def test_chainer_resize_path(golden):

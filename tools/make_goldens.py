@@ -26,7 +26,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 from tests import synth  # noqa: E402
 
-GROUPS = ["dec_T8", "dec_T16", "dec_T4", "dec_T2", "dec_T24", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "chainer_long", "misc"]
+GROUPS = ["dec_T8", "dec_T16", "dec_T4", "dec_T2", "dec_T24", "semseg", "masks", "config0", "model_ytvis", "model_kitti", "encoder", "model_davis", "cluster", "chainer", "chainer_long", "chainer_ties", "misc"]
 
 
 def _save(name, **arrays):
@@ -571,6 +571,76 @@ def gen_chainer_long():
     _save("chainer_long", **out)
 
 
+def gen_chainer_ties():
+    """Exact Hungarian cost ties (tests/synth.synth_tie_sequence) through the reference's chainer: which old track a new
+    instance joins depends on the reference's id enumeration order, list(set(unique) - {-1}) (online_chainer.py:308-309).  Also
+    stores direct associate_clusters cases on label arrays with large, colliding ids.  Checks at generation time that the
+    sequence IS order-sensitive: this repo's chain with ascending ids gives another result."""
+    import ref_shim
+    ref_shim.install()
+    import zlib
+    import torch
+    from stemseg.inference.clusterers import SequentialClustering
+    from stemseg.inference.online_chainer import OnlineChainer
+    n_clips, seed = 12, 1
+    per_clip, fg, clips = synth.synth_tie_sequence(n_clips, seed=seed)
+    dicts = [dict(frames=list(fr), embeddings=torch.from_numpy(e.copy()), bandwidths=torch.from_numpy(b.copy()), seediness=torch.from_numpy(s.copy()))
+             for fr, (e, b, s) in zip(clips, per_clip)]
+    ch = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0)
+    (track_labels, pt_counts, lifetimes), _, subseq_labels, _, meta = ch.process(torch.from_numpy(fg), dicts)
+    out = {"n_clips": np.int64(n_clips), "seed": np.int64(seed),
+           "input_crc": np.array([zlib.crc32(np.concatenate([a.reshape(-1) for a in pc]).tobytes()) for pc in per_clip] + [zlib.crc32(fg.tobytes())], np.int64),
+           "track_sizes": np.array([l.numel() for l in track_labels], np.int64),
+           "track_labels": np.concatenate([l.numpy() for l in track_labels]).astype(np.int32),
+           "pt_counts": np.array(sorted(pt_counts.items()), np.int64).reshape(-1, 2),
+           "lifetimes": np.array(sorted(lifetimes.items()), np.int64).reshape(-1, 2),
+           "instance_label_sizes": np.array([len(m["instance_labels"]) for m in meta], np.int64),
+           "instance_labels": np.concatenate([np.array(m["instance_labels"], np.int64) for m in meta])}
+    # direct association cases: ids that collide in CPython's set table, with and without the outlier id
+    rs = np.random.RandomState(4)
+    n_cases = 0
+    for case in range(40):
+        k1, k2 = rs.randint(2, 7), rs.randint(1, 6)
+        ids = rs.choice(np.arange(1, 400), k1 + k2, replace=False)
+        ids1, ids2 = ids[:k1], ids[k1:]
+        n = 600
+        l1 = rs.choice(ids1, n).astype(np.int64)
+        l2 = np.full(n, -1, np.int64)
+        # a few real overlaps, the rest of the new ids on points where labels_1 is the outlier: zero-IoU rows AND columns
+        matched = rs.permutation(min(k1, k2))[:rs.randint(0, min(k1, k2))]
+        for m in matched:
+            l2[l1 == ids1[m]] = ids2[m]
+        free2 = [i for i in range(k2) if i not in set(matched.tolist())]
+        out_pts = rs.uniform(size=n) < 0.25
+        l1[out_pts] = -1
+        l2[out_pts] = rs.choice(ids2[free2], int(out_pts.sum())) if free2 else -1
+        if rs.uniform() < 0.3:
+            l1[l1 == -1] = ids1[0]                              # no outlier id on side 1
+        assoc = ch.associate_clusters(torch.from_numpy(l1), torch.from_numpy(l2))[0]
+        out["assoc%02d_l1" % case], out["assoc%02d_l2" % case] = l1.astype(np.int32), l2.astype(np.int32)
+        out["assoc%02d_pairs" % case] = np.array(assoc, np.int64).reshape(-1, 2)
+        n_cases += 1
+    out["n_assoc"] = np.int64(n_cases)
+    # order sensitivity: the product's chain (oracle-backed ops) reproduces the reference; with ascending ids it does not
+    sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
+    from stemseg_amd.inference import online_chainer as oc
+    from stemseg_amd.inference.clusterers import SequentialClustering as SC
+    from tests.oracle_ops import OracleChainerOps
+
+    def ours():
+        d2 = [dict(frames=list(fr), embeddings=torch.from_numpy(e.copy()), bandwidths=torch.from_numpy(b.copy()), seediness=torch.from_numpy(s.copy()))
+              for fr, (e, b, s) in zip(clips, per_clip)]
+        return oc.OnlineChainer(SC(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0, ops=OracleChainerOps()).process(torch.from_numpy(fg), d2)[0][0]
+    same = all(np.array_equal(a.numpy(), b.numpy()) for a, b in zip(ours(), track_labels))
+    keep = oc.reference_id_order
+    oc.reference_id_order = lambda ids, has_outlier: sorted(ids)
+    same_sorted = all(np.array_equal(a.numpy(), b.numpy()) for a, b in zip(ours(), track_labels))
+    oc.reference_id_order = keep
+    print("chainer_ties: %d clips, highest id %d; product chain == reference: %s; with ascending ids: %s" % (n_clips, max(pt_counts), same, same_sorted))
+    assert same and not same_sorted, "the tie sequence must be order-sensitive and reproduced"
+    _save("chainer_ties", **out)
+
+
 # ------------------------------------------------------------------------------------------------
 def gen_misc():
     import ref_shim
@@ -659,6 +729,8 @@ def main():
         gen_chainer()
     elif g == "chainer_long":
         gen_chainer_long()
+    elif g == "chainer_ties":
+        gen_chainer_ties()
     elif g == "misc":
         gen_misc()
 

@@ -93,8 +93,11 @@ def lane_tensors(pipe, graph, lane, NC):
             if k[-1] == lane:
                 out["%s_ws" % name] = (v, decoder_segments(mod, k[0], k[1], k[2], k[3]))
     for i, o in enumerate(graph.out):
+        n = o["frame_offsets"][-1:] if "frame_offsets" in o else None      # (device scalar: rows beyond N are never written)
         for kk, v in o.items():
             if torch.is_tensor(v):
+                if n is not None and kk in ("voxel_index", "labels"):
+                    v = torch.where(torch.arange(v.numel(), device=v.device) < n, v.reshape(-1), torch.zeros_like(v.reshape(-1)))
                 out["out%d.%s" % (i, kk)] = (v, None)
     return out
 
@@ -109,12 +112,16 @@ def as_i32(t):
     return t.view(torch.int32)
 
 
-def describe(name, t, ref, segs):
+def describe(name, t, ref, segs, other=None):
     a, b = as_i32(t), as_i32(ref)
+    c = as_i32(other) if other is not None else None
     bad = torch.nonzero(a != b).flatten()
     if bad.numel() == 0:
         return None
     lines = []
+    if bad.numel() <= 64:                                  # few words: list them (offset, got, lone-replay value)
+        fa, fb = a[bad].view(torch.float32).tolist(), b[bad].view(torch.float32).tolist()
+        lines.append("    words: " + ", ".join("+%d %.6g (lone %.6g)" % (int(o), x, y) for o, x, y in zip(bad.tolist(), fa, fb)))
     if segs:
         bounds = [o for _, o in segs]
         for (sn, o), o2 in zip(segs[:-1], bounds[1:]):
@@ -124,6 +131,17 @@ def describe(name, t, ref, segs):
                 d = (fa - fb).abs()
                 lines.append("    %-12s %9d of %11d words differ, first +%d last +%d, max |d| %.3e (ref magnitude %.3e)"
                              % (sn, sel.numel(), o2 - o, int(sel[0]) - o, int(sel[-1]) - o, float(d.max()), float(fb.abs().max())))
+                if sel.numel() <= 40:                      # few words: list (offset in the segment, got, lone replay, lone replay of the OTHER batch)
+                    fc = c[sel].view(torch.float32).tolist() if c is not None else [float("nan")] * sel.numel()
+                    lines.append("        " + "; ".join("+%d got %.7g lone %.7g other-batch %.7g" % (int(q) - o, x, y, z)
+                                                          for q, x, y, z in zip(sel.tolist(), fa.tolist(), fb.tolist(), fc)))
+                    # the whole 32-word neighbourhood of the first differing word: got / lone / other
+                    q0 = int(sel[0]) // 16 * 16
+                    nb = slice(q0, q0 + 32)
+                    lines.append("        neighbourhood +%d..: got   %s" % (q0 - o, " ".join("%.5g" % v for v in a[nb].view(torch.float32).tolist())))
+                    lines.append("        neighbourhood +%d..: lone  %s" % (q0 - o, " ".join("%.5g" % v for v in b[nb].view(torch.float32).tolist())))
+                    if c is not None:
+                        lines.append("        neighbourhood +%d..: other %s" % (q0 - o, " ".join("%.5g" % v for v in c[nb].view(torch.float32).tolist())))
     else:
         fa, fb = a[bad].view(torch.float32), b[bad].view(torch.float32)
         lines.append("    %9d of %11d words differ, first %d last %d, max |d| %.3e" % (bad.numel(), a.numel(), int(bad[0]), int(bad[-1]),
@@ -199,7 +217,7 @@ def main():
                     reports += 1
                     print("round %d lane %d (batch %d): %d buffers differ from the lone replay" % (rep, k, which[k], len(differing)), flush=True)
                     for n in differing:
-                        d = describe(n, cur[n][0], ref[n], cur[n][1])
+                        d = describe(n, cur[n][0], ref[n], cur[n][1], refs[k][1 - which[k]].get(n))
                         if d:
                             print(d, flush=True)
     print("RESULT: %d of %d lane-rounds differ (%d clip results checked); first differing buffer: %s" % (bad_rounds, args.reps * args.lanes, results, first_seg))
