@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 4
+#define STEMSEG_HIP_ABI_VERSION 5
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -273,6 +273,13 @@ size_t stemseg_hip_encoder_workspace_bytes(const StemsegEncoderDesc* desc);
 /* Debugging aid: float offsets of the encoder plan's buffers inside the workspace (S0, X1, A, B, Cst[4], M1[4], M2, DS, XS, L[4], FO[4],
  * SK, total: 25 values, -1 = absent). */
 int stemseg_hip_encoder_plan_offsets(const StemsegEncoderDesc* desc, int64_t* out25);
+
+/* The stem alone (resnet.py:285-304 up to the ReLU; FrozenBN folded into w / bias): frames float32 [T][3][H][W] ->
+ * out float32 [64][T][H/2][W/2] = relu(conv7x7 stride 2 pad 3 + bias).  w_tap_major: [3*7*7][64] (tap-major: the folded
+ * [64][3][7][7] weight reshaped to [64][147] and transposed).  What stemseg_hip_encoder_forward runs first; exported for tests
+ * and for the co-residency probe (tools/stem_corun_probe.py). */
+int stemseg_hip_stem_conv(const float* frames, const float* w_tap_major, const float* bias, float* out, int32_t T, int32_t H, int32_t W,
+                          void* stream);
 int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
 /* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[4 * c + k], c < n_clips, k = 0..3: the four FPN maps (4x, 8x, 16x,
  * 32x) of clip c as volumes [256][clip frames][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed

@@ -16,6 +16,7 @@
 //   * layers with few voxels (layer3/4: 12 960 / 3 240 voxels) use the conv kernel's split-K to fill 256 CUs.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace stemseg {
 
@@ -108,6 +109,106 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(const float* __res
                 if (ox0 + px < Wo) o[ox0 + px] = relu_keep_nan(acc0[k] + bv);
                 if (ox0 + px + 32 < Wo) o[ox0 + px + 32] = relu_keep_nan(acc1[k] + bv);
             }
+        }
+    }
+}
+
+// ---- stem on the matrix cores: the same 7x7 stride-2 convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32
+// products, fp32 accumulation).  M = 64 output channels, N = 8 rows x 64 columns of outputs per workgroup, K = 3 x 7 x 8 taps (the
+// eighth column tap is zero padding): an MFMA consumes TWO taps per issue -- lane half 0 an even dx, lane half 1 the odd dx next to
+// it -- so the input patch is staged DE-INTERLEAVED by column parity: plane p holds the input columns x = 2 i + p, and tap
+// (c, dy, dx = 2 q + p) of output column ox is plane[p][c][2 oy + dy][ox + q]: consecutive lanes read consecutive LDS words and
+// every tap is a compile-time immediate on one per-lane base (stride-2 reads of an interleaved patch would be 2-way bank
+// conflicts).  Four waves; wave w owns output rows 2w, 2w + 1 (four 32-column blocks) x both 32-channel halves: 8 accumulator
+// tiles, 6 LDS reads per 8 MFMAs.  Why it exists: the VALU form above is the step's only VALU-bound kernel, and under several HIP
+// streams a few of ITS outputs per ~10^3 launches came back wrong -- 16 lanes of one accumulator off by a product or two -- while
+// no MFMA convolution ever did (tools/soak_probe.py).  It is also 3x faster.
+constexpr int SM_PW = 68, SM_ROWS_IN = 2 * ST_ROWS + 6;          // plane row pitch (words); staged input rows (one spare for nothing: 21 used)
+constexpr int SM_PLANE = 3 * SM_ROWS_IN * SM_PW;                  // words per parity plane
+constexpr int SM_KSTEPS = 3 * 7 * 4;                              // (c, dy, q): two taps each
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void stem_conv7x7_mfma_kernel(const float* __restrict__ frames, const float* __restrict__ w_tap_major,
+                                                                 const float* __restrict__ bias, float* __restrict__ out, int T, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * SM_PLANE + SM_KSTEPS * 2 * 64];
+    float* const planes = lds;
+    float* const wl = lds + 2 * SM_PLANE;
+    const int Ho = H / 2, Wo = W / 2;
+    const int tiles_x = (Wo + ST_COLS - 1) / ST_COLS, tiles_y = (Ho + ST_ROWS - 1) / ST_ROWS;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int t = b / tiles_y;
+    const int oy0 = ty * ST_ROWS, ox0 = tx * ST_COLS;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    // weights: [step = (c * 7 + dy) * 4 + q][half][64] <- w_tap_major[(c * 7 + dy) * 7 + 2 q + half][64], zero for dx = 7
+    for (int i = threadIdx.x; i < SM_KSTEPS * 2 * 64; i += 256) {
+        const int co = i & 63, half = (i >> 6) & 1, step = i >> 7;
+        const int q = step & 3, cdy = step >> 2, dx = 2 * q + half;
+        wl[i] = dx < 7 ? w_tap_major[(cdy * 7 + dx) * 64 + co] : 0.f;
+    }
+    // input patch, 21 rows x 133 columns per channel, split by column parity (columns beyond 133 and the spare rows: zero)
+    for (int i = threadIdx.x; i < 2 * SM_PLANE; i += 256) {
+        const int par = i / SM_PLANE, r = i - par * SM_PLANE;
+        const int xi = r % SM_PW, yy = (r / SM_PW) % SM_ROWS_IN, c = r / (SM_PW * SM_ROWS_IN);
+        const int iy = iy0 + yy, ix = ix0 + 2 * xi + par;
+        float v = 0.f;
+        if (yy < ST_PR && 2 * xi + par < ST_PC && iy >= 0 && iy < H && ix >= 0 && ix < W) v = frames[(((int64_t)t * 3 + c) * H + iy) * W + ix];
+        planes[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    f32x16s acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const float* a_ptr = wl + half * 64 + l31;
+    const float* b_ptr[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b_ptr[ni] = planes + half * SM_PLANE + (2 * (2 * wave + (ni >> 1))) * SM_PW + (ni & 1) * 32 + l31;
+    auto ld = [&](const int step, float (&a)[2], float (&bv)[4]) __attribute__((always_inline)) {
+        const int q = step & 3, cdy = step >> 2, c = cdy / 7, dy = cdy - 7 * c;
+        const int boff = (c * SM_ROWS_IN + dy) * SM_PW + q;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = a_ptr[step * 128 + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bv[ni] = b_ptr[ni][boff];
+    };
+    auto mm = [&](const float (&a)[2], const float (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    };
+    // software pipeline over the k-steps (operands of step i + 1 requested before the MFMAs of step i issue)
+    float a0[2], b0[4], a1[2], b1[4];
+    ld(0, a0, b0);
+#pragma unroll
+    for (int i = 0; i < SM_KSTEPS; i += 2) {
+        ld(i + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < SM_KSTEPS) ld(i + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue: C/D layout col = lane & 31 (output column), row = (r & 3) + 8 * (r >> 2) + 4 * half (channel)
+    const int64_t plane = (int64_t)Ho * Wo;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int oy = oy0 + 2 * wave + (ni >> 1), ox = ox0 + (ni & 1) * 32 + l31;
+        if (oy < Ho && ox < Wo) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    out[((int64_t)ch * T + t) * plane + (int64_t)oy * Wo + ox] = relu_keep_nan(acc[mi][ni][r] + bias[ch]);
+                }
         }
     }
 }
@@ -308,6 +409,25 @@ extern "C" int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc
     return STEMSEG_OK;
 }
 
+// STEMSEG_STEM=valu selects the VALU form (A/B measurements, the co-residency probes); default: the MFMA form
+static bool stem_on_mfma() {
+    static const bool on = [] { const char* e = getenv("STEMSEG_STEM"); return !(e && e[0] == 'v'); }();
+    return on;
+}
+
+extern "C" int stemseg_hip_stem_conv(const float* frames, const float* w_tap_major, const float* bias, float* out, int32_t T, int32_t H, int32_t W,
+                                     void* stream) {
+    SS_CHECK_ARG(frames && w_tap_major && bias && out, "stem_conv: null pointer");
+    SS_CHECK_ARG(T >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "stem_conv: T=%d H=%d W=%d (H, W even)", T, H, W);
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t blocks = ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T;
+    SS_CHECK_ARG(blocks < (1ll << 31), "stem_conv: too many tiles");
+    if (stem_on_mfma()) hipLaunchKernelGGL(stem_conv7x7_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), frames, w_tap_major, bias, out, T, H, W);
+    else hipLaunchKernelGGL(stem_conv7x7_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), frames, w_tap_major, bias, out, T, H, W);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
 extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const StemsegEncoderWeights* wts, const float* frames,
                                            const StemsegVolume* out, void* workspace, size_t ws_bytes, void* stream) {
     EncoderPlan p;
@@ -340,7 +460,8 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         const int Ho = p.H / 2, Wo = p.W / 2;
         const int blocks = (int)(ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T);
         void* ev = profile_begin(47, 4.0 * ((double)3 * T * p.H * p.W + 64.0 * T * Ho * Wo), s);
-        hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        if (stem_on_mfma()) hipLaunchKernelGGL(stem_conv7x7_mfma_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        else hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
         profile_end(ev, s);
         SS_LAUNCH_CHECK();
         ev = profile_begin(48, 4.0 * 64.0 * T * ((double)Ho * Wo + (double)p.V[0] / T), s);

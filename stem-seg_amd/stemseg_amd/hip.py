@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Volume(C.Structure):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "stemseg_hip_conv3d": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, C.POINTER(ConvEpilogue), _P]),
     "stemseg_hip_conv3d_gn_scratch_doubles": (C.c_int64, [_I32, _I32]),
     "stemseg_hip_conv3d_gn": (C.c_int, [C.POINTER(Volume), _P, _P, C.POINTER(Volume), _I32, _I32, _I32, _I32, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
+    "stemseg_hip_stem_conv": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "stemseg_hip_encoder_init_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, _P]),
     "stemseg_hip_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), _P, C.POINTER(Volume), _P, C.c_size_t, _P]),
@@ -273,6 +274,16 @@ def pack_conv_weight_any(w, precision="f32"):
         raise ValueError("pack_conv_weight_any: unsupported shape / precision (%s, Cout %d, Cin %d, taps %d)" % (precision, Cout, Cin, taps))
     out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)      # opaque 16-B-aligned blob
     check(lib().stemseg_hip_pack_conv_weight_prec(ptr(w, torch.float32), ptr(out), Cout, Cin, taps, code, stream()))
+    return out
+
+
+def stem_conv(frames, w, bias):
+    """frames float32 [T,3,H,W], w [64,3,7,7] (FrozenBN folded), bias [64] -> [64,T,H/2,W/2] = relu(conv 7x7 s2 p3 + bias)."""
+    require_gpu()
+    T, _, H, W = frames.shape
+    out = torch.empty(64, T, H // 2, W // 2, dtype=torch.float32, device=frames.device)
+    wt = w.reshape(64, 147).t().contiguous()
+    check(lib().stemseg_hip_stem_conv(ptr(frames.contiguous(), torch.float32), ptr(wt, torch.float32), ptr(bias.contiguous(), torch.float32), ptr(out), T, H, W, stream()))
     return out
 
 

@@ -252,22 +252,28 @@ def test_split_modes_encoder_with_checkpoint_like_frozen_bn_statistics(hip):
     config.load_preset("davis")
     bb = ResNetFPN("R-101-FPN").cuda()
     rs = np.random.RandomState(5)
-    sd = {}
-    for k, v in bb.state_dict().items():
-        a = np.asarray(synth.synth_param(k, v.shape, 17)).reshape(v.shape).astype(np.float32)
-        if k.endswith("running_var"):
-            a = (10.0 ** rs.uniform(-6, 2, size=v.shape)).astype(np.float32)
-        elif k.endswith("bn1.weight") or k.endswith("bn2.weight") or k.endswith(".1.weight"):
-            a = (10.0 ** rs.uniform(np.log10(0.05), np.log10(3.0), size=v.shape)).astype(np.float32)
-        elif k.endswith("bn3.weight"):
-            a = (10.0 ** rs.uniform(np.log10(0.01), np.log10(0.5), size=v.shape)).astype(np.float32)
-        if a.ndim == 4 and "bn" not in k:
-            # keep activations O(1) despite 1 / sqrt(var) up to 1e3: scale the conv by the geometric mean of what its BN multiplies in
-            a = a * np.float32(0.03)
-        sd[k] = torch.from_numpy(a)
+    sd = {k: np.asarray(synth.synth_param(k, v.shape, 17)).reshape(v.shape).astype(np.float32) for k, v in bb.state_dict().items()}
+    # consistent statistics, as training leaves them: a channel's running_var IS the variance of its conv output, so the conv rows
+    # are scaled by sqrt(var) (var log-uniform over 1e-6 ... 1e2) and the folded weight keeps gamma / sqrt(var) * sqrt(var) = gamma
+    # times the unit-variance row -- gamma log-uniform over 1e-4 ... 3 (dead and strong channels side by side in every layer)
+    for k in list(sd):
+        if not k.endswith("running_var"):
+            continue
+        bn = k[:-len(".running_var")]
+        conv = bn.replace("bn1", "conv1").replace("bn2", "conv2").replace("bn3", "conv3")
+        if bn.endswith("downsample.1"):
+            conv = bn[:-1] + "0"
+        var = (10.0 ** rs.uniform(-6, 2, size=sd[k].shape)).astype(np.float32)
+        sd[k] = var
+        sd[conv + ".weight"] = sd[conv + ".weight"] * np.sqrt(var)[:, None, None, None]
+        top = 0.5 if bn.endswith("bn3") else 3.0
+        sd[bn + ".weight"] = (10.0 ** rs.uniform(-4, np.log10(top), size=var.shape)).astype(np.float32)
+        sd[bn + ".running_mean"] = (sd[bn + ".running_mean"] * np.sqrt(var)).astype(np.float32)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
     bb.load_state_dict(sd)
     frames = torch.from_numpy(synth.synth_frames(2, 64, 96, seed=3).astype(np.float32)).permute(0, 3, 1, 2) - 110.0
-    ref = oenc.resnet_fpn_forward(frames, {k: v.numpy() for k, v in sd.items()}, "R-101-FPN")
+    ref_d = oenc.resnet_fpn(frames, {k: v.numpy() for k, v in sd.items()}, "R-101-FPN", prefix="")
+    ref = [ref_d[s_].numpy() for s_ in (4, 8, 16, 32)]
     outs = {}
     for prec in ("f32", SP):
         bb.precision = prec

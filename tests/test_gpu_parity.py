@@ -985,6 +985,25 @@ def test_overlap_counts_ids_beyond_500_and_large_tables(hip):
         ops.present_ids([dev(np.array([5, 900], np.int64))], cap=100)                                # a wrong bound is caught
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 66, 98), (1, 34, 258), (5, 480, 864)])
+def test_stem_conv_vs_fp64(hip, shape):
+    """The stem alone (stemseg_hip_stem_conv: 7x7 stride 2 pad 3 + folded-BN bias + ReLU on v_mfma_f32_32x32x2_f32) against an
+    fp64 convolution, on sizes whose last tiles hang over the right / bottom edges; bit-identical run to run."""
+    import torch.nn.functional as F
+    T, H, W = shape
+    rs = np.random.RandomState(T * 1000 + H)
+    frames = (rs.randint(0, 256, (T, 3, H, W)).astype(np.float32) - np.array([102.9801, 115.9465, 122.7717], np.float32)[None, :, None, None])
+    w = (rs.standard_normal((64, 3, 7, 7)) * (2.0 / 147) ** 0.5).astype(np.float32)
+    b = rs.standard_normal(64).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(frames).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=3)).permute(1, 0, 2, 3).numpy()
+    got = hip.stem_conv(dev(frames), dev(w), dev(b))
+    got2 = hip.stem_conv(dev(frames), dev(w), dev(b))
+    assert tuple(got.shape) == (64, T, H // 2, W // 2) and torch.equal(got, got2)
+    err = np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print("[stem] %s max rel err vs fp64 %.3e" % (shape, err))
+    assert err <= 2e-6
+
+
 def test_chainer_exact_cost_ties_on_gpu_vs_golden(hip, golden):
     """tests/golden/chainer_ties.npz through the HIP chainer: exact Hungarian cost ties resolved in the reference's id enumeration
     order (online_chainer.reference_id_order) -- device-side id sets now also report whether the outlier id occurs."""

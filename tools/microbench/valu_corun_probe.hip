@@ -8,7 +8,8 @@
 // This program runs a "victim" kernel whose result is known exactly -- the stem's inner loop (LDS broadcast reads of the weights,
 // two pixels per thread, 64 accumulators), with the FMA issued either as v_pk_fma_f32 or as v_fma_f32 -- on one stream while an
 // "aggressor" runs on a second stream:
-//     none | mfma (back-to-back v_mfma_f32_32x32x16_f16) | valu (a second victim) | copy (a streaming copy)
+//     none | mfma (back-to-back v_mfma_f32_32x32x16_f16) | valu (a second victim) | copy (a streaming copy) |
+//     lds + mfma (eight-wave workgroups streaming ds_read_b128 fragments into MFMAs, barriers and LDS refills: the convs' k-loop)
 // and counts victim outputs that differ from the exact value, with the lane of every wrong word.
 //
 // Build: hipcc --offload-arch=gfx950 -O2 -o tools/microbench/bin/valu_corun_probe tools/microbench/valu_corun_probe.hip
@@ -112,6 +113,34 @@ __global__ __launch_bounds__(256) void aggr_mfma(float* sink, int iters) {
     sink[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
+// the split-staged convolutions' k-loop in miniature: an eight-wave workgroup streaming ds_read_b128 fragments out of 96 KB of LDS
+// into back-to-back MFMAs (the LDS pipe ~80 % busy), with a barrier and an LDS refill per "chunk"
+__global__ __launch_bounds__(512, 2) void aggr_lds_mfma(float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) float smem[24576];
+    for (int i = threadIdx.x; i < 24576; i += 512) smem[i] = (float)(i & 7);
+    __syncthreads();
+    f16v c0, c1, c2, c3;
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = c2[r] = c3[r] = 0.f;
+    const char* base = reinterpret_cast<const char*>(smem) + (threadIdx.x & 63) * 16;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const h8 a = *reinterpret_cast<const h8*>(base + ((g * 4 + 0) & 47) * 2048);
+            const h8 b = *reinterpret_cast<const h8*>(base + ((g * 4 + 1) & 47) * 2048);
+            const h8 a2 = *reinterpret_cast<const h8*>(base + ((g * 4 + 2) & 47) * 2048);
+            const h8 b2 = *reinterpret_cast<const h8*>(base + ((g * 4 + 3) & 47) * 2048);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b2, c3, 0, 0, 0);
+        }
+        __syncthreads();
+        smem[(threadIdx.x * 4 + i) % 24576] = c0[0] * 0.f + (float)(i & 3);
+        __syncthreads();
+    }
+    sink[blockIdx.x * 512 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+
 __global__ __launch_bounds__(256) void aggr_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
 }
@@ -135,7 +164,7 @@ int main(int argc, char** argv) {
     float *out, *out2, *sink;
     float4 *cin, *cout;
     const size_t ncopy = (size_t)64 << 20;                      // 1 GB in, 1 GB out
-    CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&out2, n_out * 4)); CK(hipMalloc(&sink, 4096 * 256 * 4));
+    CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&out2, n_out * 4)); CK(hipMalloc(&sink, 4096 * 512 * 4));
     CK(hipMalloc(&cin, ncopy * 16)); CK(hipMalloc(&cout, ncopy * 16)); CK(hipMemset(cin, 1, ncopy * 16));
     hipStream_t s1, s2;
     CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
@@ -149,9 +178,9 @@ int main(int argc, char** argv) {
                 for (int x = 0; x < 64; ++x) want[(((size_t)b * 64 + ch) * ROWS + py) * 64 + x] = expected(b, ch, py, x);
     CK(hipMemcpy(want_d, want.data(), n_out * 4, hipMemcpyHostToDevice));
     const char* vname[2] = {"v_fma_f32   ", "v_pk_fma_f32"};
-    const char* aname[4] = {"none", "mfma", "valu (second victim)", "copy"};
+    const char* aname[5] = {"none", "mfma", "valu (second victim)", "copy", "lds + mfma (conv-like)"};
     for (int v = 1; v >= 0; --v)
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < 5; ++a) {
             long long bad_words = 0, bad_launches = 0;
             int reported = 0;
             long long lane_hist[4] = {0, 0, 0, 0};              // wrong words by lane quarter (0-15, 16-31, 32-47, 48-63)
@@ -160,6 +189,7 @@ int main(int argc, char** argv) {
                 CK(hipStreamSynchronize(s1));
                 if (a == 1) hipLaunchKernelGGL(aggr_mfma, dim3(4096), dim3(256), 0, s2, sink, 6000);
                 if (a == 2) { if (v) hipLaunchKernelGGL(victim<1>, dim3(NB), dim3(256), 0, s2, out2, 1); else hipLaunchKernelGGL(victim<0>, dim3(NB), dim3(256), 0, s2, out2, 1); }
+                if (a == 4) hipLaunchKernelGGL(aggr_lds_mfma, dim3(1024), dim3(512), 0, s2, sink, 150);
                 if (a == 3) hipLaunchKernelGGL(aggr_copy, dim3(2048), dim3(256), 0, s2, cin, cout, ncopy);
                 if (v) hipLaunchKernelGGL(victim<1>, dim3(NB), dim3(256), 0, s1, out, 1); else hipLaunchKernelGGL(victim<0>, dim3(NB), dim3(256), 0, s1, out, 1);
                 CK(hipDeviceSynchronize());
