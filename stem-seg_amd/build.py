@@ -19,6 +19,13 @@ OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(LIBDIR, "libstemseg_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# A/B builds (tools/): STEMSEG_BUILD_DEFINES="-DSS_F16_WPLANES=3" STEMSEG_BUILD_TAG=w3 -> lib/libstemseg_hip_w3.so (objects under build_w3/);
+# select at run time with STEMSEG_HIP_LIB=<path>
+TAG = os.environ.get("STEMSEG_BUILD_TAG", "")
+FLAGS += os.environ.get("STEMSEG_BUILD_DEFINES", "").split()
+if TAG:
+    OBJDIR = os.path.join(CSRC, "build_" + TAG)
+    LIB = os.path.join(LIBDIR, "libstemseg_hip_%s.so" % TAG)
 
 
 def _sources():

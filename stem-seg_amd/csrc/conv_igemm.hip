@@ -40,6 +40,14 @@
 // f16x3: activations are split as fp16 terms of x * 2^-2 (see split3)
 #define STEMSEG_F16X3_ACT_SCALE 0.25f
 
+#ifndef SS_F16_WPLANES
+#define SS_F16_WPLANES 2           // f16x3: staged weight planes.  2: hi, lo -- the third A operand, hi_w * 2^-11 (it meets the input tile's lo * 2^11
+                                  // plane), is made in registers, four packed multiplies per k-group step in the shadow of the MFMAs: a third less
+                                  // slab, LDS traffic and staging.  3: the operand is a third packed plane (every MFMA operand straight from LDS).
+                                  // Round 3 shipped 3 because the run-to-run differences under several streams were blamed on the in-register
+                                  // multiply; round 4 traced every one of them to the VALU stem kernel -- with that gone both
+                                  // forms are bit-stable in the three-lane soak, and numerically identical to each other.
+#endif
 #ifndef SS_X6_WMODE_SMALLG
 #define SS_X6_WMODE_SMALLG -1      // -1: mode 2 wherever its second register set fits (mode 1 measured 2-5 % faster on the f16x3 1x1 tiles when
                                   // that kernel still made an operand in registers; not re-measured since, see SS_X6_SPREAD)
@@ -129,8 +137,8 @@ struct ConvCfg {
     // X6 = the split-staged path (operands split once, when a chunk is staged): BF_ 2 = bf16x6 (three bf16 planes, six products),
     // BF_ 3 = f16x3 (two fp16 planes of the SCALED operand, three products)
     static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ >= 2, F16 = BF_ == 3, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
-    static constexpr int NPL = BF_ >= 2 ? 3 : 2;                        // 16-bit planes of the staged weights (f16x3: hi, lo, hi * 2^-11)
-    static constexpr int NPA = NPL;                                     // A operands of a k-group step
+    static constexpr int NPL = BF_ == 2 ? 3 : (BF_ == 3 ? SS_F16_WPLANES : 2);   // 16-bit planes of the staged weights (f16x3: hi, lo [, hi * 2^-11])
+    static constexpr int NPA = BF_ >= 2 ? 3 : 2;                        // A operands of a k-group step
     static constexpr int NPX = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged input tile (f16x3: hi, lo * 2^11)
     static constexpr int NPROD = BF_ == 2 ? 6 : 3;                      // MFMAs per (A fragment, B fragment) pair
     static constexpr int PMAX = PMAX_;
@@ -158,7 +166,7 @@ struct ConvCfg {
     static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
     // X6 weight staging of tiles with few k-groups per chunk (1x1 taps; a phase's MFMA stream is shorter than a global load):
     // 0 two phases, registers refilled per phase; 1 one phase, whole slab in registers; 2 two phases, one chunk of lookahead
-    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : ((WM * WN >= 8 || MI * NI < 8) ? 2 : 0)) : 0;
+    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : (((BF_ == 3 && SS_F16_WPLANES == 2) || WM * WN >= 8 || MI * NI < 8) ? 2 : 0)) : 0;
     // (bf16x6, 128 co x 256 voxels on four waves: the second register set of mode 2 spills)
     static constexpr bool SP = WMODE == 1, LA = WMODE == 2;
     // split-staged tiles keep TWO input tiles where LDS allows (160 KB for a lone eight-wave workgroup, 80 KB for two four-wave ones):
@@ -549,11 +557,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         // smallest products first (planes: 0 hi, 1 mid / lo, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
         auto mm = [&](const int mi, h16x8 (&a)[NPA], const h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
             if constexpr (C::F16) {
-                // (every MFMA operand comes straight from LDS.  Making hi_w * 2^-11 here with four v_pk_mul_f16 per step saved a third
-                // of the slab and 5 % of the step, but a VALU write into a register quad that MFMAs issued two or three instructions
-                // earlier still read is a hazard neither the hardware nor the compiler covers: with two or three pipelines in flight
-                // 1 % of the clip results stopped being bit-identical run to run, 20 % with the multiplies moved one MFMA closer --
-                // bench.py's determinism monitor)
+                // two staged planes: the weights' hi * 2^-11 operand (it meets the input tile's lo * 2^11 plane) is made here, four packed
+                // multiplies in the shadow of the MFMAs (exact: a power of two on a normal number; the same rounding as the packed
+                // third plane otherwise)
+                if constexpr (NPL == 2) a[2] = a[0] * (h16)(1.0f / 2048.0f);
 #define SS_X6_TERM(PA, PB)                                                                                                     \
     _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
@@ -1327,7 +1334,8 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
                                                int CK, int TPG) {
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
     const int nchunks = (Cin + CK - 1) / CK;
-    const int64_t n = (int64_t)nchunks * G * 3 * 2 * Cout;
+    constexpr int NPLW = SS_F16_WPLANES;
+    const int64_t n = (int64_t)nchunks * G * NPLW * 2 * Cout;
     float* inv = reinterpret_cast<float*>(packed + n);
     const unsigned int* max_bits = reinterpret_cast<const unsigned int*>(inv + Cout);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1337,8 +1345,8 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
         int64_t r = i / Cout;
         const int h = (int)(r & 1);
         r >>= 1;
-        const int pl = (int)(r % 3);
-        r /= 3;
+        const int pl = (int)(r % NPLW);
+        r /= NPLW;
         const int grp = (int)(r % G);
         const int chunk = (int)(r / G);
         const int cg = grp / NTG, tg = grp % NTG;
@@ -1953,7 +1961,7 @@ extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
     if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2);
     if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3);
-    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) + 8 * (int64_t)Cout;      // three planes + per output channel: float 1 / scale, uint32 bits of max|w|
+    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, SS_F16_WPLANES) + 8 * (int64_t)Cout;      // planes + per output channel: float 1 / scale, uint32 bits of max|w|
     return 0;
 }
 

@@ -70,8 +70,8 @@ def test_cabi_struct_sizes_and_argument_errors():
     assert split3 == 64 * 7 * 3 * 2 * 128 * 16 and split2 * 3 == split3 * 2
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x3"]) == split2
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x6"]) == split3
-    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) == split3 + 8 * 128
-    assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) == 32 * 2 * 3 * 2 * 256 * 16 + 8 * 256
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) in (split2 + 8 * 128, split3 + 8 * 128)      # (two or three staged weight planes: SS_F16_WPLANES)
+    assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) in (32 * 2 * 2 * 2 * 256 * 16 + 8 * 256, 32 * 2 * 3 * 2 * 256 * 16 + 8 * 256)
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f32"]) == 0 and l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 7) == 0
     # encoder plan offsets (debugging aid): distinct offsets, the first buffer at 0, the last value = the workspace size in floats
     e.n_clips, e.W = 4, 864
