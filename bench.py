@@ -9,7 +9,9 @@ One "step" = a batch of --clips-per-step (default 4) synthetic clips (each T=8 f
 DAVIS heads: embedding decoder + separate seediness decoder): ONE encoder pass over all their frames (the encoder is
 per-frame), then per clip 3-D decoders -> fused heads -> fg mask -> fg gather -> sequential clustering -> read-back of the
 clustering record (K, instance list), with the input frames already resident in HBM.  The step is captured as a hipGraph
-per lane; --lanes (default 3) steps are in flight on their own streams and workspaces.  value = clips / s.  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
+per lane; --lanes (default 3) steps are in flight on their own streams and workspaces.  value = clips / s.  Every clip result of the
+run is checked bitwise against the first result of its input batch (a mismatch: exit code 5, no line).  At N = 1 the same step is then
+timed in the two reference-width MFMA modes as well (``alt_precision``: bf16x6 and f32, shorter regions).  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
 are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus N                          # N > 1 without a launcher: re-executes itself under torch.distributed.run
@@ -348,8 +350,8 @@ PRECISION_NOTE = {
               "not a reduced precision: max error vs an fp64 convolution = 0.78-1.56x that of the fp32-input MFMA kernel on every kernel class / "
               "tile / epilogue (tests/test_gpu_bf16x6.py); labels identical to the reference's own CPU results on its flows (tests/test_gpu_parity.py) "
               "and to the CPU oracle at full size in THIS run (cpu_baseline.parity_vs_hip_path); --precision f32 runs the fp32-input MFMA kernels",
-    "f16x3": "every fp32 operand is scaled by a power of two (activations 2^-2; a layer's weights so that the largest lands in [2^13, 2^14)) and "
-             "split into two fp16 terms (22 significand bits; the low activation term is stored as lo * 2^11 against a hi * 2^-11 weight plane (all MFMA operands straight from LDS), so "
+    "f16x3": "every fp32 operand is scaled by a power of two (activations 2^-2; every OUTPUT CHANNEL's weights so that its largest lands in [2^13, 2^14)) and "
+             "split into two fp16 terms (22 significand bits; the low activation term is stored as lo * 2^11 against a hi * 2^-11 weight operand, so "
              "the pair keeps 22 bits, or 2^-36 absolute, for 2.5e-4 <= |a| < 2.6e5); lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, fp32 "
              "accumulation, accumulators scaled back exactly.  The dropped lo*lo product and the split remainder are <= 2^-22 |a*b|: measured "
              "against an fp64 convolution the error stays at the fp32-input MFMA kernel's own level on every kernel class / tile / epilogue and "
@@ -375,9 +377,11 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["STEMSEG_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (4 clips each by default): ~2.6 s of GPU time at the default")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the bf16x6 / f32 legs (N = 1, davis workload only)")
+    ap.add_argument("--alt-steps", type=int, default=16, help="timed steps of each reference-width leg")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="MFMA mode of every convolution: f16x3 (default, the library's default) = two fp16 terms of the power-of-two-scaled "
                          "operands, three products, fp32 accumulate (fp32-level results); bf16x6 = exact three-term bf16 split, six products "
@@ -393,8 +397,9 @@ def main():
                          "one step fill the tail rounds and memory-bound phases of the other (config.determinism reports whether every clip result of the run "
                          "was bit-identical to the first one of its input batch)")
     ap.add_argument("--sequence", action="store_true",
-                    help="BASELINE configs[3]: one long sequence, clips sharded over the ranks in contiguous blocks, RCCL all-gather of the head "
-                         "outputs inside the timed region, replicated stitching (see the module docstring)")
+                    help="BASELINE configs[3]: one long sequence, clips sharded over the ranks in contiguous blocks; all-gather #1 of the seediness "
+                         "planes, own-clip clustering, all-gather #2 of one-byte label codes (both inside the timed region), Hungarian chain on "
+                         "label-pair tables (see the module docstring)")
     ap.add_argument("--frames", type=int, default=64, help="--sequence: frames of the sequence (64 -> 15 clips at overlap 4; 36 -> 8)")
     ap.add_argument("--workload", default="davis", choices=sorted(WORKLOADS), help="BASELINE config to run (default: configs[1], the metric's)")
     ap.add_argument("--partition", default="clips", choices=["clips", "replicated"],
@@ -456,132 +461,161 @@ def main():
         return
     NC = max(1, args.clips_per_step)
     clips = [torch.cat([make_clip(1000 + rank * 97 + i * NC + c, device) for c in range(NC)], 0) for i in range(2)]
-
-    # Determinism monitor: the steps alternate between two clip batches, so every result of a batch must be bit-identical to the
-    # batch's first one, whichever lane produced it and whatever else was in flight.  Per clip one tiny device-side reduction (int64
-    # sum of the fp32 BIT PATTERNS of the embedding map: exact, order-independent), compared once after the timed region.
-    bitsums = {0: [], 1: []}
-
-    def read_back(outs, batch=None):                   # the consumer's read-back (K, centres): one small D2H per clip
-        if batch is not None:
-            bitsums[batch].append(torch.stack([o["emb"].view(torch.int32).sum(dtype=torch.int64) for o in outs]))
-        return [hip.read_cluster_meta(o["meta"]) for o in outs][-1]
-
-    def step(i):
-        return read_back(pipe.step_batch(clips[i % len(clips)], NC))
-
-    def sync():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-
-    meta = None
     overlap = not (args.graph or args.no_overlap)
-    if not overlap:
-        pipe.model.overlap_decoders = False      # (the captured graph is single-stream; warm up in the same mode)
-    for i in range(max(args.warmup, 1)):
-        meta = step(i)
-    sync()
-    mark("warmup done")
-    # The ~330 launches of a step are captured ONCE into a hipGraph (ClipPipeline.capture: encoder, both decoders, fg
-    # mask, gather, clustering rounds, all on one stream) and replayed per clip: the launch-bound tail of small kernels
-    # no longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
-    graph, lanes = None, []
-    if args.graph:
-        try:
-            lanes = [pipe.capture(clips[0], overlap=bool(args.graph_overlap), n_clips=NC, lane=k) for k in range(max(1, args.lanes))]
-            graph = lanes[0]
-            mark("capture done")
-        except Exception as e:  # noqa: BLE001
-            import traceback
-            traceback.print_exc()
-            print("[bench] hipGraph capture failed (%r); falling back to eager launches" % (e,), file=sys.stderr)
-            graph = None
-            pipe.model.overlap_decoders = overlap
+
+    def run_leg(precision, steps, warmup, lane0):
+        """One measured leg in MFMA mode ``precision``: warm-up, hipGraph capture per lane (lane ids from ``lane0``: own workspaces),
+        the timed region (barrier + synchronize on both sides), the determinism check, and the eager single-stream roofline pass.
+        -> dict(dt, meta, determinism, prof, n_roof, lanes, graph)"""
+        pipe.model.set_precision(precision)
+        # Determinism monitor: the steps alternate between two clip batches, so every result of a batch must be bit-identical to the
+        # batch's first one, whichever lane produced it and whatever else was in flight.  Per clip one tiny device-side reduction (int64
+        # sum of the fp32 BIT PATTERNS of the embedding map: exact, order-independent), compared once after the timed region.
+        bitsums = {0: [], 1: []}
+
+        def read_back(outs, batch=None):                   # the consumer's read-back (K, centres): one small D2H per clip
+            if batch is not None:
+                bitsums[batch].append(torch.stack([o["emb"].view(torch.int32).sum(dtype=torch.int64) for o in outs]))
+            return [hip.read_cluster_meta(o["meta"], o.get("status")) for o in outs][-1]      # (raises on a non-finite head output)
+
+        def step(i):
+            return read_back(pipe.step_batch(clips[i % len(clips)], NC))
+
+        def sync():
             torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
 
-    pending = [None] * len(lanes)
-    pending_batch = [None] * len(lanes)
+        meta = None
+        pipe.model.set_lane(lane0)
+        if not overlap:
+            pipe.model.overlap_decoders = False      # (the captured graph is single-stream; warm up in the same mode)
+        for i in range(max(warmup, 1)):
+            meta = step(i)
+        sync()
+        mark("warmup done (%s)" % precision)
+        # The ~330 launches of a step are captured ONCE into a hipGraph (ClipPipeline.capture: encoder, both decoders, fg
+        # mask, gather, clustering rounds, all on one stream) and replayed per clip: the launch-bound tail of small kernels
+        # no longer pays per-launch host latency.  Inputs are copied into the graph's static frame buffer (device-to-device).
+        graph, lanes = None, []
+        if args.graph:
+            try:
+                lanes = [pipe.capture(clips[0], overlap=bool(args.graph_overlap), n_clips=NC, lane=lane0 + k) for k in range(max(1, args.lanes))]
+                graph = lanes[0]
+                mark("capture done")
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                print("[bench] hipGraph capture failed (%r); falling back to eager launches" % (e,), file=sys.stderr)
+                graph = None
+                pipe.model.overlap_decoders = overlap
+                torch.cuda.synchronize()
+        pending = [None] * len(lanes)
+        pending_batch = [None] * len(lanes)
 
-    def step_graph(i):
-        """Step i goes to lane i % L: first consume (read back) what that lane produced L steps ago, then enqueue the new
-        batch on the lane's stream -- L steps are in flight."""
-        k = i % len(lanes)
-        m = None
-        if pending[k] is not None:
-            with torch.cuda.stream(lanes[k].stream):
-                m = read_back(pending[k], pending_batch[k])
-        pending[k] = lanes[k].run_async(clips[i % len(clips)])
-        pending_batch[k] = i % len(clips)
-        return m
-
-    def drain():
-        m = None
-        for k in range(len(lanes)):
+        def step_graph(i):
+            """Step i goes to lane i % L: first consume (read back) what that lane produced L steps ago, then enqueue the new
+            batch on the lane's stream -- L steps are in flight."""
+            k = i % len(lanes)
+            m = None
             if pending[k] is not None:
                 with torch.cuda.stream(lanes[k].stream):
                     m = read_back(pending[k], pending_batch[k])
-                pending[k] = None
-        return m
+            pending[k] = lanes[k].run_async(clips[i % len(clips)])
+            pending_batch[k] = i % len(clips)
+            return m
 
-    run = step_graph if graph is not None else step
-    for i in range(2 * max(1, len(lanes))):
-        meta = run(i) or meta
-        mark("pre-run %d done" % i)
-    meta = drain() or meta
-    sync()
-    hip.profile_enable(graph is None)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        meta = run(i) or meta
-    meta = drain() or meta
-    sync()
-    dt = time.perf_counter() - t0
-    mark("timed region done")
-    determinism = None
-    if graph is not None:
-        checked = mismatching = 0
-        for b, rows in bitsums.items():
-            if rows:
-                t = torch.stack([r.to(device) for r in rows]).cpu()
-                checked += int(t.numel())
-                mismatching += int((t != t[0:1]).sum())
-        determinism = {"clip_results_checked": checked, "mismatching": mismatching,
-                       "what": "int64 sum of the fp32 bit patterns of every clip's embedding map, every step since the first replay (pre-runs and "
-                               "timed region, %d lanes in flight), against the first result of the same input batch" % len(lanes)}
-        if mismatching:
-            print("[bench] WARNING: %d of %d clip results differ bitwise from the first result of their batch" % (mismatching, checked), file=sys.stderr)
-    hip.profile_enable(True)
-    prof_concurrent = hip.profile_read()
-    # Roofline pass: under stream concurrency the per-launch elapsed times overlap and are not additive, so the dominant
-    # kernel is timed (same hipEvent pairs, same clips) over a few extra steps with every launch on one stream.
-    pipe.model.overlap_decoders = False
-    for i in range(2):
-        step(i)
-    hip.profile_read()
-    n_roof = max(2, min(5, args.steps))
-    for i in range(n_roof):
-        step(i)
-    prof = hip.profile_read()
-    hip.profile_enable(False)
-    pipe.model.overlap_decoders = overlap
+        def drain():
+            m = None
+            for k in range(len(lanes)):
+                if pending[k] is not None:
+                    with torch.cuda.stream(lanes[k].stream):
+                        m = read_back(pending[k], pending_batch[k])
+                    pending[k] = None
+            return m
+
+        run = step_graph if graph is not None else step
+        for i in range(2 * max(1, len(lanes))):
+            meta = run(i) or meta
+            mark("pre-run %d done" % i)
+        meta = drain() or meta
+        sync()
+        hip.profile_enable(graph is None)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            meta = run(i) or meta
+        meta = drain() or meta
+        sync()
+        dt = time.perf_counter() - t0
+        mark("timed region done")
+        determinism = None
+        if graph is not None:
+            checked = mismatching = 0
+            for b, rows in bitsums.items():
+                if rows:
+                    t = torch.stack([r.to(device) for r in rows]).cpu()
+                    checked += int(t.numel())
+                    mismatching += int((t != t[0:1]).sum())
+            determinism = {"clip_results_checked": checked, "mismatching": mismatching,
+                           "what": "int64 sum of the fp32 bit patterns of every clip's embedding map, every step since the first replay (pre-runs and "
+                                   "timed region, %d lanes in flight), against the first result of the same input batch; a mismatch makes the bench "
+                                   "exit non-zero without a line" % len(lanes)}
+            if mismatching:
+                print("[bench] FAILED: %d of %d clip results differ bitwise from the first result of their batch (%s): no line is printed"
+                      % (mismatching, checked, precision), file=sys.stderr)
+                sys.exit(5)
+        hip.profile_enable(True)
+        hip.profile_read()
+        # Roofline pass: under stream concurrency the per-launch elapsed times overlap and are not additive, so the dominant
+        # kernel is timed (same hipEvent pairs, same clips) over a few extra steps with every launch on one stream.
+        pipe.model.set_lane(lane0)
+        pipe.model.overlap_decoders = False
+        for i in range(2):
+            step(i)
+        hip.profile_read()
+        n_roof = max(2, min(5, steps))
+        for i in range(n_roof):
+            step(i)
+        prof = hip.profile_read()
+        hip.profile_enable(False)
+        pipe.model.overlap_decoders = overlap
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dict(dt=dt, meta=meta, determinism=determinism, prof=prof, n_roof=n_roof, lanes=lanes, graph=graph)
+
+    def k3_class(prof, precision):
+        """(achieved TFLOP/s, peak, ms, flop, launches) of the 3x3x3 implicit-GEMM class in mode ``precision``"""
+        peak = PEAK_MFMA_F32_TFLOPS if precision == "f32" else PEAK_MFMA_BF16_TFLOPS / PRODUCTS[precision]
+        k3 = [prof[t] for t in hip.PROFILE_CONV_TAGS["conv3x3x3"] if t in prof]
+        ms, fl, launches = sum(p[0] for p in k3), sum(p[1] for p in k3), sum(p[2] for p in k3)
+        return ((fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0), peak, ms, fl, launches
+
+    leg = run_leg(args.precision, args.steps, args.warmup, 0)
+    dt, meta, determinism, prof, n_roof, lanes, graph = (leg[k] for k in ("dt", "meta", "determinism", "prof", "n_roof", "lanes", "graph"))
+    # Reference-width legs (VERDICT round 3): the same step, graph replay and lanes in the modes whose arithmetic is at least as wide as
+    # the reference's fp32 -- bf16x6 (24 significand bits per operand, fp32's exponent range) and f32 (fp32-input MFMA) -- each over
+    # a shorter timed region, so that the line carries their throughput and roofline fraction next to the default mode's.
+    alt = {}
+    if world == 1 and not args.no_alt_precision and args.workload == "davis":
+        for j, prec in enumerate(p_ for p_ in ("bf16x6", "f32") if p_ != args.precision):
+            a = run_leg(prec, args.alt_steps, 1, 100 * (j + 1))
+            ach_a, peak_a, ms_a, _, _ = k3_class(a["prof"], prec)
+            alt[prec] = {"value": round(args.alt_steps * NC / a["dt"], 4), "unit": "clips/s", "steps": args.alt_steps, "ms_per_step": round(1e3 * a["dt"] / args.alt_steps, 3),
+                         "determinism_mismatching": a["determinism"]["mismatching"] if a["determinism"] else None,
+                         "roofline_3x3x3": {"achieved": round(ach_a, 2), "peak": round(peak_a, 1), "frac": round(ach_a / peak_a, 4), "unit": "TFLOP/s (fp32-equivalent)"}}
+            del a
+        pipe.model.set_precision(args.precision)
+        pipe.model.set_lane(0)
     ranks = rank_devices(device, rank, world, use_dist)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl":
-            assert len({r["device"] for r in ranks}) == world, "ranks share a device: %s" % (ranks,)
+    if use_dist and os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl":
+        assert len({r["device"] for r in ranks}) == world, "ranks share a device: %s" % (ranks,)
 
     if rank == 0:
         clips_total = args.steps * world * NC
         # dominant kernel: the 3x3x3 implicit-GEMM conv (all tile shapes)
-        peak = PEAK_MFMA_F32_TFLOPS if args.precision == "f32" else PEAK_MFMA_BF16_TFLOPS / PRODUCTS[args.precision]
-        k3 = [prof[t] for t in hip.PROFILE_CONV_TAGS["conv3x3x3"] if t in prof]
-        ms = sum(p[0] for p in k3)
-        fl = sum(p[1] for p in k3)
-        launches = sum(p[2] for p in k3)
-        ach = (fl / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        ach, peak, ms, fl, launches = k3_class(prof, args.precision)
         per_clip = 1.0 / (n_roof * NC)
 
         def cls(tags):
@@ -616,6 +650,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": PRECISION_DTYPE[args.precision],
             "data": "synthetic",
+            "alt_precision": alt if alt else None,
             "config": {"workload": WL["name"], "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}, "determinism": determinism,
                        "precision": {"mode": args.precision, "note": PRECISION_NOTE[args.precision]},

@@ -178,6 +178,12 @@ int stemseg_hip_heads(const float* x, int32_t Cin, int32_t T, int32_t H, int32_t
                       const int32_t* grid_axis_host, const float* grid_t, const float* grid_y, const float* grid_x,
                       float* out, void* stream);
 
+/* Overflow guard: flags[b] = 1 when chunk b (of n_flags equal chunks) of x holds an inf / NaN, else 0; every flag is rewritten by
+ * every call (no reset needed, graph-replay safe).  The split convolution modes have a finite operand range (f16x3: |activation| <
+ * 2.6e5); beyond it their outputs are non-finite BY CONSTRUCTION and the ReLUs / pools keep NaN, so a non-finite head output is the
+ * signal to re-run the clip in STEMSEG_PRECISION_BF16X6 (fp32's range) -- never cluster such maps (ClipPipeline.step_checked). */
+int stemseg_hip_nonfinite_flags(const float* x, int64_t n, int32_t* flags, int32_t n_flags, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole decoder: SqueezingExpandDecoder.forward (embedding_decoder.py:101-145) and the seediness twin
  * (seediness_decoder.py:92-112), optionally with the bandwidth activation of inference_model.py:148.

@@ -825,7 +825,17 @@ extern "C" int stemseg_hip_cluster(const float* emb, const float* bw, const floa
     // against the multi-launch form below, which stays the default -- see DESIGN.md
     static const int persistent = [] { const char* e = getenv("STEMSEG_CLUSTER_PERSISTENT"); return e ? atoi(e) : 0; }();
     const long long cap4 = (long long)CP_BLOCKS * CP_THREADS * 4, cap12 = (long long)CP_BLOCKS * CP_THREADS * 12;
-    if (persistent && !opt_masks && !opt_probs && n_max <= cap12 && ws_bytes >= stemseg_hip_cluster_workspace_bytes(n_max)) {
+    // the grid barrier needs all CP_BLOCKS workgroups resident together: refuse the form where the device cannot hold them even
+    // when it is otherwise idle (a smaller part, a register-hungrier build); co-running kernels of other streams can still delay
+    // residency -- the kernel then spins up to CP_SPIN_LIMIT and reports K = -1, which every read-back path turns into an error
+    static const bool fits = [] {
+        int dev = 0, cus = 0, b4 = 0, b12 = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, cluster_persistent_kernel<4>, CP_THREADS, 0) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, cluster_persistent_kernel<12>, CP_THREADS, 0) != hipSuccess) return false;
+        return (long long)std::min(b4, b12) * cus >= CP_BLOCKS;
+    }();
+    if (persistent && fits && !opt_masks && !opt_probs && n_max <= cap12 && ws_bytes >= stemseg_hip_cluster_workspace_bytes(n_max)) {
         ClusterSync* sy = reinterpret_cast<ClusterSync*>(p.partials);
         hipLaunchKernelGGL(cluster_persistent_init_kernel, dim3(1), dim3(256), 0, s, sy, meta_dev);
         SS_LAUNCH_CHECK();
@@ -939,9 +949,12 @@ extern "C" int stemseg_hip_pair_tables(const uint8_t* codes, const int32_t* plan
     hipStream_t s = as_stream(stream);
     SS_HIP(hipMemsetAsync(tables, 0, sizeof(int32_t) * (size_t)n_items * B * B, s));
     if (HW == 0) return STEMSEG_OK;
-    hipLaunchKernelGGL(pair_tables_kernel, dim3(grid_for(HW, 256 * 8, 64), (unsigned)n_items), dim3(256), sizeof(unsigned int) * B * B, s, codes,
-                       plane_a, plane_b, (long long)HW, B, reinterpret_cast<unsigned int*>(tables));
-    SS_LAUNCH_CHECK();
+    for (int32_t i0 = 0; i0 < n_items; i0 += 65535) {                 // (gridDim.y <= 65535: long sequences take several launches)
+        const int32_t ni = std::min<int32_t>(65535, n_items - i0);
+        hipLaunchKernelGGL(pair_tables_kernel, dim3(grid_for(HW, 256 * 8, 64), (unsigned)ni), dim3(256), sizeof(unsigned int) * B * B, s, codes,
+                           plane_a + i0, plane_b + i0, (long long)HW, B, reinterpret_cast<unsigned int*>(tables) + (size_t)i0 * B * B);
+        SS_LAUNCH_CHECK();
+    }
     return STEMSEG_OK;
 }
 
@@ -950,9 +963,12 @@ extern "C" int stemseg_hip_codes_to_labels(const uint8_t* codes, const int32_t* 
     SS_CHECK_ARG(n_items >= 0 && max_count >= 0 && HW >= 0 && B >= 3 && B <= STEMSEG_MAX_INSTANCES + 2, "codes_to_labels: bad arguments");
     if (n_items == 0 || max_count == 0) return STEMSEG_OK;
     SS_CHECK_ARG(codes && voxel_index && items && lut && out, "codes_to_labels: null pointer");
-    hipLaunchKernelGGL(codes_to_labels_kernel, dim3(grid_for(max_count, 256 * 4, 256), (unsigned)n_items), dim3(256), 0, as_stream(stream), codes,
-                       voxel_index, reinterpret_cast<const long long*>(items), reinterpret_cast<const long long*>(lut), (long long)HW, B,
-                       reinterpret_cast<long long*>(out));
-    SS_LAUNCH_CHECK();
+    for (int32_t i0 = 0; i0 < n_items; i0 += 65535) {
+        const int32_t ni = std::min<int32_t>(65535, n_items - i0);
+        hipLaunchKernelGGL(codes_to_labels_kernel, dim3(grid_for(max_count, 256 * 4, 256), (unsigned)ni), dim3(256), 0, as_stream(stream), codes,
+                           voxel_index, reinterpret_cast<const long long*>(items) + (size_t)i0 * 5, reinterpret_cast<const long long*>(lut) + (size_t)i0 * B,
+                           (long long)HW, B, reinterpret_cast<long long*>(out));
+        SS_LAUNCH_CHECK();
+    }
     return STEMSEG_OK;
 }

@@ -130,7 +130,28 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
     return rc;
 }
 
+// flags[b] = 1 when chunk b of x holds a non-finite value, else 0 -- every flag is (re)written by every launch (no reset, no atomics)
+__global__ __launch_bounds__(256) void nonfinite_flags_kernel(const float* __restrict__ x, long long n, int* __restrict__ flags) {
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int bad = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const unsigned int u = __float_as_uint(x[i]);
+        bad |= (u & 0x7f800000u) == 0x7f800000u;                       // exponent all ones: inf or NaN
+    }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 1 : 0;
+}
+
 }  // namespace stemseg
+
+extern "C" int stemseg_hip_nonfinite_flags(const float* x, int64_t n, int32_t* flags, int32_t n_flags, void* stream) {
+    using namespace stemseg;
+    SS_CHECK_ARG(flags && n >= 0 && n_flags >= 1 && n_flags <= 4096 && (x || n == 0), "nonfinite_flags: bad arguments");
+    hipLaunchKernelGGL(nonfinite_flags_kernel, dim3((unsigned)n_flags), dim3(256), 0, as_stream(stream), x, (long long)n, flags);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
 
 extern "C" int stemseg_hip_heads(const float* x, int32_t Cin, int32_t T, int32_t H, int32_t W, const float* w, const float* bias,
                                  int32_t n_out, const int32_t* act_host, const int32_t* grid_axis_host, const float* grid_t,

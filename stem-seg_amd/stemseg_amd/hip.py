@@ -101,6 +101,7 @@ SIGNATURES = {
     "stemseg_hip_upsample_trilinear": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(Volume), _P]),
     "stemseg_hip_copy_to_volume": (C.c_int, [_P, _I32, C.POINTER(Volume), _P]),
     "stemseg_hip_heads": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I32, C.POINTER(_I32), C.POINTER(_I32), _P, _P, _P, _P, _P]),
+    "stemseg_hip_nonfinite_flags": (C.c_int, [_P, _I64, _P, _I32, _P]),
     "stemseg_hip_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDesc)]),
     "stemseg_hip_decoder_init_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_forward": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(_P), _P, _P, C.c_size_t, _P]),
@@ -357,6 +358,41 @@ def heads(x, w, bias, act, grid_axis, gt, gy, gx):
     return out
 
 
+NONFINITE_FLAGS = 64
+
+
+class NonFiniteError(FloatingPointError):
+    """A head output (embedding / bandwidth / seediness / class logits) of a clip holds inf or NaN: an operand left the range of
+    the split convolution mode (f16x3: |activation| < 2.6e5).  Re-run the clip in 'bf16x6' (ClipPipeline.step_checked does)."""
+
+
+def nonfinite_flags(x, flags=None):
+    """x: contiguous float32 device tensor -> int32 [NONFINITE_FLAGS] on the device (1 where a chunk of x holds inf / NaN); no
+    synchronisation.  ``flags``: an existing int32 view to (re)write."""
+    if flags is None:
+        flags = torch.empty(NONFINITE_FLAGS, dtype=torch.int32, device=x.device)
+    assert x.is_contiguous() and x.dtype == torch.float32 and flags.numel() == NONFINITE_FLAGS
+    check(lib().stemseg_hip_nonfinite_flags(ptr(x), x.numel(), ptr(flags, torch.int32), NONFINITE_FLAGS, stream()))
+    return flags
+
+
+def overflow_status(tensors):
+    """Overflow flags of a clip's head outputs: int32 [k, NONFINITE_FLAGS] on the device, one launch per run of tensors that are
+    adjacent in memory (embeddings and bandwidths are channel slices of one decoder output).  No synchronisation; hand the result to
+    ``read_cluster_meta(meta, status)``."""
+    runs = []
+    for t in tensors:
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+        if runs and runs[-1][0] + 4 * runs[-1][1] == t.data_ptr():
+            runs[-1][1] += t.numel()
+        else:
+            runs.append([t.data_ptr(), t.numel(), t])
+    status = torch.empty(len(runs), NONFINITE_FLAGS, dtype=torch.int32, device=tensors[0].device)
+    for i, (p_, n, _) in enumerate(runs):
+        check(lib().stemseg_hip_nonfinite_flags(C.c_void_p(p_), n, ptr(status[i], torch.int32), NONFINITE_FLAGS, stream()))
+    return status
+
+
 # ------------------------------------------------------------------------------------------------ clustering ops
 def seediness_accumulate(acc, plane, first):
     check(lib().stemseg_hip_seediness_accumulate(ptr(acc, torch.float32), ptr(plane, torch.float32), plane.numel(), int(first), stream()))
@@ -429,17 +465,28 @@ def cluster(emb, bw, seed, params, label_start, n_points_dev=None, want_masks=Fa
 _meta_pinned = {}
 
 
-def read_cluster_meta(meta_dev):
+def read_cluster_meta(meta_dev, status=None):
     """Device->host copy of the StemsegClusterMeta record (synchronises the current stream).  The copy lands in a
     persistent PINNED host buffer: a direct DMA, no pageable staging (``.cpu()`` on a tensor that lives in a hipGraph's
-    private pool was seen to fault the GPU after a few replays on ROCm 7.2)."""
+    private pool was seen to fault the GPU after a few replays on ROCm 7.2).  ``status``: the clip's overflow flags
+    (nonfinite_flags, int32 on the device), read with the same synchronisation; raises NonFiniteError when one is set."""
     n = meta_dev.numel()
     key = (meta_dev.device.index, n)
     buf = _meta_pinned.get(key)
     if buf is None:
         buf = _meta_pinned[key] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
     buf.copy_(meta_dev, non_blocking=True)
+    sbuf = None
+    if status is not None:
+        skey = (meta_dev.device.index, "status", status.numel())
+        sbuf = _meta_pinned.get(skey)
+        if sbuf is None:
+            sbuf = _meta_pinned[skey] = torch.empty(status.numel(), dtype=torch.int32, pin_memory=True)
+        sbuf.copy_(status.reshape(-1), non_blocking=True)
     torch.cuda.current_stream(meta_dev.device).synchronize()
+    if sbuf is not None and bool(sbuf.any()):
+        raise NonFiniteError("a head output of this clip holds inf / NaN (an operand left the convolution mode's range): not clustered "
+                             "results -- re-run the clip with precision 'bf16x6'")
     meta = ClusterMeta.from_buffer_copy(buf.numpy().tobytes())
     if meta.K < 0:
         raise RuntimeError("stemseg_hip_cluster: the one-launch clusterer's grid barrier timed out (STEMSEG_CLUSTER_PERSISTENT)")

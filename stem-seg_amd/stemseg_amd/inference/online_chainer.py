@@ -198,6 +198,11 @@ class HipChainerOps(object):
     def unpack_meta(self, raw):
         return hip.ClusterMeta.from_buffer_copy(bytes(raw))
 
+    def overflow_byte(self, block):
+        """uint8 device scalar: 1 when the clip's head outputs (a tuple of tensors or one stacked block) hold inf / NaN; no sync."""
+        ts = [t.contiguous() for t in (block if isinstance(block, (tuple, list)) else [block])]
+        return hip.overflow_status(ts).any().to(torch.uint8)
+
     def pair_tables(self, codes, plane_a, plane_b, B):
         dev = codes.device
         return hip.pair_tables(codes, torch.as_tensor(plane_a, dtype=torch.int32).to(dev, non_blocking=True),

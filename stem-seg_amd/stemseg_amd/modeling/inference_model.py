@@ -81,6 +81,7 @@ class InferenceModel(nn.Module):
         self.eval()
 
     semseg_outputs_on_cpu = False       # True under stemseg_amd.overlay: the reference's writers index these on the host
+    overflow_fallback = "bf16x6"        # mode a sequence is re-run in when a head output comes back non-finite (None: raise instead)
     has_semseg_head = property(lambda self: self._model.semseg_head is not None)
     mask_scale = property(lambda self: self._model.semseg_output_scale)                 # inference_model.py:43-45
 
@@ -113,7 +114,7 @@ class InferenceModel(nn.Module):
                 mod.lane = self.lane
 
     def set_precision(self, precision):
-        """'f32' (exact fp32 MFMA, default) or 'bf16x3' (3-term bf16 split on the bf16 matrix cores, fp32 accumulate)."""
+        """MFMA mode of every convolution: 'f16x3' (default), 'bf16x6', 'f32', 'bf16x3' (hip.PRECISIONS)."""
         assert precision in hip.PRECISIONS, precision
         m = self._model
         for mod in (m.backbone, m.embedding_head, m.seediness_head, m.semseg_head):
@@ -291,7 +292,7 @@ class InferenceModel(nn.Module):
         for i, sub in enumerate(subseq_idxes):
             for t in sub:
                 deps.setdefault(t, set()).add(i)
-        maps = []
+        maps, overflow = [], []
         acc, counts = None, [0] * len(frames)
         for i, sub in enumerate(subseq_idxes):
             need = sorted(set(t for t in sub if t not in cache))
@@ -300,8 +301,10 @@ class InferenceModel(nn.Module):
                 for j, t in enumerate(need):
                     cache[t] = {s: f[:, j] for s, f in zip((4, 8, 16, 32), feats)}
             emb, bw, seed = self.embed_clip([cache[t] for t in sub], len(sub), H, W)
+            overflow.append(hip.overflow_status([emb.contiguous(), bw.contiguous(), seed.contiguous()]))
             if self.has_semseg_head:                                                    # same zero-haloed inputs, third decoder
                 logits = self.semseg_logits_clip(len(sub), H, W, emb.device)
+                overflow.append(hip.overflow_status([logits]))
                 if acc is None:
                     acc = torch.zeros((len(frames), logits.shape[0]) + tuple(logits.shape[2:]), dtype=torch.float32, device=logits.device)
                 self._accumulate_semseg(acc, counts, logits, sub)
@@ -317,5 +320,18 @@ class InferenceModel(nn.Module):
                 if not deps[t]:
                     cache.pop(t, None)
                     del deps[t]
+        # Overflow policy (one 4-byte read per sequence): the split convolution modes have a finite operand range (f16x3: |activation|
+        # < 2.6e5) and answer an overflow with non-finite outputs, which every ReLU / pool on the way keeps.  A sequence whose head
+        # outputs are not all finite is re-run ONCE in bf16x6 (fp32's exponent range); never hand NaN maps to the clusterer.
+        if overflow and bool(torch.cat([o.reshape(-1) for o in overflow]).any().item()):
+            before = {n_: getattr(m, n_).precision for n_ in ("backbone", "embedding_head", "seediness_head", "semseg_head") if getattr(m, n_) is not None}
+            if self.overflow_fallback is None or all(v == self.overflow_fallback for v in before.values()):
+                raise hip.NonFiniteError("head outputs hold inf / NaN (convolution mode %s)" % sorted(set(before.values())))
+            self.set_precision(self.overflow_fallback)
+            try:
+                return self.forward(frames, subseq_idxes)
+            finally:
+                for n_, v in before.items():
+                    getattr(m, n_).precision = v
         fg_masks, multiclass_masks = self.get_semseg_masks(acc, counts)
         return {"fg_masks": fg_masks, "multiclass_masks": multiclass_masks, "embeddings": maps}

@@ -2,12 +2,14 @@
 
 * ``ClipPipeline.step`` is BASELINE.json's unit of work: one T-frame clip through encoder -> two 3-D decoders ->
   fused heads -> fg mask -> fg gather -> sequential clustering, all enqueued on one HIP stream with no host
-  synchronisation (N, K and the instance list stay on the device until the caller reads them).
-* ``run_sequence_sharded`` is the one-process-per-GPU form for long sequences: every rank takes a contiguous block of
-  the clips and embeds it (frames shared by neighbouring clips of the block pass the encoder trunk once), ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests)
-  exchanges the per-clip head outputs (<= 5.8 MB per clip at 480p), and the cheap chain (fg mask from the
-  cross-clip mean seediness, clustering, Hungarian stitching: < 1 % of the work) is replicated so every rank
-  ends with the single-process result bit for bit.
+  synchronisation (N, K, the instance list and the overflow flags stay on the device until the caller reads them).
+* ``run_sequence_sharded`` is the one-process-per-GPU form for long sequences, partitioned as SURVEY.md section 8(e) lays out:
+  every rank takes a contiguous block of the clips, embeds it (frames shared by neighbouring clips of the block pass the encoder
+  trunk once) AND clusters it with label_start = 1; two small all-gathers (RCCL over xGMI on the GPU box, gloo in the CPU tests)
+  carry the foreground evidence (seediness planes, or the semseg head's foreground probability) and then one byte per voxel of
+  clip-local label codes + the clustering records; the Hungarian chain runs on label-pair tables, so every rank ends with the
+  single-process result bit for bit.  ``run_sequence_replicated`` keeps the round-2 form (all head outputs gathered, chain
+  replicated) for A/B runs.
 """
 import torch
 
@@ -48,6 +50,7 @@ class ClipPipeline(object):
         (inference_model.py:197-231, inference/main.py:142-144); under --resize_embeddings the head outputs are up-sampled x4 and
         the clip is clustered at full resolution (online_chainer.py:127-140)."""
         fg, logits = None, None
+        emb0, bw0, seed0 = emb, bw, seed                     # the decoders' own outputs (before any resize)
         if self.model.has_semseg_head:
             logits = self.model.semseg_logits_clip(T, H, W, emb.device, slot=slot)
             fg, _ = hip.semseg_fg_clip(logits, 0.5)
@@ -56,8 +59,11 @@ class ClipPipeline(object):
             emb, bw = hip.upsample_trilinear(emb.contiguous(), 1, r, r), hip.upsample_trilinear(bw.contiguous(), 1, r, r)
             if seed.shape[-1] != emb.shape[-1]:          # (a separate seediness head is already resized by the model, :156)
                 seed = hip.upsample_trilinear(seed.contiguous(), 1, r, r)
+        # overflow guard: a non-finite head output (an operand left the split convolution mode's range) is flagged on the device and
+        # read with the clustering record -- such maps are never clustered silently (hip.read_cluster_meta raises NonFiniteError)
+        status = hip.overflow_status([t.contiguous() for t in ([emb0, bw0, seed0] + ([logits] if logits is not None else []))])
         out = self.cluster(emb, bw, seed, fg=fg)
-        out.update(emb=emb, bw=bw, seed=seed)
+        out.update(emb=emb, bw=bw, seed=seed, status=status)
         if logits is not None:
             out["semseg_logits"] = logits
         return out
@@ -67,6 +73,28 @@ class ClipPipeline(object):
         T, _, H, W = frames.shape
         emb, bw, seed = self.embed(frames)
         return self._finish_clip(emb, bw, seed, T, H, W)
+
+    @torch.no_grad()
+    def step_checked(self, frames, fallback_precision="bf16x6"):
+        """``step`` + the consumer's read-back, with the overflow policy: when a head output of the clip is non-finite (an activation
+        left the range of the split convolution mode, e.g. |a| >= 2.6e5 in f16x3) the clip is re-run ONCE in ``fallback_precision``
+        (bf16x6: fp32's full exponent range, twice the matrix work) and the model's mode is restored; still non-finite -> raises
+        hip.NonFiniteError.  -> (step dict, StemsegClusterMeta on the host)."""
+        out = self.step(frames)
+        try:
+            return out, hip.read_cluster_meta(out["meta"], out["status"])
+        except hip.NonFiniteError:
+            m = self.model._model
+            before = {name: getattr(m, name).precision for name in ("backbone", "embedding_head", "seediness_head", "semseg_head") if getattr(m, name) is not None}
+            if all(v == fallback_precision for v in before.values()):
+                raise
+            self.model.set_precision(fallback_precision)
+            try:
+                out = self.step(frames)
+                return out, hip.read_cluster_meta(out["meta"], out["status"])
+            finally:
+                for name, v in before.items():
+                    getattr(m, name).precision = v
 
     @torch.no_grad()
     def step_batch(self, frames, n_clips):
@@ -319,7 +347,7 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     vox_all, offs_all = ops.compact(fg)
 
     # ---- 3. cluster this rank's clips with label_start = 1; one byte per voxel ------------------------------------------
-    meta_planes = (ops.meta_bytes() + hw - 1) // hw
+    meta_planes = (ops.meta_bytes() + 1 + hw - 1) // hw                # clustering record + one overflow byte per clip
     P = T + meta_planes                                               # planes per clip in the exchange buffer
     codes_local = torch.zeros((per_rank, P * hw), dtype=torch.uint8, device=dev)
     for slot, ci in enumerate(mine):
@@ -332,6 +360,8 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
         labels, meta_dev, _ = ops.cluster(clusterer, pts, 1, False)
         ops.codes_from_labels(pts, labels, 1, codes_local[slot, :len(uniq[ci]) * hw])
         codes_local[slot, T * hw:T * hw + ops.meta_bytes()] = ops.pack_meta(meta_dev)
+        # overflow guard: one byte per clip travels with the record, so EVERY rank refuses a sequence with a non-finite head output
+        codes_local[slot, T * hw + ops.meta_bytes()] = ops.overflow_byte(blocks[slot])
 
     # ---- 4. all-gather #2: label codes + clustering records -------------------------------------------------------------
     if distributed and world > 1:
@@ -359,12 +389,22 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
             plane_b.append(plane_index(ci, j))
     B = clusterer.max_instances + 2
     tables_dev = ops.pair_tables(planes, plane_a, plane_b, B)
-    meta_rows = codes_all.view(world * per_rank, P * hw)[:, T * hw:T * hw + ops.meta_bytes()]
+    meta_rows = codes_all.view(world * per_rank, P * hw)[:, T * hw:T * hw + ops.meta_bytes() + 1]
     tables, offs, meta_raw = ops.read_back(tables_dev, offs_all, meta_rows.contiguous())
     metas = []
     for ci in range(n_clips):
         owner, slot = plane_of(ci)
-        metas.append(ops.unpack_meta(meta_raw[owner * per_rank + slot].tobytes()))
+        row = meta_raw[owner * per_rank + slot]
+        if int(row[-1]) != 0:
+            raise hip.NonFiniteError("clip %d (rank %d): a head output holds inf / NaN (an operand left the convolution mode's range) -- "
+                                     "re-run the sequence with precision 'bf16x6'" % (ci, owner))
+        m_ = ops.unpack_meta(row[:-1].tobytes())
+        if int(m_.K) < 0:                                   # (the opt-in one-launch clusterer reports a timed-out grid barrier as K = -1)
+            raise RuntimeError("clip %d (rank %d): the clusterer reported K = %d (STEMSEG_CLUSTER_PERSISTENT grid barrier timed out)" % (ci, owner, int(m_.K)))
+        # (labels are i + label_start with i < K: with K <= max_instances every code is <= B - 2, so the out-of-range clamp of
+        # labels_to_codes_kernel cannot be reached -- checked here rather than trusted)
+        assert int(m_.K) <= clusterer.max_instances, "clip %d: K = %d exceeds max_instances = %d" % (ci, int(m_.K), clusterer.max_instances)
+        metas.append(m_)
     t_host = time.perf_counter()
     st = stitch_from_tables(uniq, tables, item_of, [m.K for m in metas], B)
     host_ms = 1e3 * (time.perf_counter() - t_host)

@@ -111,6 +111,10 @@ class OracleChainerOps(object):
         from stemseg_amd import hip
         return hip.ClusterMeta.from_buffer_copy(bytes(raw))
 
+    def overflow_byte(self, block):
+        ts = block if isinstance(block, (tuple, list)) else [block]
+        return torch.tensor(0 if all(bool(torch.isfinite(t).all()) for t in ts) else 1, dtype=torch.uint8)
+
     @staticmethod
     def _bins(c, B):
         c = c.astype(np.int64)

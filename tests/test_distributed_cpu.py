@@ -165,3 +165,27 @@ def test_shard_clips_contiguous_blocks():
             blocks = [shard_clips(n, r, w) for r in range(w)]
             assert sum(blocks, []) == list(range(n)) and max(map(len, blocks)) - min(map(len, blocks)) <= 1
             assert all(clip_owner(ci, n, w) == (r, k) for r, b in enumerate(blocks) for k, ci in enumerate(b))
+
+
+def test_sharded_sequence_refuses_a_non_finite_head_output_on_every_rank():
+    """Overflow guard of the clip-parallel path: the owner of a clip whose head outputs hold NaN flags it in the byte that travels
+    with the clustering record, and EVERY rank raises (none stitches NaN-derived labels)."""
+    from stemseg_amd import config, hip, pipeline
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    from tests.oracle_ops import OracleChainerOps
+    from tests.virtual_ranks import run_virtual_ranks
+    emb, bw, sd, fg, clips, overlap, _ = _case("seq20_ov4")
+    emb = emb.copy()
+    emb[1, clips[2][3], 2, 5] = np.nan                      # one voxel of a frame only clip 2 (and its neighbours) holds
+    config.load_preset("davis")
+
+    def one(comm):
+        chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 1.0, ops=OracleChainerOps())
+        embed = lambda fr: (torch.from_numpy(emb[:, fr].copy()), torch.from_numpy(bw[:, fr].copy()), torch.from_numpy(sd[:, fr].copy()))
+        try:
+            pipeline.run_sequence_sharded(fg.shape[0], embed, chainer, "davis", frame_overlap=overlap, fg_mask_fn=lambda e, t: torch.from_numpy(fg), comm=comm)
+        except hip.NonFiniteError:
+            return True
+        return False
+    assert all(run_virtual_ranks(3, one))

@@ -985,6 +985,65 @@ def test_overlap_counts_ids_beyond_500_and_large_tables(hip):
         ops.present_ids([dev(np.array([5, 900], np.int64))], cap=100)                                # a wrong bound is caught
 
 
+def test_nonfinite_flags_op(hip):
+    x = torch.randn(7, 1000, device="cuda")
+    assert int(hip.nonfinite_flags(x).sum()) == 0
+    x[3, 500] = float("inf")
+    x[6, 999] = float("nan")
+    f = hip.nonfinite_flags(x).cpu().numpy()
+    n, per = x.numel(), -(-x.numel() // hip.NONFINITE_FLAGS)
+    assert f.sum() == 2 and f[(3 * 1000 + 500) // per] == 1 and f[(n - 1) // per] == 1
+    x[3, 500], x[6, 999] = 0.0, 0.0
+    assert int(hip.nonfinite_flags(x, hip.nonfinite_flags(x)).sum()) == 0                 # flags are rewritten, not accumulated
+    st = hip.overflow_status([x[:4], x[4:], torch.full((5,), float("-inf"), device="cuda")])    # adjacent views -> one run
+    assert tuple(st.shape) == (2, hip.NONFINITE_FLAGS) and int(st[0].sum()) == 0 and int(st[1].sum()) >= 1
+
+
+def test_overflow_guard_reruns_the_clip_in_bf16x6(hip):
+    """Frames scaled far beyond pixel range drive the first f16x3 convolutions past |activation| = 2.6e5: the head outputs come back
+    non-finite (every ReLU / pool on the way keeps NaN), the clustering read-back raises instead of returning labels, and
+    ``ClipPipeline.step_checked`` re-runs the clip in bf16x6 (fp32's exponent range) -- same result as a plain bf16x6 run -- and
+    restores the model's mode."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset("davis")
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        model = InferenceModel()
+        sd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 29))).reshape(v.shape) for k, v in sd.items()}
+        new["seediness_head.conv_out.weight"] = new["seediness_head.conv_out.weight"] * 40.0
+        model._model.load_state_dict(new)
+        model.set_precision("f16x3")
+        pipe = ClipPipeline(model, seediness_thresh=0.5)
+        clip = dev(synth.synth_frames(8, 96, 160, seed=4).astype(np.float32).transpose(0, 3, 1, 2) - 110.0)
+        ok = pipe.step(clip)
+        assert int(ok["status"].sum()) == 0 and hip.read_cluster_meta(ok["meta"], ok["status"]).K >= 0
+        big = clip * 3.0e4
+        bad = pipe.step(big)
+        assert int(bad["status"].sum()) > 0 and not bool(torch.isfinite(bad["emb"]).all())
+        with pytest.raises(hip.NonFiniteError):
+            hip.read_cluster_meta(bad["meta"], bad["status"])
+        out, meta = pipe.step_checked(big)
+        assert model._model.backbone.precision == "f16x3" and model._model.embedding_head.precision == "f16x3"
+        assert bool(torch.isfinite(out["emb"]).all()) and int(out["status"].sum()) == 0
+        got = {k: out[k].clone() for k in ("emb", "bw", "seed", "labels")}
+        model.set_precision("bf16x6")
+        ref = pipe.step(big)
+        assert all(torch.equal(got[k], ref[k]) for k in got) and hip.read_cluster_meta(ref["meta"], ref["status"]).K == meta.K
+        model.set_precision("f16x3")
+        # the reference-API flow: InferenceModel.forward re-runs the sequence itself
+        res = model(big, [list(range(8))])
+        assert all(bool(torch.isfinite(getattr(res["embeddings"][0], k)).all()) for k in ("embeddings", "bandwidths", "seediness"))
+        assert model._model.backbone.precision == "f16x3"
+        model.overflow_fallback = None
+        with pytest.raises(hip.NonFiniteError):
+            model(big, [list(range(8))])
+    finally:
+        config.load_preset("defaults")
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (3, 66, 98), (1, 34, 258), (5, 480, 864)])
 def test_stem_conv_vs_fp64(hip, shape):
     """The stem alone (stemseg_hip_stem_conv: 7x7 stride 2 pad 3 + folded-BN bias + ReLU on v_mfma_f32_32x32x2_f32) against an
@@ -1131,7 +1190,15 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         # bf16x3 (measured): maps within 8e-5, 1 fg pixel flips, same 20 instances -- but 8.6 % of the points change instance.  With
         # random-init weights the clusters of this fixture overlap, and a 1e-4 perturbation moves seeds / boundary points: the
         # opt-in mode is NOT label-exact on such inputs (on the structured YT-VIS / KITTI fixtures it is, see below)
-        assert (got_fg != ref_fg).sum() <= (20 if exact else 60) and agree >= (0.999 if exact else 0.85)
+        if exact:
+            # exact-or-in-band: a foreground pixel may differ from the reference only where the seediness sits within
+            # 1e-4 of the threshold (two fp32 pipelines' maps agree to ~3e-5 here), and every label on the common foreground is identical
+            flips = np.flatnonzero((got_fg != ref_fg).reshape(-1))
+            seed_map = e.seediness.cpu().numpy().reshape(-1)
+            assert flips.size <= 4 and (np.abs(seed_map[flips] - thr) <= 1e-4).all(), "fg pixels differ away from the threshold band: %s" % np.abs(seed_map[flips] - thr)
+            assert agree == 1.0, "labels differ on the common foreground"
+        else:
+            assert (got_fg != ref_fg).sum() <= 60 and agree >= 0.85
         assert meta[0]["instance_labels"] == g["instance_labels"].tolist()
     finally:
         config.load_preset("defaults")

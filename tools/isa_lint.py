@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Register-hazard lint for the split-staged convolution tiles: compiles one tile of csrc/conv_igemm.hip to gfx950
+"""ISA diagnostic for the split-staged convolution tiles -- NOT a correctness rule any more.  Round 3 blamed run-to-run differences under
+several HIP streams on packed / 64-bit VALU writes inside the MFMA streams (a presumed VALU-write-after-MFMA-read hazard) and this
+tool enforced "none of those".  Round 4 traced every one of those differences to the encoder's VALU stem kernel (tools/soak_probe.py;
+with the stem on the matrix cores the build WITH v_pk_mul_f16 inside the streams is bit-stable over 2 400 lane-rounds), so the rule
+is withdrawn; the tool stays as a way to see what the compiler puts between the MFMAs.  It compiles one tile of csrc/conv_igemm.hip to gfx950
 assembly and reports, for every write into a VGPR inside the kernel's MFMA streams, how many MFMAs were issued since the last MFMA that
 read that register as its A or B operand.  VALU writes are the dangerous class (they land within cycles of their issue); LDS returns
 and global loads land one memory latency later.  Usage: tools/isa_lint.py "<ConvCfg template arguments>" [more configs ...]
