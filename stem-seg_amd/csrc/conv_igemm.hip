@@ -1471,7 +1471,11 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.T * ceil_div(p.Cout, C::MT);
     const int64_t slab = (int64_t)p.Cout * p.T * p.H * p.W;
     int ksplit = 1;
-    while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= 640 && slab * ksplit * 2 <= scratch_floats) ksplit *= 2;
+    // split until the launch holds ~2.5 workgroups per CU for the tiles that share a CU, ~1.25 for the eight-wave split-staged tiles
+    // that own one (256 workgroups of those already fill the chip: splitting them only adds slab traffic -- measured, L3 conv2)
+    static const int wg_target_env = [] { const char* e = getenv("STEMSEG_SPLITK_WGS"); return e ? atoi(e) : 0; }();
+    const int64_t wg_target = wg_target_env > 0 ? wg_target_env : ((C::X6 && C::NWAVES >= 8) ? 320 : 640);
+    while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= wg_target && slab * ksplit * 2 <= scratch_floats) ksplit *= 2;
     // uneven rounds (STEMSEG_AUTOSPLIT=1, off by default until measured): a launch of a few hundred long-running 3x3(x3)
     // workgroups -- 424 on 256 CUs = two rounds for 1.66 rounds of work -- splits K by the k in {2, 3, 4} whose
     // ceil(workgroups * k / 256) / k rounds, plus the slab round trip at ~4 TB/s, beat the plain launch by > 7 %
