@@ -129,7 +129,9 @@ extern "C" int stemseg_hip_semseg_accumulate(float* acc, const float* clip_logit
 extern "C" int stemseg_hip_semseg_masks(const float* acc, const float* counts, int32_t F, int32_t C, int64_t HW, int32_t output_type,
                                         float* fg, void* multiclass, void* stream) {
     SS_CHECK_ARG(acc && counts && fg, "semseg_masks: null pointer");
-    SS_CHECK_ARG(F >= 0 && C >= 2 && HW >= 1, "semseg_masks: bad dims F=%d C=%d", F, C);
+    SS_CHECK_ARG(F >= 0 && C >= 1 && HW >= 1, "semseg_masks: bad dims F=%d C=%d", F, C);
+    // C == 1: the lone channel is the foreground logit of a multi-class head (what the clip-parallel path exchanges): sigmoid of its mean
+    SS_CHECK_ARG(C >= 2 || output_type == STEMSEG_SEMSEG_NONE, "semseg_masks: a single channel carries no class logits (output_type must be none)");
     SS_CHECK_ARG(output_type >= STEMSEG_SEMSEG_NONE && output_type <= STEMSEG_SEMSEG_ARGMAX, "semseg_masks: output_type %d", output_type);
     SS_CHECK_ARG(C == 2 || output_type == STEMSEG_SEMSEG_NONE || multiclass, "semseg_masks: multiclass output buffer missing");
     if (F == 0) return STEMSEG_OK;

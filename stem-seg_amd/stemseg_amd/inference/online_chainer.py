@@ -198,6 +198,24 @@ class HipChainerOps(object):
     def unpack_meta(self, raw):
         return hip.ClusterMeta.from_buffer_copy(bytes(raw))
 
+    def fg_from_semseg(self, per_clip, n_frames, resize_scale):
+        """Foreground mask of a whole sequence from the clips' semseg foreground logits (inference_model.py:121-128: every slot of
+        every clip, repeats included, adds its RESIZED logits to its frame and bumps the frame's count; :197-231: mean -> sigmoid of
+        the foreground logit (1 channel given) or softmax channel 1 (2 channels); inference/main.py:142-144: > 0.5).
+        per_clip: list of (frame numbers of the T slots, float32 [Cfg, T, h, w] on the device) in clip order -> uint8 [F, H, W]."""
+        from ..modeling.inference_model import InferenceModel
+        r = _int_scale(resize_scale)
+        acc, counts = None, [0] * n_frames
+        for frames, plane in per_clip:
+            x = plane.contiguous().float()
+            if r != 1:
+                x = hip.upsample_trilinear(x, 1, r, r)
+            if acc is None:
+                acc = torch.zeros((n_frames, x.shape[0]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+            InferenceModel._accumulate_semseg(acc, counts, x, list(frames))
+        prob, _ = hip.semseg_masks(acc, torch.as_tensor(counts, dtype=torch.float32).to(acc.device), None)
+        return hip.fg_mask(prob.contiguous(), 1.0, 0.5)
+
     def overflow_byte(self, block):
         """uint8 device scalar: 1 when the clip's head outputs (a tuple of tensors or one stacked block) hold inf / NaN; no sync."""
         ts = [t.contiguous() for t in (block if isinstance(block, (tuple, list)) else [block])]

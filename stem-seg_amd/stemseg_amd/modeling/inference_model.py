@@ -233,14 +233,22 @@ class InferenceModel(nn.Module):
         return emb, bw, seed
 
     @torch.no_grad()
-    def semseg_logits_clip(self, T, H, W, dev, slot=0):
-        """Class logits [C, T, h4*r, w4*r] of the clip whose features sit in the zero-haloed buffers of ``slot`` (inference_model.py:121-124)."""
+    def semseg_logits_clip(self, T, H, W, dev, slot=0, resize=True):
+        """Class logits [C, T, h4*r, w4*r] of the clip whose features sit in the zero-haloed buffers of ``slot`` (inference_model.py:121-124);
+        ``resize=False``: at the head's own resolution."""
         sh = self._model.semseg_head
         sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
         logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2)
-        if self.resize_scale != 1.0:
+        if self.resize_scale != 1.0 and resize:
             logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return logits.contiguous()
+
+    def semseg_fg_logits_clip(self, T, H, W, dev, slot=0):
+        """The channels of the clip's class logits that decide foreground (inference_model.py:207-225), at the head's resolution:
+        [1, T, h4, w4] (the last channel of a multi-class head) or [2, T, h4, w4] (a binary head) -- what the clip-parallel
+        sequence path exchanges instead of all class logits (pipeline.run_sequence_sharded)."""
+        logits = self.semseg_logits_clip(T, H, W, dev, slot=slot, resize=False)
+        return logits if logits.shape[0] == 2 else logits[-1:].contiguous()
 
     @staticmethod
     def _accumulate_semseg(acc, counts, logits, sub):
@@ -292,7 +300,7 @@ class InferenceModel(nn.Module):
         for i, sub in enumerate(subseq_idxes):
             for t in sub:
                 deps.setdefault(t, set()).add(i)
-        maps, overflow = [], []
+        maps, overflow, clip_fg_logits = [], [], []
         acc, counts = None, [0] * len(frames)
         for i, sub in enumerate(subseq_idxes):
             need = sorted(set(t for t in sub if t not in cache))
@@ -303,7 +311,9 @@ class InferenceModel(nn.Module):
             emb, bw, seed = self.embed_clip([cache[t] for t in sub], len(sub), H, W)
             overflow.append(hip.overflow_status([emb.contiguous(), bw.contiguous(), seed.contiguous()]))
             if self.has_semseg_head:                                                    # same zero-haloed inputs, third decoder
-                logits = self.semseg_logits_clip(len(sub), H, W, emb.device)
+                lo = self.semseg_logits_clip(len(sub), H, W, emb.device, resize=False)
+                logits = lo if self.resize_scale == 1.0 else hip.upsample_trilinear(lo, 1, int(self.resize_scale), int(self.resize_scale)).contiguous()
+                clip_fg_logits.append(lo if lo.shape[0] == 2 else lo[-1:].contiguous())  # (what the clip-parallel path exchanges)
                 overflow.append(hip.overflow_status([logits]))
                 if acc is None:
                     acc = torch.zeros((len(frames), logits.shape[0]) + tuple(logits.shape[2:]), dtype=torch.float32, device=logits.device)
@@ -334,4 +344,4 @@ class InferenceModel(nn.Module):
                 for n_, v in before.items():
                     getattr(m, n_).precision = v
         fg_masks, multiclass_masks = self.get_semseg_masks(acc, counts)
-        return {"fg_masks": fg_masks, "multiclass_masks": multiclass_masks, "embeddings": maps}
+        return {"fg_masks": fg_masks, "multiclass_masks": multiclass_masks, "embeddings": maps, "clip_fg_logits": clip_fg_logits}

@@ -114,12 +114,14 @@ class ClipPipeline(object):
         return GraphedStep(self, example_frames, False, n_clips, lane, embed_only=True)
 
     @torch.no_grad()
-    def embed_many(self, frames, clips, batch=4, lanes=2, use_graph=True, share_overlap=True):
+    def embed_many(self, frames, clips, batch=4, lanes=2, use_graph=True, share_overlap=True, with_fg_logits=False):
         """Embeds the clips ``clips`` (lists of frame indices into ``frames`` [F,3,H,W], all of one length) ``batch`` at a time
         through one encoder pass each, full batches as hipGraph replays alternating over ``lanes`` streams, the remainder
         eagerly.  When the clips are consecutive windows of the sequence (constant stride, as get_subsequence_frames cuts them)
         and ``share_overlap``, a pass covers the windows' UNION of frames: shared frames go through the encoder trunk once.
-        Returns per clip a [E+Ev+1, T, h4, w4] block (emb | bw | seed stacked) that the caller owns."""
+        Returns per clip a [E+Ev+1, T, h4, w4] block (emb | bw | seed stacked) that the caller owns; ``with_fg_logits`` (presets with
+        a semseg head): 1 or 2 more trailing channels, the foreground logits of the clip at the heads' resolution
+        (InferenceModel.semseg_fg_logits_clip) -- the foreground evidence ``run_sequence_sharded`` exchanges."""
         dev = frames.device
         out = [None] * len(clips)
         T = len(clips[0])
@@ -133,8 +135,8 @@ class ClipPipeline(object):
         if n_win < 2:
             n_win = 0
         if 0 < n_win < len(clips):
-            head = self.embed_many(frames, clips[:n_win], batch, lanes, use_graph, share_overlap)
-            tail = self.embed_many(frames, clips[n_win:], batch, lanes, use_graph, False)
+            head = self.embed_many(frames, clips[:n_win], batch, lanes, use_graph, share_overlap, with_fg_logits)
+            tail = self.embed_many(frames, clips[n_win:], batch, lanes, use_graph, False, with_fg_logits)
             return head + tail
         windows = n_win == len(clips) and n_win > 0
         groups = [list(range(i, min(i + batch, len(clips)))) for i in range(0, len(clips), batch)]
@@ -146,11 +148,16 @@ class ClipPipeline(object):
 
         def embed_pass(x, n):
             if windows and n > 1:
-                return self.model.embed_frames_windows(x, n, T, stride)
-            return self.model.embed_frames_batch(x, n) if n > 1 else [self.model.embed_frames(x)]
+                res = self.model.embed_frames_windows(x, n, T, stride)
+            else:
+                res = self.model.embed_frames_batch(x, n) if n > 1 else [self.model.embed_frames(x)]
+            if with_fg_logits:                               # third decoder on clip c's zero-haloed FPN buffers (slot c)
+                H_, W_ = x.shape[-2:]
+                res = [r_ + (self.model.semseg_fg_logits_clip(T, H_, W_, x.device, slot=c),) for c, r_ in enumerate(res)]
+            return res
         full = [g for g in groups if len(g) == batch] if use_graph and batch > 1 else []
         if full:
-            key = (batch, T, stride if windows else 0, tuple(frames.shape[1:]), lanes)
+            key = (batch, T, stride if windows else 0, tuple(frames.shape[1:]), lanes, bool(with_fg_logits))
             cache = self.__dict__.setdefault("_embed_graphs", {})
             if key not in cache:
                 ex = frames[torch.as_tensor(pass_frames(full[0]), device=dev)].contiguous()
@@ -162,8 +169,8 @@ class ClipPipeline(object):
             def collect(k):
                 if pending[k] is not None:
                     gs[k].wait()
-                    for c, (emb, bw, seed) in zip(pending[k][0], gs[k].out):
-                        out[c] = torch.cat([emb, bw, seed], 0)
+                    for c, parts in zip(pending[k][0], gs[k].out):
+                        out[c] = torch.cat(list(parts), 0)
                     pending[k] = None
             for n, g in enumerate(full):
                 k = n % len(gs)
@@ -178,8 +185,8 @@ class ClipPipeline(object):
             if g in full:
                 continue
             res = embed_pass(frames[torch.as_tensor(pass_frames(g), device=dev)].contiguous(), len(g))
-            for c, (emb, bw, seed) in zip(g, res):
-                out[c] = torch.cat([emb, bw, seed], 0)
+            for c, parts in zip(g, res):
+                out[c] = torch.cat(list(parts), 0)
         return out
 
     def capture(self, example_frames, overlap=False, n_clips=None, lane=0):
@@ -263,16 +270,23 @@ def clip_owner(ci, n_clips, world_size):
 
 @torch.no_grad()
 def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
-                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None, outputs_on_cpu=True, comm=None):
+                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None, outputs_on_cpu=True, comm=None,
+                         fg_logit_channels=0):
     """One long sequence over the ranks of ``group``, partitioned as SURVEY.md 8(e) lays out:
 
       1. every rank embeds ITS contiguous block of clips (``embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w],
          seed [1,T,h,w])`` per clip, or ``embed_many_fn(list of clips) -> list of stacked [E+Ev+1,T,h,w] blocks`` with
          ``channel_split = (E, Ev)``, e.g. ClipPipeline.embed_many: several overlapping windows per encoder pass);
-      2. all-gather #1: the SEEDINESS planes only (1 of the E+Ev+1 channels) -> the cross-clip mean-seediness foreground mask of
-         the whole sequence on every rank (inference/main.py:93-103), one launch;
+      2. all-gather #1: the FOREGROUND EVIDENCE only -- the seediness planes (1 of the E+Ev+1 channels) -> the cross-clip
+         mean-seediness foreground mask of the whole sequence on every rank (inference/main.py:93-103), one launch; or, for presets
+         with a semseg head (``fg_logit_channels`` = 1: the foreground logit of a multi-class head, 2: both logits of a binary
+         head; the clip functions then return a fourth tensor / extra trailing channels [Cfg, T, h, w], BEFORE any resize), those
+         planes -> every rank resizes them (x ``chainer.resize_scale``), accumulates them per frame in clip order, averages, and
+         thresholds the foreground probability at 0.5 (inference_model.py:121-128, 197-231, inference/main.py:142-144);
       3. every rank gathers + clusters its OWN clips with label_start = 1 (labels are i + label_start, clusterers.py:121, so the
-         global id is an offset applied later) and leaves one byte per voxel (0 background, 1..K instance, 255 outlier);
+         global id is an offset applied later) -- at FULL resolution when ``chainer.resize_scale`` > 1 (embeddings, bandwidths and
+         seediness resized first, online_chainer.py:127-140) -- and leaves one byte per voxel (0 background, 1..K instance, 255
+         outlier);
       4. all-gather #2: those byte planes + the 4.4 KB clustering record per clip;
       5. replicated and tiny: ONE launch builds the K1 x K2 label-pair tables of every (clip, overlap frame), one read-back, the
          Hungarian chain with ``next_track_label = highest id + 1`` runs on the host over the tables
@@ -289,7 +303,8 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     distributed = dist.world > 1
     rank, world = dist.rank, dist.world
     ops, clusterer = chainer.ops, chainer.clusterer
-    assert chainer.resize_scale == 1.0, "the sharded sequence path clusters at the heads' resolution (resize_scale 1.0)"
+    r_scale = float(chainer.resize_scale)
+    Cfg = int(fg_logit_channels)
     clips, _ = get_subsequence_frames(n_frames, cfg.INPUT.NUM_FRAMES, dataset_name, frame_overlap)
     n_clips = len(clips)
     mine = shard_clips(n_clips, rank, world)
@@ -299,31 +314,32 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     sels = [None if len(u) == len(c) else [max(j for j, v in enumerate(c) if v == t) for t in u] for u, c in zip(uniq, clips)]
 
     # ---- 1. embed this rank's clips ---------------------------------------------------------------------------------
-    blocks = []                                           # per own clip: (emb, bw, seed) with all T slots
+    blocks = []                                           # per own clip: (emb, bw, seed[, fg logits]) with all T slots
     if embed_many_fn is not None and mine:
         E, Ev = channel_split
-        blocks = [(b[:E], b[E:E + Ev], b[E + Ev:]) for b in embed_many_fn([clips[ci] for ci in mine])]
+        blocks = [(b[:E], b[E:E + Ev], b[E + Ev:E + Ev + 1]) + ((b[E + Ev + 1:E + Ev + 1 + Cfg],) if Cfg else ()) for b in embed_many_fn([clips[ci] for ci in mine])]
     elif mine:
-        blocks = [embed_clip_fn(clips[ci]) for ci in mine]
+        blocks = [tuple(embed_clip_fn(clips[ci])) for ci in mine]
+    assert all(len(b) == (4 if Cfg else 3) for b in blocks), "clip functions must return (emb, bw, seed%s)" % (", fg logits" if Cfg else "")
 
-    # ---- 2. all-gather #1: seediness planes ---------------------------------------------------------------------------
+    # ---- 2. all-gather #1: the foreground evidence (seediness planes, or the semseg head's foreground logits) -------------
     shape_info = None
     if blocks:
         seed0 = blocks[0][2]
-        dev, (h, w) = seed0.device, tuple(seed0.shape[-2:])
-        shape_info = [h, w, blocks[0][0].shape[0]]
+        dev, (hl, wl) = seed0.device, tuple(blocks[0][0].shape[-2:])
+        shape_info = [hl, wl, blocks[0][0].shape[0]]
     if distributed and world > 1 and n_clips < world:     # some ranks own no clip: they learn the map size from the others
         dev = _default_device() if not blocks else dev
         info = torch.tensor(shape_info if shape_info else [0, 0, 0], dtype=torch.int64, device=dev)
         infos = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(infos, info)
         shape_info = next(i for i in infos if int(i[0]) > 0).tolist()
-        h, w = int(shape_info[0]), int(shape_info[1])
+    hl, wl = int(shape_info[0]), int(shape_info[1])       # the heads' resolution
     E_dims = int(shape_info[2])
-    hw = h * w
-    seeds_local = torch.zeros((per_rank, T, h, w), dtype=torch.float32, device=dev)
+    Cg = Cfg if Cfg else 1
+    seeds_local = torch.zeros((per_rank, Cg, T, hl, wl), dtype=torch.float32, device=dev)
     for slot, blk in enumerate(blocks):
-        seeds_local[slot] = blk[2].reshape(T, h, w)
+        seeds_local[slot] = (blk[3] if Cfg else blk[2]).reshape(Cg, T, hl, wl)
     if distributed and world > 1:
         seeds_all = [torch.empty_like(seeds_local) for _ in range(world)]
         t_ag1 = _Timer(seeds_local)
@@ -334,16 +350,29 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
 
     def plane_of(ci):
         return clip_owner(ci, n_clips, world)
-    entries = []
-    for ci in range(n_clips):
-        owner, slot = plane_of(ci)
-        sd = seeds_all[owner][slot]
-        if sels[ci] is not None:
-            sd = sd[torch.as_tensor(sels[ci], device=sd.device)]
-        entries.append(EmbeddingMapEntry(uniq[ci], None, None, sd[None]))
-    fg_fn = fg_mask_fn if fg_mask_fn is not None else fg_masks_from_seediness
-    fg = ops.to_device(fg_fn(entries, seediness_thresh))              # [F, h, w] uint8
-    assert tuple(fg.shape[-2:]) == (h, w), "Size mismatch between embeddings {} and masks {}".format((h, w), tuple(fg.shape))
+    if Cfg:
+        # semseg foreground: every slot of every clip (repeats included) adds its resized logits to its frame, clip order
+        per_clip = []
+        for ci in range(n_clips):
+            owner, slot = plane_of(ci)
+            per_clip.append((list(clips[ci]), seeds_all[owner][slot]))
+        fg = ops.to_device(fg_mask_fn(per_clip, n_frames, r_scale) if fg_mask_fn is not None else ops.fg_from_semseg(per_clip, n_frames, r_scale))
+    else:
+        entries = []
+        for ci in range(n_clips):
+            owner, slot = plane_of(ci)
+            sd = seeds_all[owner][slot][0]
+            if sels[ci] is not None:
+                sd = sd[torch.as_tensor(sels[ci], device=sd.device)]
+            if r_scale != 1.0 and fg_mask_fn is None:      # (a seediness-derived mask is formed at the resolution the clusterer sees)
+                sd = ops.resize(sd[None], r_scale)[0]
+            entries.append(EmbeddingMapEntry(uniq[ci], None, None, sd[None]))
+        fg_fn = fg_mask_fn if fg_mask_fn is not None else fg_masks_from_seediness
+        fg = ops.to_device(fg_fn(entries, seediness_thresh))              # [F, h, w] uint8
+    h, w = int(fg.shape[-2]), int(fg.shape[-1])
+    assert (h, w) == (int(round(hl * r_scale)), int(round(wl * r_scale))), \
+        "Size mismatch between embeddings {} (x {}) and masks {}".format((hl, wl), r_scale, tuple(fg.shape))
+    hw = h * w
     vox_all, offs_all = ops.compact(fg)
 
     # ---- 3. cluster this rank's clips with label_start = 1; one byte per voxel ------------------------------------------
@@ -351,10 +380,12 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     P = T + meta_planes                                               # planes per clip in the exchange buffer
     codes_local = torch.zeros((per_rank, P * hw), dtype=torch.uint8, device=dev)
     for slot, ci in enumerate(mine):
-        emb, bw, seed = blocks[slot]
+        emb, bw, seed = blocks[slot][:3]
         if sels[ci] is not None:
             sel = torch.as_tensor(sels[ci], device=emb.device)
             emb, bw, seed = emb[:, sel], bw[:, sel], seed[:, sel]
+        if r_scale != 1.0:                                   # online_chainer.py:127-140: x r trilinear of all three
+            emb, bw, seed = ops.resize(emb, r_scale), ops.resize(bw, r_scale), ops.resize(seed, r_scale)
         fg_clip = fg[torch.as_tensor(uniq[ci], device=fg.device)]
         pts = ops.gather(emb, bw, seed, fg_clip)
         labels, meta_dev, _ = ops.cluster(clusterer, pts, 1, False)

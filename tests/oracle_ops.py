@@ -111,6 +111,23 @@ class OracleChainerOps(object):
         from stemseg_amd import hip
         return hip.ClusterMeta.from_buffer_copy(bytes(raw))
 
+    def fg_from_semseg(self, per_clip, n_frames, resize_scale):
+        """inference_model.py:121-128, 197-231 + inference/main.py:142-144 in torch CPU ops."""
+        F_ = torch.nn.functional
+        acc, counts = None, [0] * n_frames
+        for frames, plane in per_clip:
+            x = plane.float()
+            if float(resize_scale) != 1.0:
+                x = F_.interpolate(x[None], scale_factor=(1.0, resize_scale, resize_scale), mode="trilinear", align_corners=False)[0]
+            if acc is None:
+                acc = [torch.zeros((x.shape[0],) + tuple(x.shape[2:])) for _ in range(n_frames)]
+            for i, t in enumerate(frames):
+                acc[t] = acc[t] + x[:, i]
+                counts[t] += 1
+        logits = torch.stack([a / float(c) for a, c in zip(acc, counts)], 0)          # [F, Cfg, H, W]
+        prob = logits[:, 0].sigmoid() if logits.shape[1] == 1 else F_.softmax(logits, dim=1)[:, 1]
+        return (prob > 0.5).to(torch.uint8)
+
     def overflow_byte(self, block):
         ts = block if isinstance(block, (tuple, list)) else [block]
         return torch.tensor(0 if all(bool(torch.isfinite(t).all()) for t in ts) else 1, dtype=torch.uint8)

@@ -189,3 +189,86 @@ def test_sharded_sequence_refuses_a_non_finite_head_output_on_every_rank():
             return True
         return False
     assert all(run_virtual_ranks(3, one))
+
+
+def _semseg_case(r, binary):
+    """A sequence for the semseg / resize variant of the clip-parallel path: the seq20_ov4 golden's maps serve as the LOW-resolution
+    head outputs, every clip additionally carries foreground logits [Cfg, T, h, w] (different per clip on shared frames, so the
+    cross-clip mean matters), and everything is resized x r before masks and clustering (--resize_embeddings)."""
+    emb, bw, sd, fg, clips, overlap, _ = _case("seq20_ov4")
+    rs = np.random.RandomState(11)
+    fgl = {}
+    for ci, fr in enumerate(clips):
+        base = np.where(fg[fr] > 0, 2.0, -2.0).astype(np.float32) + rs.standard_normal(fg[fr].shape).astype(np.float32)
+        fgl[ci] = np.stack([-base, base], 0) if binary else base[None]
+    return emb, bw, sd, clips, overlap, fgl
+
+
+def _run_semseg(r, binary, comm=None):
+    from stemseg_amd import config, pipeline
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    from tests.oracle_ops import OracleChainerOps
+    emb, bw, sd, clips, overlap, fgl = _semseg_case(r, binary)
+    n_frames = emb.shape[1]
+    config.load_preset("davis")
+    ops = OracleChainerOps()
+    # single process: the reference's order -- resize each clip's logits, accumulate per frame, mean, sigmoid / softmax, > 0.5; chain with resize
+    fg_full = ops.fg_from_semseg([(list(fr), torch.from_numpy(fgl[ci])) for ci, fr in enumerate(clips)], n_frames, float(r))
+    dicts = [dict(frames=list(fr), embeddings=torch.from_numpy(emb[:, fr].copy()), bandwidths=torch.from_numpy(bw[:, fr].copy()),
+                  seediness=torch.from_numpy(sd[:, fr].copy())) for fr in clips]
+    want = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), float(r), ops=OracleChainerOps()).process(fg_full, dicts)
+    by = {tuple(fr): ci for ci, fr in enumerate(clips)}
+
+    def embed(frames):
+        ci = by[tuple(frames)]
+        return (torch.from_numpy(emb[:, frames].copy()), torch.from_numpy(bw[:, frames].copy()), torch.from_numpy(sd[:, frames].copy()),
+                torch.from_numpy(fgl[ci].copy()))
+    chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), float(r), ops=OracleChainerOps())
+    got = pipeline.run_sequence_sharded(n_frames, embed, chainer, "davis", frame_overlap=overlap, fg_logit_channels=2 if binary else 1,
+                                        **({"comm": comm} if comm is not None else {}))
+    (t0, c0, l0), m0, s0, _, meta0 = want
+    (t1, c1, l1), m1, s1, _, meta1 = got
+    ok = len(t0) == len(t1) and all(torch.equal(a, b) for a, b in zip(t0, t1)) and dict(c0) == dict(c1) and l0 == l1
+    ok = ok and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(m0, m1))
+    ok = ok and [m["instance_labels"] for m in meta0] == [m["instance_labels"] for m in meta1]
+    ok = ok and all(torch.equal(torch.cat(a), torch.cat(b)) for a, b in zip(s0, s1))
+    return bool(ok), int(fg_full.sum()), max(list(c0) + [0])
+
+
+@pytest.mark.parametrize("r,binary", [(2, False), (2, True), (1, False), (4, False)])
+def test_clip_parallel_chain_with_semseg_foreground_and_resize(r, binary):
+    """The clip-parallel path for presets with a semseg head and --resize_embeddings: foreground from the
+    exchanged foreground logits (1 channel of a multi-class head / both of a binary head), clustering at full resolution -- the
+    single-process chain's result bit for bit, at world 1 and on three virtual ranks."""
+    from tests.virtual_ranks import run_virtual_ranks
+    ok, n_fg, top = _run_semseg(r, binary)
+    assert ok and n_fg > 100 and top >= 3
+    assert all(x[0] for x in run_virtual_ranks(3, lambda comm: _run_semseg(r, binary, comm=comm)))
+
+
+def test_sharded_semseg_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 300) + 77
+    procs = [ctx.Process(target=_semseg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True], res
+
+
+def _semseg_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "stem-seg_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _run_semseg(2, False)[0]))
+    finally:
+        dist.destroy_process_group()

@@ -114,3 +114,64 @@ def test_virtual_ranks_on_one_gpu_identical_tracks(hip, world, tag):
     assert ok1 and all(r[0] for r in res)
     assert {r[1] for r in res} == {crc1}
     assert all(r[2] == centers1 for r in res)
+
+
+@pytest.mark.parametrize("flow", ["ytvis", "kitti"])
+def test_sharded_semseg_presets_match_the_single_process_chain(hip, flow):
+    """the clip-parallel sequence path for the presets whose foreground comes from the semseg head -- YouTube-VIS
+    (41+1 class logits, --resize_embeddings: everything x4, clustering at full resolution) and KITTI-MOTS (3+1 classes) -- on the
+    reduced-size flows of tests/golden/model_{ytvis,kitti}.npz.  Fed with the head outputs of ``InferenceModel.forward`` the
+    sharded driver must reproduce ``TrackGenerator.do_inference + do_clustering`` BIT FOR BIT at world 1 and on 2 / 3 virtual
+    ranks; fed by ``ClipPipeline.embed_many`` (its own encoder passes: another launch shape, last-bit differences in the maps)
+    the tracks must still agree on >= 99.9 % of the points."""
+    from stemseg_amd import config, pipeline
+    from stemseg_amd.inference.main import TrackGenerator
+    from stemseg_amd.modeling.inference_model import InferenceModel, preprocess_frames
+    from tests.virtual_ranks import run_virtual_ranks
+    yt = flow == "ytvis"
+    config.load_preset("ytvis" if yt else "kittimots")
+    config.cfg.INPUT.MIN_DIM, config.cfg.INPUT.MAX_DIM = (96, 128) if yt else (96, 320)
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    config.cfg.CLUSTERING.MIN_SEEDINESS_PROB = 0.8
+    try:
+        r = 4.0 if yt else 1.0
+        model = InferenceModel(resize_scale=r)
+        msd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 81 if yt else 91))).reshape(v.shape) for k, v in msd.items()}
+        new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 6.0
+        model._model.load_state_dict(new)
+        model = model.cuda()
+        frames = synth.synth_frames(12, 96, 128, seed=81) if yt else synth.synth_frames(14, 60, 190, seed=91)
+        name = "ytvis" if yt else "kittimots"
+        tg = TrackGenerator(model, name, resize_scale=r, frame_overlap=4)
+        n = len(frames)
+        out = model([f for f in frames], pipeline.get_subsequence_frames(n, 8, name, 4)[0])
+        fg1 = torch.stack([hip.fg_mask(p.contiguous(), 1.0, 0.5) for p in out["fg_masks"]], 0)
+        dicts = [{"frames": e.subseq_frames, "embeddings": e.embeddings, "bandwidths": e.bandwidths, "seediness": e.seediness} for e in out["embeddings"]]
+        (t0, c0, l0), m0, _, _, meta0 = tg.chainer.process(fg1, dicts)
+        assert int(fg1.sum()) > 1000 and len(c0) >= 2
+        by = {tuple(e.subseq_frames): (e.embeddings, e.bandwidths, e.seediness, fl) for e, fl in zip(out["embeddings"], out["clip_fg_logits"])}
+        Cfg = out["clip_fg_logits"][0].shape[0]
+
+        def run(comm=None):
+            (t1, c1, l1), m1, _, _, meta1 = pipeline.run_sequence_sharded(
+                n, lambda fr: by[tuple(sorted(set(fr)))], tg.chainer, name, frame_overlap=4, fg_logit_channels=Cfg,
+                **({"comm": comm} if comm is not None else {}))
+            ok = all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(t0, t1)) and dict(c0) == dict(c1) and l0 == l1
+            ok = ok and all(torch.equal(a[0].cpu(), b[0].cpu()) and torch.equal(a[1].cpu(), b[1].cpu()) for a, b in zip(m0, m1))
+            return ok and [m["instance_labels"] for m in meta0] == [m["instance_labels"] for m in meta1]
+        assert run()
+        for world in (2, 3):
+            assert all(run_virtual_ranks(world, lambda comm: run(comm)))
+        # the full device path: the rank's own encoder passes + third decoder (embed_many with the foreground logits)
+        pipe = pipeline.ClipPipeline(model)
+        x, _ = preprocess_frames(np.stack([np.asarray(f) for f in frames], 0), "cuda")
+        eh = model._model.embedding_head
+        (t2, c2, _), _, _, _, _ = pipeline.run_sequence_sharded(
+            n, None, tg.chainer, name, frame_overlap=4, fg_logit_channels=Cfg, channel_split=(eh.embedding_size, eh.variance_channels),
+            embed_many_fn=lambda my: pipe.embed_many(x, my, batch=2, lanes=1, use_graph=False, with_fg_logits=True))
+        same = [float((a.cpu() == b.cpu()).float().mean()) for a, b in zip(t0, t2) if a.numel() == b.numel() and a.numel()]
+        print("[sharded-semseg] %s: embed_many-fed tracks identical on %.5f of the points (%d of %d frames with equal fg)" % (flow, float(np.mean(same)), len(same), n))
+        assert len(same) >= n - 1 and np.mean(same) >= 0.999
+    finally:
+        config.load_preset("defaults")
