@@ -352,6 +352,26 @@ int stemseg_hip_cluster(const float* emb, const float* bw, const float* seed, in
                         uint8_t* opt_masks, float* opt_probs,
                         void* workspace, size_t ws_bytes, void* stream);
 
+/* The same for several independent point sets at once -- the clips of one step: every launch of the loop serves all of them
+ * (grid.y = set), so a step's clustering costs max_instances + 2 launches instead of that per clip.  Sets are independent
+ * (own workspace, own record); results are bit-identical to n_items separate stemseg_hip_cluster calls.  E, Ev and params are shared. */
+typedef struct StemsegClusterItem {
+    const float*   emb;              /* [n_max][E] */
+    const float*   bw;               /* [n_max][Ev] */
+    const float*   seed;             /* [n_max] */
+    int64_t        n_max;
+    const int64_t* n_points_dev;     /* optional device pointer to the actual N */
+    int64_t        label_start;
+    int64_t*       labels;           /* [n_max] */
+    StemsegClusterMeta* meta_dev;
+    uint8_t*       opt_masks;
+    float*         opt_probs;
+    void*          workspace;        /* >= stemseg_hip_cluster_workspace_bytes(n_max) */
+    size_t         ws_bytes;
+} StemsegClusterItem;
+int stemseg_hip_cluster_batch(const StemsegClusterItem* items, int32_t n_items, int32_t E, int32_t Ev,
+                              const StemsegClusterParams* params, void* stream);
+
 /* online_chainer.py:291-343: label-pair statistics on the overlap frames.  lut_a / lut_b map (label + 1)
  * to a row / column index or -1 (ignore; the outlier label -1 maps through slot 0).  Outputs (int64,
  * zeroed by the call): inter [Ka][Kb], cnt_a [Ka], cnt_b [Kb].  No limit on Ka, Kb or on the label values

@@ -57,6 +57,12 @@ struct ClusterKParams {
     int nblk;
 };
 
+// Several independent point sets (the clips of one step) through the same launches: blockIdx.y selects the set.  The parameter
+// blocks travel in the kernel arguments and are read in place (a reference into the kernarg segment: scalar loads, no private copy).
+constexpr int CL_MAX_BATCH = 8;
+struct ClusterBatch {
+    ClusterKParams p[CL_MAX_BATCH];
+};
 __device__ __forceinline__ long long cl_n(const ClusterKParams& p) {
     long long n = p.n_dev ? *p.n_dev : p.n_max;
     return n < p.n_max ? n : p.n_max;
@@ -126,7 +132,9 @@ __device__ __forceinline__ float cl_prob(float d) { return expf(__fmul_rn(-0.5f,
 // Latency is what a round costs (20 of them run back to back on ~2e5 points), so (a) a thread owns ONE point wherever the
 // grid allows (n_max <= 256 * CL_MAX_BLOCKS) and (b) its point's state, embedding and seediness are requested BEFORE the loop
 // header's chain of dependent reads (termination flag -> partials -> the seed's centre), which they do not depend on.
-__global__ __launch_bounds__(CL_THREADS) void cluster_round_kernel(const ClusterKParams p, const int round) {
+__global__ __launch_bounds__(CL_THREADS) void cluster_round_kernel(const ClusterBatch batch, const int round) {
+    const ClusterKParams& p = batch.p[blockIdx.y];
+    if ((int)blockIdx.x >= p.nblk) return;                  // (sets of a batch differ in size: the grid is cut for the largest)
     __shared__ float sh_s[CL_THREADS / 64];
     __shared__ int sh_i[CL_THREADS / 64];
     __shared__ int sh_c[CL_THREADS / 64];
@@ -246,7 +254,8 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_round_kernel(const Cluster
 }
 
 // secondary assignment (clusterers.py:148-159) + int64 labels + meta record
-__global__ __launch_bounds__(CL_THREADS) void cluster_final_kernel(const ClusterKParams p) {
+__global__ __launch_bounds__(CL_THREADS) void cluster_final_kernel(const ClusterBatch batch) {
+    const ClusterKParams& p = batch.p[blockIdx.y];
     __shared__ float sh_c[STEMSEG_MAX_INSTANCES][STEMSEG_MAX_EMB_DIMS];
     __shared__ float sh_b[STEMSEG_MAX_INSTANCES][STEMSEG_MAX_EMB_DIMS];
     const long long N = cl_n(p);
@@ -787,72 +796,103 @@ extern "C" size_t stemseg_hip_cluster_workspace_bytes(int64_t n_max) {
     return (size_t)round_up((int64_t)n_max * 4, 256) + 2 * CL_MAX_BLOCKS * sizeof(ClusterPartial) + 256;
 }
 
+static int cl_fill(ClusterKParams& p, const StemsegClusterItem& it, int32_t E, int32_t Ev, const StemsegClusterParams* params) {
+    SS_CHECK_ARG(it.n_max > 0 && it.n_max < (1ll << 31), "cluster: n_max out of range");
+    SS_CHECK_ARG(it.meta_dev && it.emb && (it.bw || Ev == 0) && it.seed && it.labels && it.workspace, "cluster: null pointer");
+    SS_CHECK_ARG(it.ws_bytes >= stemseg_hip_cluster_workspace_bytes(it.n_max), "cluster: workspace too small");
+    p.emb = it.emb; p.bw = it.bw; p.seed = it.seed; p.n_dev = reinterpret_cast<const long long*>(it.n_points_dev); p.n_max = it.n_max;
+    p.E = E; p.Ev = Ev; p.n_free = params->n_free_dims;
+    for (int e = 0; e < STEMSEG_MAX_EMB_DIMS; ++e) p.free_bw[e] = params->free_dim_bandwidths[e];
+    p.primary = params->primary_prob_thresh; p.secondary = params->secondary_prob_thresh; p.min_seed = params->min_seediness_prob;
+    p.max_instances = params->max_instances; p.label_start = it.label_start;
+    char* w = reinterpret_cast<char*>(it.workspace);
+    p.round_of = reinterpret_cast<int*>(w);
+    w += round_up((int64_t)it.n_max * 4, 256);
+    p.partials = reinterpret_cast<ClusterPartial*>(w);
+    w += 2 * CL_MAX_BLOCKS * sizeof(ClusterPartial);
+    p.state = reinterpret_cast<ClusterState*>(w);
+    p.meta = it.meta_dev; p.labels = reinterpret_cast<long long*>(it.labels); p.masks = it.opt_masks; p.probs = it.opt_probs;
+    p.nblk = grid_for(it.n_max, CL_THREADS, CL_MAX_BLOCKS);          // one point per thread up to 262 144 points
+    return STEMSEG_OK;
+}
+
+extern "C" int stemseg_hip_cluster_batch(const StemsegClusterItem* items, int32_t n_items, int32_t E, int32_t Ev, const StemsegClusterParams* params,
+                                         void* stream) {
+    SS_CHECK_ARG(params && (items || n_items == 0) && n_items >= 0, "cluster_batch: null params / items");
+    SS_CHECK_ARG(E >= 1 && E <= STEMSEG_MAX_EMB_DIMS && Ev >= 0 && Ev + params->n_free_dims == E,
+                 "cluster: E=%d must equal Ev=%d + n_free_dims=%d (<= %d)", E, Ev, params->n_free_dims, STEMSEG_MAX_EMB_DIMS);
+    SS_CHECK_ARG(params->max_instances >= 1 && params->max_instances <= STEMSEG_MAX_INSTANCES, "cluster: max_instances out of range");
+    static_assert(sizeof(StemsegClusterMeta) % 4 == 0 && sizeof(ClusterState) % 4 == 0, "word-zeroed in the round -1 launch");
+    hipStream_t s = as_stream(stream);
+    for (int i0 = 0; i0 < n_items; i0 += CL_MAX_BATCH) {
+        ClusterBatch b;
+        int n = 0, nblk = 1;
+        long long n_largest = 1;
+        double work = 0.0;
+        for (int i = i0; i < n_items && i < i0 + CL_MAX_BATCH; ++i) {
+            SS_CHECK_ARG(items[i].n_max >= 0 && items[i].meta_dev, "cluster: bad item %d", i);
+            if (items[i].n_max == 0) {       // clusterers.py:62-69: nothing to cluster, empty record
+                SS_HIP(hipMemsetAsync(items[i].meta_dev, 0, sizeof(StemsegClusterMeta), s));
+                continue;
+            }
+            const int rc = cl_fill(b.p[n], items[i], E, Ev, params);
+            if (rc) return rc;
+            nblk = std::max(nblk, b.p[n].nblk);
+            n_largest = std::max<long long>(n_largest, items[i].n_max);
+            // compulsory bytes: every point's inputs read once, its int64 label written once (36 B / point for E+Ev = 6)
+            work += (double)items[i].n_max * (4.0 * (E + Ev + 1) + 8.0);
+            ++n;
+        }
+        if (n == 0) continue;
+        for (int k = n; k < CL_MAX_BATCH; ++k) b.p[k] = b.p[0];      // (never selected: blockIdx.y < n)
+        void* ev = profile_begin(46, work, s);
+        // One set alone may take the one-launch form (STEMSEG_CLUSTER_PERSISTENT=1: persistent workgroups + grid barrier per round)
+        // when its points fit the resident threads' registers and no per-round mask / probability output is asked for; measured
+        // (tools/cluster_probe.py) against the multi-launch form below, which stays the default -- see DESIGN.md
+        static const int persistent = [] { const char* e = getenv("STEMSEG_CLUSTER_PERSISTENT"); return e ? atoi(e) : 0; }();
+        const long long cap4 = (long long)CP_BLOCKS * CP_THREADS * 4, cap12 = (long long)CP_BLOCKS * CP_THREADS * 12;
+        // the grid barrier needs all CP_BLOCKS workgroups resident together: refuse the form where the device cannot hold them even
+        // when it is otherwise idle (a smaller part, a register-hungrier build); co-running kernels of other streams can still delay
+        // residency -- the kernel then spins up to CP_SPIN_LIMIT and reports K = -1, which every read-back path turns into an error
+        static const bool fits = [] {
+            int dev = 0, cus = 0, b4 = 0, b12 = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, cluster_persistent_kernel<4>, CP_THREADS, 0) != hipSuccess) return false;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, cluster_persistent_kernel<12>, CP_THREADS, 0) != hipSuccess) return false;
+            return (long long)std::min(b4, b12) * cus >= CP_BLOCKS;
+        }();
+        if (persistent && fits && n == 1 && !b.p[0].masks && !b.p[0].probs && b.p[0].n_max <= cap12) {
+            const ClusterKParams& p = b.p[0];
+            ClusterSync* sy = reinterpret_cast<ClusterSync*>(p.partials);
+            hipLaunchKernelGGL(cluster_persistent_init_kernel, dim3(1), dim3(256), 0, s, sy, p.meta);
+            SS_LAUNCH_CHECK();
+            if (p.n_max <= cap4) hipLaunchKernelGGL(cluster_persistent_kernel<4>, dim3(CP_BLOCKS), dim3(CP_THREADS), 0, s, p, sy);
+            else hipLaunchKernelGGL(cluster_persistent_kernel<12>, dim3(CP_BLOCKS), dim3(CP_THREADS), 0, s, p, sy);
+            profile_end(ev, s);
+            SS_LAUNCH_CHECK();
+            continue;
+        }
+        for (int round = -1; round < params->max_instances; ++round) {
+            hipLaunchKernelGGL(cluster_round_kernel, dim3(nblk, n), dim3(CL_THREADS), 0, s, b, round);
+            SS_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(cluster_final_kernel, dim3(grid_for(n_largest, CL_THREADS, 2048), n), dim3(CL_THREADS), 0, s, b);
+        profile_end(ev, s);
+        SS_LAUNCH_CHECK();
+    }
+    return STEMSEG_OK;
+}
+
 extern "C" int stemseg_hip_cluster(const float* emb, const float* bw, const float* seed, int64_t n_max, const int64_t* n_points_dev,
                                    int32_t E, int32_t Ev, const StemsegClusterParams* params, int64_t label_start, int64_t* labels,
                                    StemsegClusterMeta* meta_dev, uint8_t* opt_masks, float* opt_probs, void* workspace, size_t ws_bytes,
                                    void* stream) {
     SS_CHECK_ARG(params && meta_dev, "cluster: null params/meta");
     SS_CHECK_ARG(n_max >= 0 && n_max < (1ll << 31), "cluster: n_max out of range");
-    SS_CHECK_ARG(E >= 1 && E <= STEMSEG_MAX_EMB_DIMS && Ev >= 0 && Ev + params->n_free_dims == E,
-                 "cluster: E=%d must equal Ev=%d + n_free_dims=%d (<= %d)", E, Ev, params->n_free_dims, STEMSEG_MAX_EMB_DIMS);
-    SS_CHECK_ARG(params->max_instances >= 1 && params->max_instances <= STEMSEG_MAX_INSTANCES, "cluster: max_instances out of range");
-    SS_CHECK_ARG(ws_bytes >= stemseg_hip_cluster_workspace_bytes(n_max), "cluster: workspace too small");
-    hipStream_t s = as_stream(stream);
-    if (n_max == 0) {                    // clusterers.py:62-69: nothing to cluster, empty record
-        SS_HIP(hipMemsetAsync(meta_dev, 0, sizeof(StemsegClusterMeta), s));
-        return STEMSEG_OK;
-    }
-    SS_CHECK_ARG(emb && (bw || Ev == 0) && seed && labels && workspace, "cluster: null pointer");
-    ClusterKParams p;
-    p.emb = emb; p.bw = bw; p.seed = seed; p.n_dev = reinterpret_cast<const long long*>(n_points_dev); p.n_max = n_max;
-    p.E = E; p.Ev = Ev; p.n_free = params->n_free_dims;
-    for (int e = 0; e < STEMSEG_MAX_EMB_DIMS; ++e) p.free_bw[e] = params->free_dim_bandwidths[e];
-    p.primary = params->primary_prob_thresh; p.secondary = params->secondary_prob_thresh; p.min_seed = params->min_seediness_prob;
-    p.max_instances = params->max_instances; p.label_start = label_start;
-    char* w = reinterpret_cast<char*>(workspace);
-    p.round_of = reinterpret_cast<int*>(w);
-    w += round_up((int64_t)n_max * 4, 256);
-    p.partials = reinterpret_cast<ClusterPartial*>(w);
-    w += 2 * CL_MAX_BLOCKS * sizeof(ClusterPartial);
-    p.state = reinterpret_cast<ClusterState*>(w);
-    p.meta = meta_dev; p.labels = reinterpret_cast<long long*>(labels); p.masks = opt_masks; p.probs = opt_probs;
-    p.nblk = grid_for(n_max, CL_THREADS, CL_MAX_BLOCKS);          // one point per thread up to 262 144 points
-    static_assert(sizeof(StemsegClusterMeta) % 4 == 0 && sizeof(ClusterState) % 4 == 0, "word-zeroed in the round -1 launch");
-    // compulsory bytes: every point's inputs read once, its int64 label written once (36 B / point for E+Ev = 6)
-    void* ev = profile_begin(46, (double)n_max * (4.0 * (E + Ev + 1) + 8.0), s);
-    // STEMSEG_CLUSTER_PERSISTENT=1: the one-launch form (persistent workgroups + grid barrier per round) when the points fit the
-    // resident threads' registers and no per-round mask / probability output is asked for; measured (tools/cluster_probe.py)
-    // against the multi-launch form below, which stays the default -- see DESIGN.md
-    static const int persistent = [] { const char* e = getenv("STEMSEG_CLUSTER_PERSISTENT"); return e ? atoi(e) : 0; }();
-    const long long cap4 = (long long)CP_BLOCKS * CP_THREADS * 4, cap12 = (long long)CP_BLOCKS * CP_THREADS * 12;
-    // the grid barrier needs all CP_BLOCKS workgroups resident together: refuse the form where the device cannot hold them even
-    // when it is otherwise idle (a smaller part, a register-hungrier build); co-running kernels of other streams can still delay
-    // residency -- the kernel then spins up to CP_SPIN_LIMIT and reports K = -1, which every read-back path turns into an error
-    static const bool fits = [] {
-        int dev = 0, cus = 0, b4 = 0, b12 = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, cluster_persistent_kernel<4>, CP_THREADS, 0) != hipSuccess) return false;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, cluster_persistent_kernel<12>, CP_THREADS, 0) != hipSuccess) return false;
-        return (long long)std::min(b4, b12) * cus >= CP_BLOCKS;
-    }();
-    if (persistent && fits && !opt_masks && !opt_probs && n_max <= cap12 && ws_bytes >= stemseg_hip_cluster_workspace_bytes(n_max)) {
-        ClusterSync* sy = reinterpret_cast<ClusterSync*>(p.partials);
-        hipLaunchKernelGGL(cluster_persistent_init_kernel, dim3(1), dim3(256), 0, s, sy, meta_dev);
-        SS_LAUNCH_CHECK();
-        if (n_max <= cap4) hipLaunchKernelGGL(cluster_persistent_kernel<4>, dim3(CP_BLOCKS), dim3(CP_THREADS), 0, s, p, sy);
-        else hipLaunchKernelGGL(cluster_persistent_kernel<12>, dim3(CP_BLOCKS), dim3(CP_THREADS), 0, s, p, sy);
-        profile_end(ev, s);
-        SS_LAUNCH_CHECK();
-        return STEMSEG_OK;
-    }
-    for (int round = -1; round < params->max_instances; ++round) {
-        hipLaunchKernelGGL(cluster_round_kernel, dim3(p.nblk), dim3(CL_THREADS), 0, s, p, round);
-        SS_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(cluster_final_kernel, dim3(grid_for(n_max, CL_THREADS, 2048)), dim3(CL_THREADS), 0, s, p);
-    profile_end(ev, s);
-    SS_LAUNCH_CHECK();
-    return STEMSEG_OK;
+    StemsegClusterItem it;
+    it.emb = emb; it.bw = bw; it.seed = seed; it.n_max = n_max; it.n_points_dev = n_points_dev; it.label_start = label_start; it.labels = labels;
+    it.meta_dev = meta_dev; it.opt_masks = opt_masks; it.opt_probs = opt_probs; it.workspace = workspace; it.ws_bytes = ws_bytes;
+    return stemseg_hip_cluster_batch(&it, 1, E, Ev, params, stream);
 }
 
 extern "C" int stemseg_hip_overlap_counts(const int64_t* labels_a, const int64_t* labels_b, int64_t n, const int32_t* lut_a,

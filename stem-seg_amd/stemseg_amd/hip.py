@@ -72,6 +72,12 @@ class ClusterMeta(C.Structure):
                 ("seed_prob", C.c_float * MAX_INSTANCES)]
 
 
+class ClusterItem(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("bw", C.c_void_p), ("seed", C.c_void_p), ("n_max", C.c_int64), ("n_points_dev", C.c_void_p),
+                ("label_start", C.c_int64), ("labels", C.c_void_p), ("meta_dev", C.c_void_p), ("opt_masks", C.c_void_p), ("opt_probs", C.c_void_p),
+                ("workspace", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
 # name -> (restype, argtypes); mirrors include/stemseg_hip.h one to one (tests check the export list)
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
@@ -112,6 +118,7 @@ SIGNATURES = {
     "stemseg_hip_fg_gather": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "stemseg_hip_cluster_workspace_bytes": (C.c_size_t, [_I64]),
     "stemseg_hip_cluster": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, C.POINTER(ClusterParams), _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "stemseg_hip_cluster_batch": (C.c_int, [C.POINTER(ClusterItem), _I32, _I32, _I32, C.POINTER(ClusterParams), _P]),
     "stemseg_hip_overlap_counts": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "stemseg_hip_label_presence": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _P]),
     "stemseg_hip_relabel": (C.c_int, [_P, _I64, _P, _I32, _P]),
@@ -460,6 +467,33 @@ def cluster(emb, bw, seed, params, label_start, n_points_dev=None, want_masks=Fa
                                     ptr(n_points_dev), E, Ev, C.byref(params), int(label_start), ptr(labels), ptr(meta),
                                     ptr(masks), ptr(probs), ptr(ws), ws_bytes, stream()))
     return labels, meta, masks, probs
+
+
+def cluster_batch(point_sets, params, label_start=1):
+    """Several independent point sets (the clips of one step) through ONE sequence of launches (grid.y = set): point_sets = list of
+    (emb [Nmax,E], bw [Nmax,Ev], seed [Nmax], n_points_dev | None).  Returns a list of (labels int64 [Nmax], meta device blob), bit
+    identical to separate ``cluster`` calls; no synchronisation."""
+    n = len(point_sets)
+    items = (ClusterItem * n)()
+    keep, outs = [], []
+    E, Ev = point_sets[0][0].shape[1], point_sets[0][1].shape[1]
+    for i, (emb, bw, seed, n_dev) in enumerate(point_sets):
+        assert emb.shape[1] == E and bw.shape[1] == Ev
+        n_max, dev = emb.shape[0], emb.device
+        labels = torch.empty(n_max, dtype=torch.int64, device=dev)
+        meta = torch.empty(C.sizeof(ClusterMeta), dtype=torch.uint8, device=dev)
+        ws_bytes = lib().stemseg_hip_cluster_workspace_bytes(n_max)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        seed = seed.reshape(-1)
+        it = items[i]
+        it.emb, it.bw, it.seed = ptr(emb, torch.float32), ptr(bw, torch.float32) if Ev else None, ptr(seed, torch.float32)
+        it.n_max, it.n_points_dev, it.label_start = n_max, ptr(n_dev), int(label_start)
+        it.labels, it.meta_dev, it.opt_masks, it.opt_probs = ptr(labels), ptr(meta), None, None
+        it.workspace, it.ws_bytes = ptr(ws), ws_bytes
+        keep.append(ws)
+        outs.append((labels, meta))
+    check(lib().stemseg_hip_cluster_batch(items, n, E, Ev, C.byref(params), stream()))
+    return outs
 
 
 _meta_pinned = {}

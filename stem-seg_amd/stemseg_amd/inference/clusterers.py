@@ -77,6 +77,14 @@ class SequentialClustering(ClustererBase):
         return hip.cluster(embeddings.contiguous(), bandwidths.contiguous(), seediness.reshape(-1).contiguous(), self._params(),
                            cluster_label_start, n_points_dev, return_label_masks, return_probs)
 
+    @torch.no_grad()
+    def enqueue_batch(self, point_sets, cluster_label_start=1):
+        """The clips of one step at once: point_sets = [(embeddings [Nmax,E], bandwidths [Nmax,Ev], seediness [Nmax], n_points_dev)];
+        one sequence of max_instances + 2 launches serves all of them (stemseg_hip_cluster_batch).  -> [(labels, meta_dev)]."""
+        hip.require_gpu()
+        return hip.cluster_batch([(e.contiguous(), b.contiguous(), s.reshape(-1).contiguous(), n) for e, b, s, n in point_sets],
+                                 self._params(), cluster_label_start)
+
     def meta_to_dict(self, meta, E, label_start, masks=None, probs=None, n=None):
         K = meta.K
         out = {"instance_labels": [label_start + i for i in range(K)],

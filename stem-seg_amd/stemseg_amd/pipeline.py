@@ -26,6 +26,7 @@ class ClipPipeline(object):
         self.tg = TrackGenerator(self.model, "davis", seediness_thresh=seediness_thresh)
         self.clusterer = self.tg.chainer.clusterer
         self.seediness_thresh = seediness_thresh
+        self.batch_clustering = True         # step_batch: the clips of a step share the clustering launches (False: one sequence per clip)
 
     @torch.no_grad()
     def embed(self, frames):
@@ -33,18 +34,25 @@ class ClipPipeline(object):
         return self.model.embed_frames(frames.contiguous())
 
     @torch.no_grad()
-    def cluster(self, emb, bw, seed, label_start=1, fg=None):
-        """Single-clip fg mask (seediness > thr unless ``fg`` is given), gather, clustering.  Returns device tensors only."""
-        T = seed.shape[1]
+    def gather(self, emb, bw, seed, fg=None):
+        """Single-clip fg mask (seediness > thr unless ``fg`` is given) + gather; device tensors only."""
         if fg is None:
             acc = torch.empty_like(seed[0])
             hip.seediness_accumulate(acc, seed[0].contiguous(), True)
             fg = hip.fg_mask(acc, 1.0, self.seediness_thresh)
         e, b, s, vox, offs = hip.fg_gather(emb.contiguous(), bw.contiguous(), seed.contiguous(), fg)
-        labels, meta_dev, _, _ = self.clusterer.enqueue(e, b, s, label_start, offs[T:])
-        return dict(labels=labels, meta=meta_dev, voxel_index=vox, frame_offsets=offs, fg=fg)
+        return dict(points=(e, b, s, offs[seed.shape[1]:]), voxel_index=vox, frame_offsets=offs, fg=fg)
 
-    def _finish_clip(self, emb, bw, seed, T, H, W, slot=0):
+    @torch.no_grad()
+    def cluster(self, emb, bw, seed, label_start=1, fg=None):
+        """Single-clip fg mask (seediness > thr unless ``fg`` is given), gather, clustering.  Returns device tensors only."""
+        g = self.gather(emb, bw, seed, fg)
+        e, b, s, n = g.pop("points")
+        labels, meta_dev, _, _ = self.clusterer.enqueue(e, b, s, label_start, n)
+        g.update(labels=labels, meta=meta_dev)
+        return g
+
+    def _finish_clip(self, emb, bw, seed, T, H, W, slot=0, defer_clustering=False):
         """Everything after the embedding decoder of one independent clip.  Presets with a semseg head (YouTube-VIS, KITTI-MOTS):
         third decoder -> class logits (x resize_scale, inference_model.py:121-124) -> foreground = its fg probability > 0.5
         (inference_model.py:197-231, inference/main.py:142-144); under --resize_embeddings the head outputs are up-sampled x4 and
@@ -62,7 +70,7 @@ class ClipPipeline(object):
         # overflow guard: a non-finite head output (an operand left the split convolution mode's range) is flagged on the device and
         # read with the clustering record -- such maps are never clustered silently (hip.read_cluster_meta raises NonFiniteError)
         status = hip.overflow_status([t.contiguous() for t in ([emb0, bw0, seed0] + ([logits] if logits is not None else []))])
-        out = self.cluster(emb, bw, seed, fg=fg)
+        out = self.gather(emb, bw, seed, fg=fg) if defer_clustering else self.cluster(emb, bw, seed, fg=fg)
         out.update(emb=emb, bw=bw, seed=seed, status=status)
         if logits is not None:
             out["semseg_logits"] = logits
@@ -102,8 +110,14 @@ class ClipPipeline(object):
         gather + clustering per clip.  Returns a list of ``step``-style dicts."""
         NT, _, H, W = frames.shape
         # (with a semseg head its decoder reads clip c's zero-haloed FPN buffers, slot c, which stay valid after the pass)
-        return [self._finish_clip(emb, bw, seed, NT // n_clips, H, W, slot=c)
+        outs = [self._finish_clip(emb, bw, seed, NT // n_clips, H, W, slot=c, defer_clustering=self.batch_clustering)
                 for c, (emb, bw, seed) in enumerate(self.model.embed_frames_batch(frames.contiguous(), n_clips))]
+        if self.batch_clustering:
+            # the clips are independent point sets: ONE sequence of clustering launches serves all of them (grid.y = clip)
+            res = self.clusterer.enqueue_batch([o.pop("points") for o in outs], 1)
+            for o, (labels, meta_dev) in zip(outs, res):
+                o.update(labels=labels, meta=meta_dev)
+        return outs
 
     @torch.no_grad()
     def capture_embed(self, example_frames, n_clips=None, lane=0):

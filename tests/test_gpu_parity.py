@@ -985,6 +985,40 @@ def test_overlap_counts_ids_beyond_500_and_large_tables(hip):
         ops.present_ids([dev(np.array([5, 900], np.int64))], cap=100)                                # a wrong bound is caught
 
 
+def test_cluster_batch_equals_separate_calls(hip, golden):
+    """stemseg_hip_cluster_batch: several independent point sets through ONE sequence of launches (grid.y = set) -- labels and
+    the whole clustering record bit-identical to separate stemseg_hip_cluster calls; sets of very different sizes (one of them
+    larger than a launch's one-point-per-thread capacity), an empty set, n_points on the device."""
+    rs = np.random.RandomState(17)
+    params = hip.make_cluster_params(0.5, 0.3, 0.6, 20, [0.3, 0.3])
+    sets = []
+    for n, k in ((3000, 5), (207360, 20), (1, 1), (70000, 9), (300000, 12), (0, 0), (17, 2), (40000, 25), (9000, 3)):
+        centers = rs.uniform(-1, 1, (max(k, 1), 4)).astype(np.float32)
+        which = rs.randint(0, max(k, 1), n)
+        emb = (centers[which] + 0.03 * rs.standard_normal((n, 4))).astype(np.float32)
+        bw = (20 + rs.uniform(0, 5, (n, 2))).astype(np.float32)
+        seed = rs.uniform(0, 1, n).astype(np.float32)
+        n_dev = dev(np.array([max(n - 3, 0)], np.int64)) if n > 100 else None
+        sets.append((dev(emb), dev(bw), dev(seed), n_dev))
+    sep = []
+    for e, b, s_, nd in sets:
+        if e.shape[0] == 0:
+            sep.append(None)
+            continue
+        labels, meta, _, _ = hip.cluster(e, b, s_, params, 7, nd)
+        sep.append((labels.clone(), meta.clone()))
+    got = hip.cluster_batch(sets, params, 7)
+    torch.cuda.synchronize()
+    assert len(got) == len(sets)
+    for i, ((labels, meta), ref) in enumerate(zip(got, sep)):
+        if ref is None:
+            assert hip.read_cluster_meta(meta).K == 0
+            continue
+        n = sets[i][0].shape[0] if sets[i][3] is None else int(sets[i][3].item())
+        assert torch.equal(labels[:n], ref[0][:n]) and torch.equal(meta, ref[1]), "set %d differs" % i
+        assert hip.read_cluster_meta(meta).K >= (1 if n > 1000 else 0)
+
+
 def test_nonfinite_flags_op(hip):
     x = torch.randn(7, 1000, device="cuda")
     assert int(hip.nonfinite_flags(x).sum()) == 0

@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -s -p no:cacheprovider -k "cluster or step_batch or graphed or embed_many or fullsize" 2>&1 | tail -3
+timeout 300 python -m pytest tests/test_gpu_soak.py tests/test_gpu_fullsize.py -q -x -p no:cacheprovider 2>&1 | tail -2
+b() { timeout 300 python bench.py --no-cpu-baseline --no-alt-precision --steps 40 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; cl=[k for k in r['hbm_kernels_eager']['kernels'] if 'cluster' in k['kernel']]; print(sys.argv[1:], d['value'], 'cluster us/clip', cl[0]['us_per_clip'] if cl else None, 'mismatch', d['config']['determinism']['mismatching'])" "$@"; }
+b; b
