@@ -796,7 +796,7 @@ extern "C" size_t stemseg_hip_cluster_workspace_bytes(int64_t n_max) {
     return (size_t)round_up((int64_t)n_max * 4, 256) + 2 * CL_MAX_BLOCKS * sizeof(ClusterPartial) + 256;
 }
 
-static int cl_fill(ClusterKParams& p, const StemsegClusterItem& it, int32_t E, int32_t Ev, const StemsegClusterParams* params) {
+static int cl_fill(ClusterKParams& p, const StemsegClusterItem& it, int32_t E, int32_t Ev, const StemsegClusterParams* params, int points_per_thread) {
     SS_CHECK_ARG(it.n_max > 0 && it.n_max < (1ll << 31), "cluster: n_max out of range");
     SS_CHECK_ARG(it.meta_dev && it.emb && (it.bw || Ev == 0) && it.seed && it.labels && it.workspace, "cluster: null pointer");
     SS_CHECK_ARG(it.ws_bytes >= stemseg_hip_cluster_workspace_bytes(it.n_max), "cluster: workspace too small");
@@ -812,7 +812,10 @@ static int cl_fill(ClusterKParams& p, const StemsegClusterItem& it, int32_t E, i
     w += 2 * CL_MAX_BLOCKS * sizeof(ClusterPartial);
     p.state = reinterpret_cast<ClusterState*>(w);
     p.meta = it.meta_dev; p.labels = reinterpret_cast<long long*>(it.labels); p.masks = it.opt_masks; p.probs = it.opt_probs;
-    p.nblk = grid_for(it.n_max, CL_THREADS, CL_MAX_BLOCKS);          // one point per thread up to 262 144 points
+    // one point per thread up to 262 144 points for a lone set (a round's cost is latency); two when several sets share the
+    // launches, so that all their workgroups are resident together (8 x 256 threads per CU).  The partials' reduction is a
+    // max with a lowest-index tie-break and integer counts: the result does not depend on how the points are cut into blocks.
+    p.nblk = grid_for(it.n_max, CL_THREADS * points_per_thread, CL_MAX_BLOCKS);
     return STEMSEG_OK;
 }
 
@@ -826,6 +829,10 @@ extern "C" int stemseg_hip_cluster_batch(const StemsegClusterItem* items, int32_
     hipStream_t s = as_stream(stream);
     for (int i0 = 0; i0 < n_items; i0 += CL_MAX_BATCH) {
         ClusterBatch b;
+        int n_live = 0;
+        for (int i = i0; i < n_items && i < i0 + CL_MAX_BATCH; ++i) n_live += items[i].n_max > 0 ? 1 : 0;
+        static const int ppt_env = [] { const char* e = getenv("STEMSEG_CLUSTER_PPT"); return e ? atoi(e) : 0; }();
+        const int ppt = ppt_env > 0 ? ppt_env : (n_live >= 3 ? 2 : 1);
         int n = 0, nblk = 1;
         long long n_largest = 1;
         double work = 0.0;
@@ -835,7 +842,7 @@ extern "C" int stemseg_hip_cluster_batch(const StemsegClusterItem* items, int32_
                 SS_HIP(hipMemsetAsync(items[i].meta_dev, 0, sizeof(StemsegClusterMeta), s));
                 continue;
             }
-            const int rc = cl_fill(b.p[n], items[i], E, Ev, params);
+            const int rc = cl_fill(b.p[n], items[i], E, Ev, params, ppt);
             if (rc) return rc;
             nblk = std::max(nblk, b.p[n].nblk);
             n_largest = std::max<long long>(n_largest, items[i].n_max);
