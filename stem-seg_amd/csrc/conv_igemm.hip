@@ -96,6 +96,8 @@ struct ConvKParams {
     int dec_H, dec_W;
     int vec_epi;                 // 16-B epilogue through an LDS transpose (dense, aligned outputs only)
     int t_fastest;               // tile order: t-planes of one (x, y) tile are neighbours in launch order (3-D taps)
+    int flat_t;                  // FLAT tiles of a 2-D conv: the run of flat positions crosses the frames ([T][H+2][pitch] is one run; p.T in the grid = 1)
+    int T_all;                   // flat_t: the frames of the volume (p.T is then 1)
     int n_co;                    // output-channel tiles (Cout / MT), the fastest-running part of the workgroup index
     // GroupNorm statistics of the output, taken in the epilogue (decoder stages): per (group, slot) partial sum / sum of squares
     // in fp64, one slot per tile (or per reduce block under split-K), combined in fixed order by gn_finalize_slots_kernel
@@ -153,7 +155,7 @@ struct ConvCfg {
     static constexpr int NT = NSEG * 32;                                // FLAT: voxels (flat plane positions) per tile
     static constexpr int FL = NT + 2 * PMAX + 8;                        // FLAT: staged run per (channel, dt): tile + one row and 4 either side
     static constexpr int IN_CH_STRIDE = FLAT ? KT * FL : KT * RH * XP;
-    static constexpr int IN_PAIR_STRIDE = KT * RH * XP;                 // X6: words of one channel pair of one plane
+    static constexpr int IN_PAIR_STRIDE = PMAX_ > 0 ? KT * (WN_ * NI_ * 32 + 2 * PMAX_ + 8) : KT * RH * XP;   // X6: words of one channel pair of one plane (flat: KT runs of FL)
     static constexpr int IN_PLANE_STRIDE = (CK / 2) * IN_PAIR_STRIDE;   // X6: words of one bf16 plane
     static constexpr int IN_FLOATS = X6 ? NPX * IN_PLANE_STRIDE : CK * IN_CH_STRIDE;
     // bf16x3 grouping: taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
@@ -179,8 +181,8 @@ struct ConvCfg {
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
     static_assert(CK % 4 == 0 || (DB && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (DB)");
     static_assert(LDS_FLOATS * 4 <= (X6 ? 160 : 80) * 1024, "two workgroups per CU (x6 eight-wave tiles: one)");
-    static_assert(!X6 || (!FLAT && !DB && !GL && G >= 2 && CK % 2 == 0), "x6: 2-D / 3-D tiles, two weight phases");
-    static_assert(!FLAT || (!BF && (!DB || GL) && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: fp32 3x3 taps only");
+    static_assert(!X6 || (!DB && !GL && G >= 2 && CK % 2 == 0), "x6: 2-D / 3-D tiles, two weight phases");
+    static_assert(!FLAT || ((!BF || X6) && (!DB || GL) && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: 3x3 taps, fp32 or split-staged");
     static_assert(!GL || (DB && !BF), "direct-to-LDS staging is the double-buffered fp32 form");
     // workgroups per CU the register allocator must leave room for: the GL forms carry no staging registers, so the tiles whose
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
-        b_ptr6[ni] = reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+        b_ptr6[ni] = C::FLAT ? reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + s * 32 + l31 + 3   // (the staged run starts at F0 - pitch - 4)
+                             : reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
     }
     const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
@@ -408,10 +411,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             l = *reinterpret_cast<const unsigned short*>(&bl);
         }
     };
-    constexpr int NQ6 = (C::CK / 2) * C::KT * C::RH * XQ;               // 16-B pieces of a channel PAIR's rows: [pair][dt][row][xq]
+    constexpr int FQ6 = C::FL / 4;                                       // flat: 16-B pieces of one (pair, dt) run
+    constexpr int NQ6 = C::FLAT ? (C::CK / 2) * C::KT * FQ6 : (C::CK / 2) * C::KT * C::RH * XQ;   // 16-B pieces of a channel PAIR's rows: [pair][dt][row][xq] (flat: [pair][dt][run])
     constexpr int IN_PT6 = C::X6 ? (NQ6 + C::NTHREADS - 1) / C::NTHREADS : 1;
     constexpr int NWQ_A = C::NPL * C::GA * 2 * C::MT, NWQ6 = C::NPL * C::G * 2 * C::MT;   // 16-B pieces of weight phase A / of the slab
-    auto in6_rel = [&](int q, int& c) -> int64_t {                   // piece q -> float offset of its first channel (c0 = 0) from in_tile
+    auto in6_rel = [&](int q, int& c) -> int64_t {                   // piece q -> float offset of its first channel (c0 = 0) from in_tile (< 0: not needed / outside)
+        if constexpr (C::FLAT) {                                      // [pair][dt][FL]: flat run of the plane from F0 - pitch - 4
+            const int j4 = q % FQ6, rr = q / FQ6, dt = rr % C::KT;
+            c = 2 * (rr / C::KT);
+            const int f = F0 - pitch - 4 + 4 * j4;
+            if (f < 0 || 4 * j4 >= C::NT + 2 * pitch + 8) return -1;  // before the volume (feeds halo-column outputs only) / beyond what this pitch needs
+            return (int64_t)c * p.in_cs + (int64_t)dt * p.in_ts + f;
+        }
         const int xq = q % XQ;
         int rr = q / XQ;
         const int r = rr % C::RH;
@@ -423,8 +434,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     };
     auto fetch_in6 = [&](int c0, int q, float4& v0, float4& v1) {    // piece q of both channels of its pair
         int c;
-        const int64_t rel = in6_rel(q, c) + (int64_t)c0 * p.in_cs;
+        const int64_t rel0 = in6_rel(q, c);
+        const int64_t rel = rel0 + (int64_t)c0 * p.in_cs;
         v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rel0 < 0) return;
         if (c0 + c < p.Cin && tile_base + rel + 4 <= p.in_limit) v0 = *reinterpret_cast<const float4*>(in_tile + rel);
         if (c0 + c + 1 < p.Cin && tile_base + rel + p.in_cs + 4 <= p.in_limit) v1 = *reinterpret_cast<const float4*>(in_tile + rel + p.in_cs);
     };
@@ -438,11 +451,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         for (int k = 0; k < IN_PT6; ++k) {
             const int q = tid + k * C::NTHREADS;
             int c = 0;
-            const int64_t rel = q < NQ6 ? in6_rel(q, c) : 0;
+            const int64_t rel0 = q < NQ6 ? in6_rel(q, c) : 0;
+            const int64_t rel = rel0 < 0 ? 0 : rel0;
             in6_voff[k] = (unsigned int)(rel * 4);
             const int64_t slack = in6_room - rel * 4;                   // c0 * cs * 4 <= slack
             const int64_t by_room = slack < 0 ? 0 : slack / (p.in_cs * 4) + 1;
-            in6_clim[k] = q < NQ6 ? (int)min((int64_t)(p.Cin - c), by_room) : 0;
+            in6_clim[k] = (q < NQ6 && rel0 >= 0) ? (int)min((int64_t)(p.Cin - c), by_room) : 0;
         }
     }
     // branch-free (the loads are issued between the MFMAs of the running chunk): a lane whose piece lies outside the volume reads
@@ -482,7 +496,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 fetch_in6(c0, q, v0, v1);
                 store_in6(q, v0, v1, wbuf);
             }
-        } else {
+        } else if constexpr (!C::FLAT) {                              // (flat tiles are only launched on 16-B aligned volumes)
             constexpr int NE6 = (C::CK / 2) * C::KT * C::RH * C::XP;     // one word (pair, position) per iteration
             for (int q = tid; q < NE6; q += C::NTHREADS) {
                 const int xx = q % C::XP;
@@ -529,6 +543,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         typedef typename std::conditional<C::F16, _Float16, __bf16>::type h16;
         typedef h16 h16x8 __attribute__((ext_vector_type(8)));
         const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
+        const unsigned int* bdy6[C::NI][3];                   // FLAT: row dy of the taps = + dy * pitch (runtime), everything else immediates
+        if constexpr (C::FLAT) {
+#pragma unroll
+            for (int ni = 0; ni < C::NI; ++ni) { bdy6[ni][0] = b_ptr6[ni]; bdy6[ni][1] = b_ptr6[ni] + pitch; bdy6[ni][2] = b_ptr6[ni] + 2 * pitch; }
+        }
         auto ld_b = [&](const int grp, h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
             const int cg = grp / C::NTG, tg = grp % C::NTG;
 #pragma unroll
@@ -543,8 +562,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                         int tap = tg * C::TPG + tapi;
                         tap = tap < C::TAPS ? tap : C::TAPS - 1;       // padded taps: any valid address (their weights are zero)
                         const int dt = tap / (C::KH * C::KW), dy = (tap / C::KW) % C::KH, dx = tap % C::KW;
-                        const int off = pl * C::IN_PLANE_STRIDE + (cg * C::CPH + chl / 2) * C::IN_PAIR_STRIDE + (dt * C::RH + dy) * C::XP + dx;
-                        wv[wd] = b_ptr6[ni][off];
+                        if constexpr (C::FLAT) {
+                            const int off = pl * C::IN_PLANE_STRIDE + (cg * C::CPH + chl / 2) * C::IN_PAIR_STRIDE + dt * C::FL + dx;
+                            wv[wd] = bdy6[ni][dy][off];
+                        } else {
+                            const int off = pl * C::IN_PLANE_STRIDE + (cg * C::CPH + chl / 2) * C::IN_PAIR_STRIDE + (dt * C::RH + dy) * C::XP + dx;
+                            wv[wd] = b_ptr6[ni][off];
+                        }
                     }
                     b[pl][ni] = __builtin_bit_cast(h16x8, w4);
                 }
@@ -991,7 +1015,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         for (int ni = 0; ni < C::NI; ++ni) {
             const int sN = wn * C::NI + ni;
             int y = y0 + sN / C::COLS, x = x0 + (sN % C::COLS) * 32 + l31;
-            if constexpr (C::FLAT) {
+            if constexpr (C::FLAT) {                           // (statistics are only fused into per-plane flat launches: flat_t == 0)
                 const int f = F0 + sN * 32 + l31, y1 = f / pitch, x1 = f - y1 * pitch;
                 y = y1 - 1;
                 x = (x1 >= 1) ? x1 - 1 : p.W;
@@ -1112,9 +1136,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         const int s = wn * C::NI + ni;
         int y = y0 + s / C::COLS;
         int x = x0 + (s % C::COLS) * 32 + l31;
+        int te = t;                                            // frame of this position (flat_t: decoded from the flat index)
         if constexpr (C::FLAT) {                               // flat position -> (row, column) of the haloed plane -> output (y, x)
-            const int f = F0 + s * 32 + l31, y1 = f / pitch, x1 = f - y1 * pitch;
-            y = y1 - 1;
+            int f = F0 + s * 32 + l31;
+            if (p.flat_t) {                                    // the run crosses the frames: [T][H + 2][pitch]
+                te = f / (int)p.in_ts;
+                f -= te * (int)p.in_ts;
+            }
+            const int y1 = f / pitch, x1 = f - y1 * pitch;
+            y = (y1 >= 1 && te < p.T_all) ? y1 - 1 : p.H;      // halo rows (and frames past the end): nothing to store
             x = (x1 >= 1) ? x1 - 1 : p.W;                      // halo columns: nothing to store
         }
         if (y < p.H && x < p.W) {
@@ -1125,8 +1155,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 off = (int64_t)t2 * p.out_ts + (int64_t)y2 * p.out_ys + x2;
                 roff = (int64_t)t2 * p.res_ts + (int64_t)y2 * p.res_ys + x2;
             } else {
-                off = (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
-                roff = (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x;
+                off = (int64_t)te * p.out_ts + (int64_t)y * p.out_ys + x;
+                roff = (int64_t)te * p.res_ts + (int64_t)y * p.res_ys + x;
             }
             float* o = p.out + (int64_t)blockIdx.z * p.out_split_stride + off;
 #pragma unroll
@@ -1450,6 +1480,10 @@ struct SplitTiles {
     using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, BFV>; // 128 co x 128 voxels
     using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, BFV>;  //  64 co x 256 voxels
     using Y1Wide = ConvCfg<1, 1, 1, 32, 4, 2, 2, 4, 8, false, BFV>; // 256 co x 256 voxels, 512 threads: an input element is split once per 256 output channels
+    // flat (ragged-width) forms of the big tiles: 128 co x 512 flat positions of the zero-haloed plane (3-D: per t-plane) or of the whole
+    // [T][H + 2][pitch] run (2-D: across the frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
+    template <int PMAX> using Y3Flat = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
+    template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
 };
 
 // sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
@@ -1464,12 +1498,17 @@ template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0) {
     p.tiles_x = C::FLAT ? (int)ceil_div((int64_t)p.H * p.in_ys, C::NT) : (int)ceil_div(p.W, C::COLS * 32);
     p.tiles_y = C::FLAT ? 1 : (int)ceil_div(p.H, C::ROWS);
+    p.T_all = p.T;
+    if (C::FLAT && p.flat_t) {                           // one run of flat positions over all frames: [T][H + 2][pitch]
+        p.tiles_x = (int)ceil_div((int64_t)p.T * p.in_ts, C::NT);
+        p.T = 1;
+    } else p.flat_t = 0;
     const int out_vec = p.vec_epi;                       // true output rows are 16-B aligned (decides the reduce kernel's form)
     if (C::FLAT) p.vec_epi = 0;
     // split-K over the input-channel chunks when the layer alone cannot give every CU two workgroups
     const int nchunks = (int)ceil_div(p.Cin, C::CK);
     const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.T * ceil_div(p.Cout, C::MT);
-    const int64_t slab = (int64_t)p.Cout * p.T * p.H * p.W;
+    const int64_t slab = (int64_t)p.Cout * p.T_all * p.H * p.W;
     int ksplit = 1;
     // split until the launch holds ~2.5 workgroups per CU for the tiles that share a CU, ~1.25 for the eight-wave split-staged tiles
     // that own one (256 workgroups of those already fill the chip: splitting them only adds slab traffic -- measured, L3 conv2)
@@ -1499,12 +1538,12 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     if (ksplit > 1) {
         rp.partial = scratch; rp.bias = p.bias; rp.res = p.res; rp.out = p.out;
         rp.out_cs = p.out_cs; rp.out_ts = p.out_ts; rp.out_ys = p.out_ys; rp.res_cs = p.res_cs; rp.res_ts = p.res_ts; rp.res_ys = p.res_ys;
-        rp.slab = slab; rp.C = p.Cout; rp.V = (int64_t)p.T * p.H * p.W; rp.ksplit = ksplit; rp.relu = p.relu;
+        rp.slab = slab; rp.C = p.Cout; rp.V = (int64_t)p.T_all * p.H * p.W; rp.ksplit = ksplit; rp.relu = p.relu;
         rp.H = p.dec_W > 0 ? p.dec_H : p.H; rp.W = p.dec_W > 0 ? p.dec_W : p.W;
         rp.gn_part = nullptr; rp.gn_cpg = rp.gn_cap = rp.gn_slot0 = 0;
         // partial slabs are dense in the launch's own tile coordinates; the whole epilogue moves to the reduce kernel
         p.out = scratch; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.dec_H = p.dec_W = 0;
-        p.out_cs = (int64_t)p.T * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
+        p.out_cs = (int64_t)p.T_all * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
         p.out_split_stride = slab;
         p.vec_epi = !C::FLAT && (p.W % 4 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0);
     } else p.out_split_stride = 0;
@@ -1521,7 +1560,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         *p.gn_used_host = slot0 + (int)slots;
     }
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), 1, (unsigned)ksplit);
-    const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T * p.H * p.W;
+    const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T_all * p.H * p.W;
     constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
     const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : (tile_rows == 16 ? 9 : tile_rows));   // 9/8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
@@ -1687,6 +1726,35 @@ static int launch_split_family(ConvKParams& p, hipStream_t s, float* scratch, in
         if (k2 && (x6_off & 2) && p.Cout > 64) cfg = 2;
         if (k1 && (x6_off & 4) && p.Cout > 64) cfg = 2;
     }
+    // flat tiles (f16x3 only: the default mode; STEMSEG_X6_FLAT=0 switches them off, tile_cfg 5 forces them where the contract holds):
+    // maps whose width wastes a 32-column tile, or whose height a 16-row one, lose that share of their MFMAs to positions that are
+    // never stored (216 x 120: 10 %, 54 x 30: 21 %); a flat tile computes the halo columns instead (4 of 220, 2 of 56)
+    // measured (4-clip steps, three lanes): 2-D flat tiles 98.5 -> 100.3 clips/s (layer-3 3x3: 256 -> 224 workgroups, 207 -> 191 us); 3-D flat
+    // tiles nothing (block_4x 448 -> 416 workgroups is two rounds of the chip either way and the flat epilogue stores 4 B per lane): default 2
+    static const int flat_mode = [] { const char* e = getenv("STEMSEG_X6_FLAT"); return e ? atoi(e) : 2; }();      // 0 off, 1 both classes, 2 only 2-D, 3 only 3-D
+    const bool flat_off = flat_mode == 0 || (flat_mode == 2 && k3) || (flat_mode == 3 && k2);
+    const bool flat_ok = BFV == 3 && !flat_off && p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0;
+    if constexpr (BFV == 3) {
+    if ((flat_ok || (tile_cfg == 5 && flat_mode != 0 && BFV == 3 && p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0)) && k3 && (tile_cfg == 5 || ((tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384))) {
+        const double e2d = (double)p.H * p.W / ((double)Y3Big::ROWS * ceil_div(p.H, Y3Big::ROWS) * 32.0 * ceil_div(p.W, 32));
+        const double efl = (double)p.H * p.W / (512.0 * ceil_div((int64_t)p.H * p.in_ys, 512));
+        if (tile_cfg == 5 || efl > 1.04 * e2d) {
+            if (p.in_ys <= 112) return launch_cfg<typename F::template Y3Flat<112>>(p, s, scratch, scratch_floats);
+            return launch_cfg<typename F::template Y3Flat<224>>(p, s, scratch, scratch_floats);
+        }
+    }
+    if (flat_ok && k2 && !p.gn_part && p.in_ts == (int64_t)p.in_H * p.in_ys && p.in_H == p.H + 2 &&
+        (tile_cfg == 5 || ((tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 384)))) {
+        const double e2d = (double)p.H * p.W / ((double)Y2Big::ROWS * ceil_div(p.H, Y2Big::ROWS) * 32.0 * ceil_div(p.W, 32));
+        const double efl = (double)p.T * p.H * p.W / (512.0 * ceil_div((int64_t)p.T * p.in_ts, 512));
+        if (tile_cfg == 5 || efl > 1.04 * e2d) {
+            p.flat_t = 1;
+            if (p.in_ys <= 56) return launch_cfg<typename F::template Y2Flat<56>>(p, s, scratch, scratch_floats);
+            if (p.in_ys <= 112) return launch_cfg<typename F::template Y2Flat<112>>(p, s, scratch, scratch_floats);
+            return launch_cfg<typename F::template Y2Flat<224>>(p, s, scratch, scratch_floats);
+        }
+    }
+    }
     if (k3) {
         if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
         // big launches: the row planner (whole rows + split-K rows, see plan_rows) with one eight-wave workgroup per CU
@@ -1763,6 +1831,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.tiles_x = p.tiles_y = 0;
     static const bool t_fast = [] { const char* e = getenv("STEMSEG_T_FASTEST"); return !(e && e[0] == '0'); }();
     p.t_fastest = t_fast ? 1 : 0;
+    p.flat_t = 0; p.T_all = p.T;
     const bool aligned = (reinterpret_cast<uintptr_t>(in.ptr) % 16 == 0) && (in.c_stride % 4 == 0) &&
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
     p.vec4 = aligned ? 1 : 0;

@@ -310,3 +310,57 @@ def test_f16x3_overflow_survives_the_fused_relu(hip, form):
     o = out.cpu().numpy()
     assert not np.isfinite(o[:, 100]).any(), "the overflow was flushed to a finite value by the %s epilogue" % form
     assert np.isfinite(np.delete(o, 100, axis=1)).all()
+
+
+@pytest.mark.parametrize("case", [("k2", 256, 256, 8, 30, 54, "plain"), ("k2", 128, 128, 3, 60, 108, "relu+res"), ("k2", 256, 128, 2, 120, 216, "splitk"),
+                                  ("k2", 64, 128, 5, 17, 23, "plain"), ("k3", 256, 128, 3, 120, 216, "plain"), ("k3", 64, 128, 4, 30, 54, "gn"),
+                                  ("k3", 128, 256, 2, 61, 107, "splitk")])
+def test_flat_split_tiles_vs_fp64(hip, case):
+    """Flat (ragged-width) forms of the big split-staged tiles (tile_cfg 5; f16x3 only): 512 flat positions of the zero-haloed plane
+    per workgroup -- for 2-D convolutions the run crosses the frames ([T][H + 2][pitch]) -- so that maps whose width / height waste a
+    32-column x 16-row tile (54 x 30: 21 %) compute the halo columns instead.  Same operands, same products: fp32-level error vs fp64,
+    bit-identical run to run, identical summation to the 2-D tile wherever no split-K is involved."""
+    if SP != "f16x3":
+        pytest.skip("flat tiles exist for the default mode")
+    kind, Cin, Cout, T, H, W, form = case
+    kt = 3 if kind == "k3" else 1
+    x, w, b = _rand((Cin, T, H, W), 5), _rand((Cout, Cin, kt, 3, 3), 6, 1.0 / np.sqrt(Cin * 9 * kt)), _rand((Cout,), 7)
+    ref = _ref64(x, w, b, kt)
+    buf, vin = _haloed(hip, x, kt)
+    pw = hip.pack_conv_weight_any(dev(w), SP)
+    outs = {}
+    for cfg in (5, 1):
+        out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        epi = dict(precision=SP)
+        r = None
+        if form == "relu+res":
+            r = _rand((Cout, T, H, W), 8)
+            rd = dev(r)
+            epi.update(relu=1, residual=rd, res_strides=(T * H * W, H * W, W))
+        scratch = torch.full((8 * Cout * T * H * W,), float("nan"), device="cuda") if form == "splitk" else None
+        if form == "gn":
+            stats = hip.conv3d_gn(vin, pw, dev(b), hip.dense_volume(out), 3, 32, 1e-5, cfg, None, SP)
+            o64 = None
+        else:
+            hip.conv3d(vin, pw, dev(b), hip.dense_volume(out), (kt, 3, 3), cfg, scratch, epi)
+        torch.cuda.synchronize()
+        outs[cfg] = out.cpu().numpy().astype(np.float64)
+        if form == "gn":
+            o = outs[cfg].reshape(32, -1)
+            st = stats.cpu().numpy().reshape(32, 2)
+            assert np.abs(st[:, 0] - o.mean(1)).max() <= 2e-6 * max(1.0, np.abs(o.mean(1)).max())
+            assert np.abs(st[:, 1] - 1.0 / np.sqrt(o.var(1) + 1e-5)).max() <= 1e-4 * (1.0 / np.sqrt(o.var(1) + 1e-5)).max()
+        if cfg == 5:                                         # run-to-run identical
+            out2 = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+            if form == "gn":
+                hip.conv3d_gn(vin, pw, dev(b), hip.dense_volume(out2), 3, 32, 1e-5, cfg, None, SP)
+            else:
+                hip.conv3d(vin, pw, dev(b), hip.dense_volume(out2), (kt, 3, 3), cfg, scratch, epi)
+            torch.cuda.synchronize()
+            assert torch.equal(out, out2)
+    want = ref if form != "relu+res" else np.maximum(ref + r, 0.0)
+    e_flat, e_2d = np.abs(outs[5] - want).max(), np.abs(outs[1] - want).max()
+    print("[f16x3] flat %s: max|err| vs fp64 flat %.3e, 2-D tile %.3e (max|ref| %.3g)" % (case, e_flat, e_2d, np.abs(want).max()))
+    assert np.isfinite(outs[5]).all() and e_flat <= max(3.0 * e_2d, 4e-7 * np.abs(want).max())
+    if form in ("plain", "relu+res", "gn"):
+        assert np.array_equal(outs[5], outs[1]), "same chunk order, same products: the flat tile must reproduce the 2-D tile bit for bit"
