@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 5
+#define STEMSEG_HIP_ABI_VERSION 6
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -227,6 +227,12 @@ typedef struct StemsegDecoderWeights {
     const float* grid_t;         /* [T], [H4], [W4] linspace vectors (may be NULL if no act uses the grid) */
     const float* grid_y;
     const float* grid_x;
+    /* Optional (NULL = absent): branch i's first convolution (block_32x.0, block_16x.0, block_8x.0, block_4x.0) has already run --
+       first_conv_out[i] = its output WITH bias, dense [inter[i]][T][h_i][w_i]; first_conv_stats[i] = the GroupNorm statistics of that
+       output, [gn_groups][2] = (mean, rstd).  Produced by stemseg_hip_shared_convs_forward for decoders that read the same FPN maps:
+       pass the decoder's channel / group slice of the shared outputs.  conv_w / conv_b of that stage are then not read. */
+    const float* first_conv_out[4];
+    const float* first_conv_stats[4];
 } StemsegDecoderWeights;
 
 size_t stemseg_hip_decoder_workspace_bytes(const StemsegDecoderDesc* desc);
@@ -239,6 +245,33 @@ int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDec
 
 /* make `stream` wait for a detached decoder_forward issued with the same concurrency set */
 int stemseg_hip_decoder_join(int32_t concurrency, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * First-layer convolutions shared between decoders.  block_32x.0 / block_16x.0 / block_8x.0 / block_4x.0 of the embedding,
+ * seediness and semseg decoders all read the same four FPN maps (embedding_decoder.py:111-127, seediness_decoder.py:92-108,
+ * semseg_decoder.py:96-112): one 3x3x3 convolution per branch with the decoders' output channels CONCATENATED (weights
+ * torch.cat(dim=0) of the decoders' weights, packed as one convolution; GroupNorm groups concatenated likewise, which needs the same
+ * channels-per-group in every decoder sharing the branch) stages every input tile once and launches (sum of Cout) / 128 x the
+ * workgroups.  Every output channel is the same dot product, in the same order, as in the decoder's own convolution whenever both
+ * pick the same tile and K-split; results otherwise agree to fp32 rounding of the split-K partial sums.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct StemsegSharedConvsDesc {
+    int32_t struct_bytes;        /* = sizeof(StemsegSharedConvsDesc), checked */
+    int32_t in_channels;         /* FPN channels (256) */
+    int32_t T, H4, W4;           /* as StemsegDecoderDesc */
+    int32_t precision;           /* STEMSEG_PRECISION_* ; conv_w packed for it */
+    int32_t cout[4];             /* concatenated output channels of branch 32x, 16x, 8x, 4x; 0 = branch not shared (skipped) */
+    int32_t gn_groups[4];        /* concatenated GroupNorm group count of the branch (1..64) */
+    float   gn_eps;
+} StemsegSharedConvsDesc;
+
+size_t stemseg_hip_shared_convs_workspace_bytes(const StemsegSharedConvsDesc* desc);
+/* feats_haloed[i]: the zero-haloed FPN map of branch i (decoder input_layout 2).  On return conv_out[i] / stats_out[i] point INTO the
+ * workspace: dense [cout[i]][T][h_i][w_i] and [gn_groups[i]][2]; decoder k's slice starts at channel / group offset = the sum of the
+ * decoders before it.  The workspace needs no initialisation and must stay untouched until the decoders that consume it have run. */
+int stemseg_hip_shared_convs_forward(const StemsegSharedConvsDesc* desc, const float* const conv_w[4], const float* const conv_b[4],
+                                     const float* const feats_haloed[4], void* workspace, size_t ws_bytes, float* conv_out[4],
+                                     float* stats_out[4], void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 2-D encoder: ResNet-50/101 + FPN over the T frames of a clip (backbone/resnet.py:105-113, fpn.py:47-69,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Volume(C.Structure):
@@ -34,7 +34,13 @@ class DecoderDesc(C.Structure):
 class DecoderWeights(C.Structure):
     _fields_ = [("conv_w", C.c_void_p * 7), ("conv_b", C.c_void_p * 7), ("gn_w", C.c_void_p * 7), ("gn_b", C.c_void_p * 7),
                 ("fuse_w", C.c_void_p * 3), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
-                ("grid_t", C.c_void_p), ("grid_y", C.c_void_p), ("grid_x", C.c_void_p)]
+                ("grid_t", C.c_void_p), ("grid_y", C.c_void_p), ("grid_x", C.c_void_p),
+                ("first_conv_out", C.c_void_p * 4), ("first_conv_stats", C.c_void_p * 4)]
+
+
+class SharedConvsDesc(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("in_channels", C.c_int32), ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32),
+                ("precision", C.c_int32), ("cout", C.c_int32 * 4), ("gn_groups", C.c_int32 * 4), ("gn_eps", C.c_float)]
 
 
 MAX_ENCODER_BLOCKS = 40
@@ -112,6 +118,9 @@ SIGNATURES = {
     "stemseg_hip_decoder_init_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_forward": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(_P), _P, _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_join": (C.c_int, [_I32, _P]),
+    "stemseg_hip_shared_convs_workspace_bytes": (C.c_size_t, [C.POINTER(SharedConvsDesc)]),
+    "stemseg_hip_shared_convs_forward": (C.c_int, [C.POINTER(SharedConvsDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t,
+                                                   C.POINTER(_P), C.POINTER(_P), _P]),
     "stemseg_hip_seediness_accumulate": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "stemseg_hip_fg_mask": (C.c_int, [_P, _F, _F, _P, _I64, _P]),
     "stemseg_hip_fg_mask_frames": (C.c_int, [_P, _P, _F, _P, _I32, _I64, _P]),

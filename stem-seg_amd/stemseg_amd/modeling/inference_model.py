@@ -12,6 +12,7 @@ result, with three deliberate differences:
     again in the chainer).
 """
 import math
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -23,6 +24,7 @@ from .. import config as _config
 from ..config import cfg
 from .embedding_utils import get_nb_free_dims  # noqa: F401  (re-export, as in the reference's import surface)
 from .model_builder import build_model
+from .decoder_base import SharedFirstConvs
 
 EmbeddingMapEntry = namedtuple("EmbeddingMapEntry", ["subseq_frames", "embeddings", "bandwidths", "seediness"])
 
@@ -77,6 +79,11 @@ class InferenceModel(nn.Module):
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
         self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
+        # the decoders' first-layer convolutions read the same FPN maps: one launch per branch with the channels concatenated
+        # (SharedFirstConvs).  Off by default: measured 99.7 vs 100.8 clips/s on the DAVIS pair -- the merged 4x-branch launch is 896
+        # one-per-CU workgroups = 3.5 -> 4 rounds of the 256 CUs, exactly the 2 x (1.75 -> 2) rounds of the separate launches.
+        self.share_first_convs = os.environ.get("STEMSEG_SHARE_FIRST_CONVS", "0") == "1"
+        self._shared, self._semseg_first = {}, {}
         self.lane = 0
         self.eval()
 
@@ -159,6 +166,15 @@ class InferenceModel(nn.Module):
         m.backbone.run_backbone_into(frames, [vols[s] for s in (4, 8, 16, 32)])
         return self._run_heads(pads, T, H, W, dev)
 
+    def _shared_first(self, feats, decoders, slot):
+        """-> the ``first`` argument of each decoder's forward_single (None when sharing is off or no branch qualifies)."""
+        if not self.share_first_convs:
+            return [None] * len(decoders)
+        key = tuple(id(d) for d in decoders)
+        if key not in self._shared:
+            self._shared[key] = SharedFirstConvs(decoders)
+        return self._shared[key].run(feats, lane=(self.lane, slot))
+
     @torch.no_grad()
     def embed_frames_batch(self, frames, n_clips):
         """``n_clips`` clips in one encoder pass: frames float32 [n_clips * T, 3, H, W] -> list of (emb, bw, seed) per clip.
@@ -175,7 +191,7 @@ class InferenceModel(nn.Module):
             v = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads[c], (32, 16, 8, 4))}
             vols += [v[s] for s in (4, 8, 16, 32)]
         m.backbone.run_backbone_into(frames, vols)
-        return [self._run_heads(pads[c], T, H, W, dev) for c in range(n_clips)]
+        return [self._run_heads(pads[c], T, H, W, dev, slot=c) for c in range(n_clips)]
 
     @torch.no_grad()
     def embed_frames_windows(self, frames, n_clips, clip_frames, clip_stride):
@@ -195,19 +211,25 @@ class InferenceModel(nn.Module):
             v = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads[c], (32, 16, 8, 4))}
             vols += [v[s] for s in (4, 8, 16, 32)]
         m.backbone.run_backbone_into(frames, vols, window=(clip_frames, clip_stride))
-        return [self._run_heads(pads[c], T, H, W, dev) for c in range(n_clips)]
+        return [self._run_heads(pads[c], T, H, W, dev, slot=c) for c in range(n_clips)]
 
     @torch.no_grad()
-    def _run_heads(self, pads, T, H, W, dev):
+    def _run_heads(self, pads, T, H, W, dev, slot=0):
         m = self._model
         feats = ([b for b, _ in pads], (T, H // 4, W // 4))
         eh = m.embedding_head
         eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
         seed = None
         eh.concurrency = 1 if self.overlap_decoders else 0
+        # block_{32,16,8,4}x.0 of the decoders that will run on these maps, as one convolution per branch
+        twin = m.seediness_head if eh.seediness_channels == 0 else m.semseg_head
+        first_e, first_t = self._shared_first(feats, [eh, twin], slot) if twin is not None else (None, None)
+        self._semseg_first.pop((T, H, W, slot, self.lane), None)
+        if twin is m.semseg_head and first_t is not None:
+            self._semseg_first[(T, H, W, slot, self.lane)] = first_t                   # consumed by semseg_logits_clip of the same clip
         if eh.seediness_channels == 0 and not self.overlap_decoders:
             m.seediness_head.concurrency, m.seediness_head.detached = 0, False
-            seed = m.seediness_head.forward_single(feats, 2)
+            seed = m.seediness_head.forward_single(feats, 2, first_t)
             if self.resize_scale != 1.0:
                 seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
             main = None
@@ -218,9 +240,9 @@ class InferenceModel(nn.Module):
             assert m.seediness_head is not None
             sh = m.seediness_head
             sh.concurrency, sh.detached = 2, True
-            seed = sh.forward_single(feats, 2)
+            seed = sh.forward_single(feats, 2, first_t)
             main = sh
-        out = eh.forward_single(feats, 2)
+        out = eh.forward_single(feats, 2, first_e)
         E, Ev = eh.embedding_size, eh.variance_channels
         emb, bw = out[:E], out[E:E + Ev]
         if seed is None:
@@ -238,7 +260,8 @@ class InferenceModel(nn.Module):
         ``resize=False``: at the head's own resolution."""
         sh = self._model.semseg_head
         sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
-        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2)
+        first = self._semseg_first.pop((T, H, W, slot, self.lane), None)               # its first-layer convolutions ran beside the embedding decoder's
+        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2, first)
         if self.resize_scale != 1.0 and resize:
             logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return logits.contiguous()
