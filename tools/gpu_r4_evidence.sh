@@ -23,5 +23,7 @@ rm -f gpurun_out/prof_graph/*.db gpucore.*
 PREC=f16x3 ROUND=${R}_f16x3 bash tools/gpu_round.sh pmc 2>&1 | grep -v rocprofv3 | tail -6
 PREC=bf16x6 ROUND=${R}_bf16x6 bash tools/gpu_round.sh pmc 2>&1 | grep -v rocprofv3 | tail -4
 bash tools/pmc_step.sh > gpurun_out/${R}_pmc_whole_step_hbm.txt 2>&1; tail -12 gpurun_out/${R}_pmc_whole_step_hbm.txt
+if [[ -z "${SKIP_PROBES:-}" ]]; then
 STEMSEG_STEM=valu timeout 600 python tools/stem_corun_probe.py --reps 100 --victims stem --aggressors none,k3_f16x3,k3_bf16x6,k2_f16x3,k1_f16x3_expand > gpurun_out/${R}_stem_corun_probe.txt 2>&1; grep victim gpurun_out/${R}_stem_corun_probe.txt | cut -c1-200
 timeout 300 tools/microbench/bin/valu_corun_probe 100 > gpurun_out/${R}_valu_corun_probe.txt 2>&1; grep -c "0 of 100 launches wrong" gpurun_out/${R}_valu_corun_probe.txt
+fi
