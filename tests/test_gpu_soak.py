@@ -5,7 +5,7 @@ whichever lane produced it and whatever else was in flight (a 1
 History: rounds 3 / 4 saw ~1 % (on some boxes 20-60 %) of the multi-lane steps differ from the lone
 replay.  tools/soak_probe.py localised every one of them to the encoder's VALU stem kernel -- 5-13 wrong words in one 16-word run
 of its output, one accumulator register, lanes 48..63 of a wave -- never to an MFMA convolution; with the stem on the matrix cores
-the differences are gone (0 of 4 200 lane-rounds).  This test is the guard: ``STEMSEG_STEM=valu`` makes it fail on such a box."""
+the differences are gone (0 of 6 900 lane-rounds).  This test is the guard: ``STEMSEG_STEM=valu`` makes it fail on such a box."""
 import numpy as np
 import pytest
 import torch
