@@ -49,20 +49,21 @@
                                   // forms are bit-stable in the three-lane soak, and numerically identical to each other.
 #endif
 #ifndef SS_X6_WMODE_SMALLG
-#define SS_X6_WMODE_SMALLG -1      // -1: mode 2 wherever its second register set fits (mode 1 measured 2-5 % faster on the f16x3 1x1 tiles when
-                                  // that kernel still made an operand in registers; not re-measured since, see SS_X6_SPREAD)
+#define SS_X6_WMODE_SMALLG -1      // weight staging of the split-staged tiles with <= 2 k-groups per chunk (1x1 taps), see ConvCfg::WMODE.  -1: f16x3 takes
+                                  // mode 1 (one phase, the whole next chunk in registers under the chunk's MFMA stream), bf16x6 mode 2 where its second
+                                  // register set fits (mode 1 costs bf16x6 1.2 %, measured); 0 / 1 / 2 force a mode for both (A/B builds)
 #endif
 #ifndef SS_X6_SPREAD
-#define SS_X6_SPREAD 0             // 1: the next chunk's global loads go out a few per (k-group, mi) step instead of at the top of the phase.
-                                  // Measured 1-3 % faster on every class, but OFF: the loads' address arithmetic is VALU inside the MFMA
-                                  // stream, the register allocator hands it fragment registers the MFMAs issued just before still read,
-                                  // and nothing orders a VALU write behind an issued MFMA's operand read -- with several pipelines in flight
-                                  // results stopped being bit-identical run to run (DESIGN.md sections 5c / 10).  Rule: no VALU in the k-loop.
+#define SS_X6_SPREAD 1             // 1: (f16x3) the next chunk's global loads go out a few per (k-group, mi) step instead of at the top of the phase;
+                                  // 2: for bf16x6 as well (no gain there); 0: off.  Round 3 measured this 1-3 % faster per class and kept it off: the loads'
+                                  // address arithmetic is VALU inside the MFMA stream, which that round blamed for the run-to-run differences under
+                                  // several streams.  Round 4 traced those to the VALU stem kernel; with this and WMODE 1 on,
+                                  // the three-lane soak stays at 0 differing lane-rounds and the step is 1.0 % faster (A/B on one box, interleaved).
 #endif
 #ifndef SS_X6_INDB
 #define SS_X6_INDB 0               // 1: two input tiles in LDS, the next chunk's split + ds_writes between the MFMAs of the running one.  Measured
-                                  // 0 ... -4 % (the store section between the barriers is not what the kernel waits for) -- and it is VALU
-                                  // inside the MFMA stream (see SS_X6_SPREAD): off, kept for the record
+                                  // 0 ... -4 % in round 3 and -0.5 % in round 4 (the store section between the barriers is not what the kernel waits
+                                  // for): off, kept for the record
 #endif
 
 namespace stemseg {
@@ -168,7 +169,7 @@ struct ConvCfg {
     static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
     // X6 weight staging of tiles with few k-groups per chunk (1x1 taps; a phase's MFMA stream is shorter than a global load):
     // 0 two phases, registers refilled per phase; 1 one phase, whole slab in registers; 2 two phases, one chunk of lookahead
-    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : (((BF_ == 3 && SS_F16_WPLANES == 2) || WM * WN >= 8 || MI * NI < 8) ? 2 : 0)) : 0;
+    static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : (BF_ == 3 ? 1 : ((WM * WN >= 8 || MI * NI < 8) ? 2 : 0))) : 0;
     // (bf16x6, 128 co x 256 voxels on four waves: the second register set of mode 2 spills)
     static constexpr bool SP = WMODE == 1, LA = WMODE == 2;
     // split-staged tiles keep TWO input tiles where LDS allows (160 KB for a lone eight-wave workgroup, 80 KB for two four-wave ones):
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         constexpr int NSA = C::GA * C::MI, NSB = (C::G - C::GA) * C::MI, NSALL = C::G * C::MI;
         constexpr int NPA = (NWQ_A + C::NTHREADS - 1) / C::NTHREADS, NPB = (NWQ6 - NWQ_A + C::NTHREADS - 1) / C::NTHREADS;
         constexpr int NPALL = (NWQ6 + C::NTHREADS - 1) / C::NTHREADS;
-        constexpr bool SPRD = SS_X6_SPREAD && (C::WMODE != 0 || C::F16 || SS_X6_SPREAD > 1);     // (bf16x6 many-k-group tiles: no registers to spare inside the stream)
+        constexpr bool SPRD = SS_X6_SPREAD && (C::F16 || SS_X6_SPREAD > 1);     // (bf16x6: no gain on the 1x1 tiles, no registers to spare on the many-k-group ones)
         typedef std::integral_constant<int, C::GA> GAc;
         typedef std::integral_constant<int, C::G> Gc;
         typedef std::integral_constant<int, 0> I0;
