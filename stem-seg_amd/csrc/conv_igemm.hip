@@ -60,6 +60,10 @@
                                   // several streams.  Round 4 traced those to the VALU stem kernel; with this and WMODE 1 on,
                                   // the three-lane soak stays at 0 differing lane-rounds and the step is 1.0 % faster (A/B on one box, interleaved).
 #endif
+#ifndef SS_X6_SPREAD_DIV
+#define SS_X6_SPREAD_DIV 2          // the spread loads go out over the first 1 / DIV of a phase's (k-group, mi) steps (A/B, step throughput vs DIV 2:
+                                  // 1: +0.4 %, 3: -0.5 %, 4: -1.0 %)
+#endif
 #ifndef SS_X6_INDB
 #define SS_X6_INDB 0               // 1: two input tiles in LDS, the next chunk's split + ds_writes between the MFMAs of the running one.  Measured
                                   // 0 ... -4 % in round 3 and -0.5 % in round 4 (the store section between the barriers is not what the kernel waits
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 const int cn = c0 + C::CK;
                 compute6(Q0{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more) {
-                        side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + 1) / 2 : 1>{}, INc{}, std::integral_constant<int, NPALL>{}, f_in_at(cn),
+                        side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, INc{}, std::integral_constant<int, NPALL>{}, f_in_at(cn),
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
                         in_stores(st, NSALL, cn);
                     }
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 __syncthreads();
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + 1) / 2 : 1>{}, I0{}, std::integral_constant<int, NPA>{}, [](const int) {},
+                    if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPA>{}, [](const int) {},
                                           [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cnn, Q0{}, QA{}, rw6, k); });
                     if constexpr (more) in_stores(st, NSB, cn);
                 });
@@ -869,14 +873,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 constexpr bool more = decltype(more_c)::value;
                 const int cn = c0 + C::CK;
                 compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
-                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + 1) / 2 : 1>{}, INc{}, std::integral_constant<int, NPA>{}, f_in_at(cn),
+                    if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, INc{}, std::integral_constant<int, NPA>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QA{}, rw6, k); });
                 });
                 __syncthreads();                                   // phase A's slots are idle
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more) {
-                        side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + 1) / 2 : 1>{}, I0{}, std::integral_constant<int, NPB>{}, [](const int) {},
+                        side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPB>{}, [](const int) {},
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
                         in_stores(st, NSB, cn);
                     }
