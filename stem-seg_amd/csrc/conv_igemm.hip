@@ -1752,7 +1752,9 @@ static int launch_split_family(ConvKParams& p, hipStream_t s, float* scratch, in
         (tile_cfg == 5 || ((tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 384)))) {
         const double e2d = (double)p.H * p.W / ((double)Y2Big::ROWS * ceil_div(p.H, Y2Big::ROWS) * 32.0 * ceil_div(p.W, 32));
         const double efl = (double)p.T * p.H * p.W / (512.0 * ceil_div((int64_t)p.T * p.in_ts, 512));
-        if (tile_cfg == 5 || efl > 1.04 * e2d) {
+        // (measured, tools/conv_sweep.py T = 32: a flat workgroup is 6 % slower than a 2-D one at pitch 56 -- by-element epilogue -- and 15-25 %
+        // slower at pitch 112 / 224, where the staged run is 1.15x / 1.49x the 2-D tile's piece: the 13-21 % fewer workgroups only pay at 56)
+        if (tile_cfg == 5 || (efl > 1.04 * e2d && p.in_ys <= 56)) {
             p.flat_t = 1;
             if (p.in_ys <= 56) return launch_cfg<typename F::template Y2Flat<56>>(p, s, scratch, scratch_floats);
             if (p.in_ys <= 112) return launch_cfg<typename F::template Y2Flat<112>>(p, s, scratch, scratch_floats);
@@ -1791,6 +1793,9 @@ static int launch_split_family(ConvKParams& p, hipStream_t s, float* scratch, in
         // f16x3 (tools/conv_sweep.py, T = 32): every x4 expansion of the encoder is ~10 % faster on the 128-voxel tile (64 -> 256 444 ->
         // 403 us, 128 -> 512 263 -> 236, 512 -> 2048 128 -> 115)
         if (BFV == 3 && p.Cout >= 4 * p.Cin) cfg = 2;
+        // ... and with the one-phase weight schedule (WMODE 1) the 128-voxel tile wins on every other 1x1 shape of the step too (T = 32:
+        // 512 -> 128 133 vs 146 us, 2048 -> 512 115 vs 123, 2048 -> 256 70 vs 75; the decoders' fuse convs likewise)
+        if (BFV == 3) cfg = 2;
     }
     if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats);
     return launch_cfg<Y1Small>(p, s, scratch, scratch_floats);
