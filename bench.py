@@ -11,8 +11,11 @@ per-frame), then per clip 3-D decoders -> fused heads -> fg mask -> fg gather ->
 clustering record (K, instance list), with the input frames already resident in HBM.  The step is captured as a hipGraph
 per lane; --lanes (default 3) steps are in flight on their own streams and workspaces.  value = clips / s.  Every clip result of the
 run is checked bitwise against the first result of its input batch (a mismatch: exit code 5, no line).  At N = 1 the same step is then
-timed in the two reference-width MFMA modes as well (``alt_precision``: bf16x6 and f32, shorter regions).  Clips are independent, so ranks share nothing (weak scaling, no data-path collective); the only collectives
-are the barrier / max-over-ranks around the timed region.  Prints ONE JSON line on rank 0.
+timed in the two reference-width MFMA modes as well (``alt_precision``: bf16x6 and f32, shorter regions).  Clips are independent, so
+ranks share nothing in ``value`` (weak scaling, no data-path collective; barrier / max-over-ranks around the timed region only).
+The same process then runs BASELINE configs[3] -- one 64-frame sequence sharded over the ranks, BOTH all-gathers (RCCL at N > 1)
+inside its timed region -- and attaches it as ``sequence`` (strong scaling, per-collective times, the ranks the process group saw,
+and a label checksum that is the same at every N); ``--no-sequence-leg`` skips it.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus N                          # N > 1 without a launcher: re-executes itself under torch.distributed.run
     python bench.py --workload davis|ytvis|kitti      # BASELINE configs[1] (default) | configs[2] | configs[4]
@@ -24,9 +27,9 @@ windows per encoder pass; frames shared by neighbouring clips pass the trunk onc
 (RCCL over xGMI) of the SEEDINESS planes -> cross-clip foreground mask; every rank gathers + clusters ITS OWN clips with
 label_start = 1; all-gather #2 of the one-byte label codes; the Hungarian chain runs on label-pair tables (host, microseconds per
 clip).  Both collectives are INSIDE the timed region.  value = clips / s of the whole job (strong scaling: the sequence is
-fixed); the line also carries the exchanges' bytes / time and a checksum of the stitched track labels that must be the same at
-every N.  ``--partition replicated`` selects the round-2 form (every rank receives all head outputs and repeats the whole chain)
-for A/B runs.  The default mode and this one share the model, weights and kernels.
+fixed); the line also carries the exchanges' bytes / time and a checksum of the stitched track labels that IS the same at
+every N (the encoder plans its launches for a fixed frame count, so a clip's embeddings do not depend on how many clips share its
+pass).  The default mode and this one share the model, weights and kernels.
 
 --workload: ``davis`` = BASELINE configs[1] (the metric's configuration, the default: T=8, 480x854 -> 480x864, R-101-FPN,
 embedding + seediness decoders); ``ytvis`` = configs[2] (T=8, 360x640 -> 384x640, youtube_vis.yaml heads: in-head seediness, 41+1
@@ -171,33 +174,30 @@ def cpu_baseline(sd, frames_cpu, gpu_out=None, runs=3):
     return res
 
 
-def sequence_mode(args, pipe, device, rank, world, use_dist):
-    """One step = the whole sequence (see the module docstring).  Every rank ends with the same stitched tracks."""
+def run_sequence_leg(args, pipe, device, rank, world, use_dist, frames_n, steps, warmup):
+    """BASELINE configs[3]: one step = the whole sequence through ``pipeline.run_sequence_sharded`` (see the module docstring), both
+    all-gathers inside the timed region.  Every rank ends with the same stitched tracks (asserted).  -> dict (identical on all ranks)."""
     import zlib
     import torch.distributed as dist
-    from stemseg_amd import hip
     from stemseg_amd.inference.main import get_subsequence_frames
     from stemseg_amd.pipeline import run_sequence_sharded
-    F, overlap = args.frames, 4
+    F, overlap = frames_n, 4
     n_src = (F + T - 1) // T
     frames = torch.cat([make_clip(5000 + i, device) for i in range(n_src)], 0)[:F].contiguous()      # same frames on every rank
     clips, _ = get_subsequence_frames(F, T, "davis", overlap)
+    prev_overlap = pipe.model.overlap_decoders
     pipe.model.overlap_decoders = False
+    pipe.model.set_lane(0)
     eh = pipe.model._model.embedding_head
     split = (eh.embedding_size, eh.variance_channels)
+    per_pass = 8                                      # up to 8 overlapping windows per encoder pass (36 frames), full batches as graph replays on two lanes
 
-    def embed_many(my_clips):                         # up to 4 clips per encoder pass, full batches as graph replays on two lanes
-        return pipe.embed_many(frames, my_clips, batch=max(1, args.clips_per_step), lanes=2, use_graph=not args.no_graph)
+    def embed_many(my_clips):
+        return pipe.embed_many(frames, my_clips, batch=per_pass, lanes=2, use_graph=not args.no_graph)
     chainer = pipe.tg.chainer
-    stats, ag_ms, res = {}, [], None
-
-    replicated = args.partition == "replicated"
+    stats, ag1_ms, ag2_ms, host_ms, res = {}, [], [], [], None
 
     def one():
-        if replicated:
-            from stemseg_amd.pipeline import run_sequence_replicated
-            return run_sequence_replicated(F, None, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats,
-                                           embed_many_fn=embed_many, channel_split=split)
         return run_sequence_sharded(F, None, chainer, "davis", frame_overlap=overlap, seediness_thresh=0.25, stats=stats,
                                     embed_many_fn=embed_many, channel_split=split, outputs_on_cpu=False)
 
@@ -205,17 +205,18 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         res = one()
     sync()
     t0 = time.perf_counter()
-    host_ms = []
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = one()
-        ag_ms.append(stats["allgather_ms"])
+        ag1_ms.append(stats["allgather_seediness_ms"])
+        ag2_ms.append(stats["allgather_codes_ms"])
         host_ms.append(stats.get("host_chain_ms", 0.0))
     sync()
     dt = time.perf_counter() - t0
+    pipe.model.overlap_decoders = prev_overlap
     (track, counts, life) = res[0]
     crc = zlib.crc32(torch.cat([t.cpu() for t in track]).numpy().tobytes()) if track else 0
     if os.environ.get("STEMSEG_BENCH_DUMP") and rank == 0:      # (debugging aid: the stitched labels of the last step, for comparisons across N)
@@ -230,30 +231,41 @@ def sequence_mode(args, pipe, device, rank, world, use_dist):
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dt = float(tmax[0].item())
         assert float(tmax[1].item()) == float(tmin[1].item()), "ranks disagree on the stitched tracks"
+    n_clips = len(clips)
+    med = lambda v: round(sorted(v)[len(v) // 2], 3) if v else 0.0      # noqa: E731
+    backend = (os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") if use_dist else "none")
+    return {
+        "metric": "clips/sec (T=8, 480p) embed+cluster, one %d-frame sequence sharded over the GPUs" % F,
+        "value": round(n_clips * steps / dt, 4), "unit": "clips/s", "n_gpus": len(ranks), "ranks": ranks, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "strong",
+        "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt in contiguous blocks "
+                               "to %d rank(s), %s, both decoders; all-gather #1 of the seediness planes -> fg mask; every rank clusters ITS clips with "
+                               "label_start = 1; all-gather #2 of one-byte label codes + clustering records; Hungarian chain on label-pair tables (host)"
+                               % (F, overlap, n_clips, world, BACKBONE),
+                   "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world,
+                   "embed": "up to %d windows per encoder pass, %s" % (per_pass, "eager" if args.no_graph else "full batches as hipGraph replays on 2 lanes"),
+                   "encoder_plan_frames": int(pipe.model._model.backbone.plan_frames)},
+        "exchange": {"collective": ("all_gather x2 per sequence (%s)" % ("RCCL over xGMI" if backend == "nccl" else backend + ": functional check, ranks share a GPU"))
+                     if world > 1 else "none (one rank: the process group, if any, has a single member and the exchange buffers are used in place)",
+                     "backend": backend, "ranks_in_group": world,
+                     "bytes_received_per_rank": stats["allgather_bytes"], "inside_timed_region": True,
+                     "allgather_1_seediness_us_median": round(1e3 * med(ag1_ms), 1), "allgather_2_codes_us_median": round(1e3 * med(ag2_ms), 1),
+                     "host_chain_ms_median": med(host_ms)},
+        "result": {"frames": len(track), "fg_points": int(sum(counts.values())), "highest_track_id": int(max(list(counts) + [0])),
+                   "label_checksum_crc32": int(crc),
+                   "note": "identical on every rank of a run (asserted) AND across N: every convolution of the encoder decides its tile and split-K "
+                           "factor for a fixed planning frame count, so a clip's embeddings are bit-identical whatever shares its encoder pass "
+                           "(tests/test_gpu_sharded.py asserts the checksum at virtual world 1 / 2 / 3 / 8)"}}
+
+
+def sequence_mode(args, pipe, device, rank, world, use_dist):
+    """``--sequence``: the sequence leg as the line of its own."""
+    from stemseg_amd import hip
+    leg = run_sequence_leg(args, pipe, device, rank, world, use_dist, args.frames, args.steps, args.warmup)
     if rank == 0:
-        n_clips = len(clips)
-        print(json.dumps({
-            "metric": "clips/sec (T=8, 480p) embed+cluster, one %d-frame sequence sharded over the GPUs" % F,
-            "value": round(n_clips * args.steps / dt, 4), "unit": "clips/s", "n_gpus": world, "ranks": ranks, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: %d DAVIS-shape frames (480x854 -> 480x864), T=8, overlap %d -> %d clips dealt in contiguous blocks "
-                                   "to %d rank(s), %s, both decoders; %s" % (F, overlap, n_clips, world, BACKBONE,
-                                   "all-gather of the [E+Ev+1, T, h4, w4] head outputs; replicated fg mask + clustering + Hungarian stitching (round-2 partitioning)"
-                                   if replicated else "all-gather #1 of the seediness planes -> fg mask; every rank clusters ITS clips with label_start = 1; "
-                                   "all-gather #2 of one-byte label codes + clustering records; Hungarian chain on label-pair tables (host)"),
-                       "clips": n_clips, "clips_per_rank_max": (n_clips + world - 1) // world, "embed": "%d clips per encoder pass, %s" % (max(1, args.clips_per_step), "eager" if args.no_graph else "full batches as hipGraph replays on 2 lanes"),
-                       "switches": library_switches()},
-            "exchange": {"collective": ("all_gather (%s)" % ("RCCL" if os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl" else
-                                                             os.environ["STEMSEG_BENCH_BACKEND"] + ": functional check, ranks share a GPU")) if world > 1 else "none (one rank)", "bytes_received_per_rank": stats["allgather_bytes"],
-                         "ms_median": round(sorted(ag_ms)[len(ag_ms) // 2], 3) if ag_ms else 0.0, "inside_timed_region": True,
-                         "host_chain_ms_median": round(sorted(host_ms)[len(host_ms) // 2], 3) if host_ms else 0.0,
-                         "partition": args.partition},
-            "result": {"frames": len(track), "fg_points": int(sum(counts.values())), "highest_track_id": int(max(list(counts) + [0])),
-                       "label_checksum_crc32": int(crc),
-                       "note": "identical on every rank of a run (asserted); across N it is identical whenever the encoder passes have the same shapes "
-                               "(N = 1 and 2 at 64 frames) -- other shapes round the embeddings differently in the last bits and the few points whose "
-                               "probability sits within that of a threshold may flip (measured: 2 of 1 656 561 labels between 8- and 5-window passes)"}}))
+        leg.update({"vs_baseline": None, "dtype": PRECISION_DTYPE[args.precision], "data": "synthetic",
+                    "operand_significand_bits": hip.PRECISION_INFO[args.precision]["operand_significand_bits"]})
+        print(json.dumps(leg))
 
 
 def rank_devices(device, rank, world, use_dist):
@@ -333,18 +345,21 @@ def stub_main(args, rank, world, use_dist):
         dist.destroy_process_group()
 
 
-PRECISION_DTYPE = {"f32": "f32", "bf16x3": "f32 operands as bf16x3 split (3 bf16 MFMAs per product, fp32 accumulate; ~1e-4)",
-                   "bf16x6": "f32 (every operand split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate: fp32-level results)",
-                   "f16x3": "f32 (every operand scaled by a power of two and split into 2 fp16 terms = 22 significand bits, 3 fp16 MFMAs per product, "
-                            "fp32 accumulate: fp32-level results)"}
+# ``dtype`` names the arithmetic the matrix products compute in -- it never opens with "f32" unless the operands ARE fp32
+PRECISION_DTYPE = {
+    "f32": "f32 (fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate)",
+    "bf16x6": "bf16x6: fp32 emulated from 3 bf16 terms per operand (exact split, 24-bit operand significands, fp32 exponent range), 6 bf16 MFMA "
+              "products per fp32 product, fp32 accumulate",
+    "f16x3": "f16x3: fp32 emulated from 2 fp16 terms per operand (22-bit operand significands; fp32 has 24), power-of-two operand scaling, 3 fp16 MFMA "
+             "products per fp32 product, fp32 accumulate; |activation| >= 2.6e5 -> non-finite, flagged on the device, clip re-run in bf16x6",
+}
 
 
-PRODUCTS = {"bf16x3": 3.0, "bf16x6": 6.0, "f16x3": 3.0}
+PRODUCTS = {"bf16x6": 6.0, "f16x3": 3.0}
 
 
 PRECISION_NOTE = {
     "f32": "v_mfma_f32_32x32x2_f32 on fp32 operands",
-    "bf16x3": "opt-in: two bf16 terms per operand, three products (~1e-4 on the maps; labels not identical on every input)",
     "bf16x6": "every fp32 operand split EXACTLY into three bf16 terms (24 significand bits), the six products of weight >= 2^-16 on "
               "v_mfma_f32_32x32x16_bf16, fp32 accumulation; the dropped products are <= 2^-23 |a*b|.  Evidence that this is fp32-level arithmetic, "
               "not a reduced precision: max error vs an fp64 convolution = 0.78-1.56x that of the fp32-input MFMA kernel on every kernel class / "
@@ -357,13 +372,9 @@ PRECISION_NOTE = {
              "against an fp64 convolution the error stays at the fp32-input MFMA kernel's own level on every kernel class / tile / epilogue and "
              "over activation magnitudes of 1e-4 ... 2e4 (tests/test_gpu_bf16x6.py, both modes); labels are checked against the reference's CPU results (tests/test_gpu_parity.py) and the "
              "CPU oracle at full size in THIS run (cpu_baseline.parity_vs_hip_path).  Half the matrix work of bf16x6; |activation| >= 2.6e5 "
-             "overflows to non-finite outputs -- --precision bf16x6 has fp32's full range",
+             "overflows to non-finite outputs: the lane that reads such a clip back re-runs its batch in bf16x6 (GraphedStep.collect); "
+             "--precision bf16x6 has fp32's full range.  NOT the reference's arithmetic width: the alt_precision legs of this line are",
 }
-
-
-def library_switches():
-    """The A/B switches the library reads from the environment (csrc/conv_igemm.hip), as set for this run."""
-    return {k: os.environ.get(k, "default") for k in ("STEMSEG_K3_DB", "STEMSEG_FLAT", "STEMSEG_PLANNER", "STEMSEG_T_FASTEST", "STEMSEG_GLDS", "STEMSEG_GN_EPILOGUE", "STEMSEG_TILE224", "STEMSEG_AUTOSPLIT")}
 
 
 def mark(msg):
@@ -382,10 +393,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the bf16x6 / f32 legs (N = 1, davis workload only)")
     ap.add_argument("--alt-steps", type=int, default=16, help="timed steps of each reference-width leg")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3"],
                     help="MFMA mode of every convolution: f16x3 (default, the library's default) = two fp16 terms of the power-of-two-scaled "
                          "operands, three products, fp32 accumulate (fp32-level results); bf16x6 = exact three-term bf16 split, six products "
-                         "(fp32-level, fp32's exponent range); f32 = fp32-input MFMA; bf16x3 = two-term bf16 split (~1e-4)")
+                         "(fp32-level, fp32's exponent range); f32 = fp32-input MFMA")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly instead of replaying the captured hipGraph of the step (use under rocprofv3)")
     ap.add_argument("--graph", action="store_true", help=argparse.SUPPRESS)      # (the default; kept for old command lines)
@@ -402,8 +413,11 @@ def main():
                          "label-pair tables (see the module docstring)")
     ap.add_argument("--frames", type=int, default=64, help="--sequence: frames of the sequence (64 -> 15 clips at overlap 4; 36 -> 8)")
     ap.add_argument("--workload", default="davis", choices=sorted(WORKLOADS), help="BASELINE config to run (default: configs[1], the metric's)")
-    ap.add_argument("--partition", default="clips", choices=["clips", "replicated"],
-                    help="--sequence: 'clips' = every rank clusters its own clips, label codes exchanged (SURVEY 8(e)); 'replicated' = round-2 form")
+    ap.add_argument("--no-sequence-leg", action="store_true", help="clip bench: skip the attached BASELINE configs[3] leg (``sequence`` in the line)")
+    ap.add_argument("--sequence-steps", type=int, default=4, help="timed sequences of the attached leg (1 warm-up)")
+    ap.add_argument("--plan-frames", type=int, default=None,
+                    help="frames the encoder plans its launches for (ResNetFPN.plan_frames; default: the frames of one step = clips-per-step x 8, "
+                         "32 under --sequence).  Results are bit-identical across batch shapes for ONE value; it is a throughput knob only")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -454,6 +468,9 @@ def main():
     hip.require_gpu()
     pipe, sd = build_pipeline(device)
     pipe.model.set_precision(args.precision)
+    if args.plan_frames is None:
+        args.plan_frames = 32 if args.sequence else max(1, args.clips_per_step) * T
+    pipe.model._model.backbone.plan_frames = int(args.plan_frames)
     if args.sequence:
         sequence_mode(args, pipe, device, rank, world, use_dist)
         if use_dist:
@@ -473,10 +490,19 @@ def main():
         # sum of the fp32 BIT PATTERNS of the embedding map: exact, order-independent), compared once after the timed region.
         bitsums = {0: [], 1: []}
 
-        def read_back(outs, batch=None):                   # the consumer's read-back (K, centres): one small D2H per clip
+        fallbacks = [0]
+
+        def read_back(outs, batch=None, lane=None):        # the consumer's read-back (K, centres): one small D2H per clip
+            if lane is not None:
+                # graph lane: GraphedStep.collect reads the records; a batch with a non-finite head output is re-run in bf16x6 on the lane
+                got, metas = lane.collect()
+                fallbacks[0] += int(got[0] is not outs[0])
+                outs = got
+            else:
+                metas = [hip.read_cluster_meta(o["meta"], o.get("status")) for o in outs]      # (eager steps: raises on a non-finite head output)
             if batch is not None:
                 bitsums[batch].append(torch.stack([o["emb"].view(torch.int32).sum(dtype=torch.int64) for o in outs]))
-            return [hip.read_cluster_meta(o["meta"], o.get("status")) for o in outs][-1]      # (raises on a non-finite head output)
+            return metas[-1]
 
         def step(i):
             return read_back(pipe.step_batch(clips[i % len(clips)], NC))
@@ -520,7 +546,7 @@ def main():
             m = None
             if pending[k] is not None:
                 with torch.cuda.stream(lanes[k].stream):
-                    m = read_back(pending[k], pending_batch[k])
+                    m = read_back(pending[k], pending_batch[k], lanes[k])
             pending[k] = lanes[k].run_async(clips[i % len(clips)])
             pending_batch[k] = i % len(clips)
             return m
@@ -530,7 +556,7 @@ def main():
             for k in range(len(lanes)):
                 if pending[k] is not None:
                     with torch.cuda.stream(lanes[k].stream):
-                        m = read_back(pending[k], pending_batch[k])
+                        m = read_back(pending[k], pending_batch[k], lanes[k])
                     pending[k] = None
             return m
 
@@ -556,7 +582,7 @@ def main():
                     t = torch.stack([r.to(device) for r in rows]).cpu()
                     checked += int(t.numel())
                     mismatching += int((t != t[0:1]).sum())
-            determinism = {"clip_results_checked": checked, "mismatching": mismatching,
+            determinism = {"clip_results_checked": checked, "mismatching": mismatching, "overflow_fallbacks": fallbacks[0],
                            "what": "int64 sum of the fp32 bit patterns of every clip's embedding map, every step since the first replay (pre-runs and "
                                    "timed region, %d lanes in flight), against the first result of the same input batch; a mismatch makes the bench "
                                    "exit non-zero without a line" % len(lanes)}
@@ -602,7 +628,9 @@ def main():
         for j, prec in enumerate(p_ for p_ in ("bf16x6", "f32") if p_ != args.precision):
             a = run_leg(prec, args.alt_steps, 1, 100 * (j + 1))
             ach_a, peak_a, ms_a, _, _ = k3_class(a["prof"], prec)
-            alt[prec] = {"value": round(args.alt_steps * NC / a["dt"], 4), "unit": "clips/s", "steps": args.alt_steps, "ms_per_step": round(1e3 * a["dt"] / args.alt_steps, 3),
+            alt[prec] = {"value": round(args.alt_steps * NC / a["dt"], 4), "unit": "clips/s", "dtype": PRECISION_DTYPE[prec],
+                         "operand_significand_bits": hip.PRECISION_INFO[prec]["operand_significand_bits"],
+                         "steps": args.alt_steps, "ms_per_step": round(1e3 * a["dt"] / args.alt_steps, 3),
                          "determinism_mismatching": a["determinism"]["mismatching"] if a["determinism"] else None,
                          "roofline_3x3x3": {"achieved": round(ach_a, 2), "peak": round(peak_a, 1), "frac": round(ach_a / peak_a, 4), "unit": "TFLOP/s (fp32-equivalent)"}}
             del a
@@ -611,6 +639,20 @@ def main():
     ranks = rank_devices(device, rank, world, use_dist)
     if use_dist and os.environ.get("STEMSEG_BENCH_BACKEND", "nccl") == "nccl":
         assert len({r["device"] for r in ranks}) == world, "ranks share a device: %s" % (ranks,)
+    # BASELINE configs[3] in the same process group: one 64-frame sequence sharded over the ranks, both all-gathers (RCCL at N > 1)
+    # inside its timed region -- the data-path collectives of the framework, which the weak-scaling value above never touches
+    seq_leg = None
+    if not args.no_sequence_leg and args.workload == "davis":
+        try:
+            pipe.model.set_precision(args.precision)
+            seq_leg = run_sequence_leg(args, pipe, device, rank, world, use_dist, 64, max(1, args.sequence_steps), 1)
+        except Exception as e:  # noqa: BLE001  (never lose the clip number because the attached leg failed; at N > 1 a failure here is fatal for the group anyway)
+            if use_dist and world > 1:
+                raise
+            import traceback
+            traceback.print_exc()
+            seq_leg = {"value": None, "error": repr(e)}
+        pipe.model.set_lane(0)
 
     if rank == 0:
         clips_total = args.steps * world * NC
@@ -649,13 +691,14 @@ def main():
             "n_gpus": len(ranks), "ranks": ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": PRECISION_DTYPE[args.precision],
+            "operand_significand_bits": hip.PRECISION_INFO[args.precision]["operand_significand_bits"],
             "data": "synthetic",
             "alt_precision": alt if alt else None,
             "config": {"workload": WL["name"], "clips_per_step": NC, "steps_in_flight": len(lanes) if graph is not None else 1, "random_init": "He-normal; seediness head gain 30 so clustering runs its rounds",
                        "last_clip": {"K": int(meta.K), "n_points": int(meta.n_points)}, "determinism": determinism,
-                       "precision": {"mode": args.precision, "note": PRECISION_NOTE[args.precision]},
-                       "switches": library_switches()},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x3": "bf16x3 on MFMA 32x32x16 bf16; peak = 2500/3", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s", "f16x3": "f16x3 on MFMA 32x32x16 f16; peak = 2500/3 fp32-equivalent TFLOP/s"}[args.precision],
+                       "precision": dict(hip.PRECISION_INFO[args.precision], mode=args.precision, note=PRECISION_NOTE[args.precision]),
+                       "encoder_plan_frames": int(args.plan_frames)},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s", "f16x3": "f16x3 on MFMA 32x32x16 f16; peak = 2500/3 fp32-equivalent TFLOP/s"}[args.precision],
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s" if args.precision == "f32" else "TFLOP/s (fp32-equivalent: conv FLOPs / time; the MFMA pipe issues %d 16-bit products per fp32 product)" % PRODUCTS.get(args.precision, 1),
                          "frac": round(ach / peak, 4), "achieved_vs_fp32_input_mfma_peak": round(ach / PEAK_MFMA_F32_TFLOPS, 3),
                          "achieved_vs_bf16x6_roof": round(ach / (PEAK_MFMA_BF16_TFLOPS / 6.0), 3),
@@ -674,6 +717,7 @@ def main():
                          "conv_classes_eager": breakdown,
                          "hbm_kernels_eager": {"peak_gb_per_s": PEAK_HBM_GBPS, "bytes": "algorithmic: inputs read once + outputs written once", "kernels": hbm}},
         }
+        res["sequence"] = seq_leg
         if world == 1 and not args.no_cpu_baseline and args.workload == "davis":
             try:
                 pipe.model.set_lane(0)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 6
+#define STEMSEG_HIP_ABI_VERSION 7
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -95,37 +95,38 @@ typedef struct StemsegConvEpilogue {
     int64_t      res_c_stride, res_t_stride, res_y_stride;
     int32_t      decode_H, decode_W; /* > 0: the 1x1x1 conv runs on a flat [C][V] input (in->T = in->H = 1, in->W = V) and
                                         voxel v is stored at (t,y,x) = (v/(H*W), (v/W)%H, v%W) of `out` (e.g. dense -> haloed) */
-    int32_t      precision;        /* STEMSEG_PRECISION_F32 (exact fp32 MFMA) or STEMSEG_PRECISION_BF16X3: every fp32 operand is
-                                      split hi + lo into bf16 and a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores
-                                      with fp32 accumulation (~2^-17 relative per product, 5.3x the fp32-MFMA rate); packed_w
-                                      must then come from stemseg_hip_pack_conv_weight_bf16x3.
+    int32_t      precision;        /* arithmetic of the matrix products; packed_w must be packed for the same mode.
+                                      STEMSEG_PRECISION_F32: v_mfma_f32_32x32x2_f32 on the fp32 operands (exact products);
+                                      packed_w from stemseg_hip_pack_conv_weight.
                                       STEMSEG_PRECISION_BF16X6: every fp32 operand is split EXACTLY into three bf16 terms
                                       (hi + mid + lo, 24 significand bits) and a*b is the sum of the six products of weight
                                       >= 2^-16 on the bf16 matrix cores, fp32 accumulation: the dropped products are <= 2^-23
-                                      |a*b|, below the rounding of the fp32 accumulation itself -- fp32-level results at 2.7x
-                                      the fp32-MFMA rate; packed_w from stemseg_hip_pack_conv_weight_split(..., planes = 3).
+                                      |a*b|, below the rounding of the fp32 accumulation itself -- fp32-level results, fp32's
+                                      exponent range, 2.7x the fp32-MFMA rate.
                                       STEMSEG_PRECISION_F16X3: both operands are scaled by a power of two (activations by 2^-2,
                                       every OUTPUT CHANNEL's weights so that its largest lands in [2^13, 2^14)) and split into two fp16
-                                      terms (hi + lo, 22 significand bits); the low activation term is stored as lo * 2^11
-                                      and meets a third weight plane, hi_w * 2^-11, so hi is a normal fp16 number and the
-                                      pair keeps 22 bits (or 2^-36 absolute) for 2.5e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a + hi_w*lo_a + hi_w*hi_a on the fp16
-                                      matrix cores, fp32 accumulation, accumulators scaled back exactly: the dropped lo*lo
-                                      product and the split remainder are <= 2^-22 |a*b| -- measured below the rounding
-                                      spread of fp32 accumulation orders -- at HALF the matrix work of bf16x6.  |a| >= 2.6e5
-                                      overflows (inf in, non-finite out); packed_w from
-                                      stemseg_hip_pack_conv_weight_prec(..., STEMSEG_PRECISION_F16X3) */
+                                      terms (hi + lo: 22 significand bits, fp32 has 24); the low activation term is stored as
+                                      lo * 2^11 and meets a third weight operand, hi_w * 2^-11, so hi is a normal fp16 number and
+                                      the pair keeps 22 bits (or 2^-36 absolute) for 2.5e-4 <= |a| < 2.6e5.  a*b = lo_w*hi_a +
+                                      hi_w*lo_a + hi_w*hi_a on the fp16 matrix cores, fp32 accumulation, accumulators scaled back
+                                      exactly: the dropped lo*lo product and the split remainder are <= 2^-22 |a*b| -- measured
+                                      below the rounding spread of fp32 accumulation orders -- at HALF the matrix work of
+                                      bf16x6.  |a| >= 2.6e5 overflows (inf in, non-finite out: see stemseg_hip_nonfinite_flags).
+                                      packed_w of both split modes from stemseg_hip_pack_conv_weight_prec. */
+    /* Planning shape: the launch holds `frames` frames (its T axis, or -- flat [C][V] input -- V / the per-frame voxel count), and
+       the tile shape and split-K factor are decided as if it held `plan_frames`, counting on `plan_scratch_floats` of split-K
+       scratch (the real scratch must hold frames / plan_frames times what the plan uses, or the call fails).  The K-partition of a
+       split-K launch is a summation order: decided this way, every output bit is a function of the per-frame layer shape, the
+       precision and plan_frames -- not of how many frames share the launch.  plan_frames = 0: decide on the real shape. */
+    int32_t      frames, plan_frames;
+    int64_t      plan_scratch_floats;
 } StemsegConvEpilogue;
 #define STEMSEG_PRECISION_F32    0
-#define STEMSEG_PRECISION_BF16X3 1
-#define STEMSEG_PRECISION_BF16X6 2
+#define STEMSEG_PRECISION_BF16X6 2      /* (1 was the two-term bf16 split of rounds 2-4: ~1e-4 on the maps, retired) */
 #define STEMSEG_PRECISION_F16X3  3
-int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t Cin, int32_t taps);
-int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream);
-/* planes = 2: the bf16x3 packing above; planes = 3: the bf16x6 packing (hi | mid | lo planes per k-group). */
-int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes);
-int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream);
-/* By precision code (1, 2: the packings above; 3: three fp16 planes of the scaled weights (hi, lo, hi * 2^-11) + per output
- * channel a float 1 / (weight scale x activation scale) and the bits of max|w| of the channel: 8 * Cout bytes). */
+/* Split-staged packings, by precision code.  2: per channel chunk [k-group][hi | mid | lo][lane half][Cout] x 8 bf16; 3: the same
+ * order with two fp16 planes (hi, lo) of the scaled weights + per output channel a float 1 / (weight scale x activation scale) and
+ * the bits of max|w| of the channel (8 * Cout bytes).  bytes = 0 for any other code. */
 int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision);
 int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t precision, void* stream);
 /* (kt,kh,kw) additionally accepts (1,3,3): a 2-D 3x3 convolution over every t-plane (the encoder's frames).
@@ -211,7 +212,7 @@ typedef struct StemsegDecoderDesc {
                                     streams and the call returns without joining; the caller must enqueue
                                     stemseg_hip_decoder_join(concurrency, stream) before it consumes `out` or re-uses the
                                     inputs / workspace.  Lets a twin decoder be enqueued in between (both fill the chip). */
-    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 | _F16X3 for every convolution of the decoder
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X6 | _F16X3 for every convolution of the decoder
                                     (weights in StemsegDecoderWeights must be packed for the same mode)                    */
 } StemsegDecoderDesc;
 
@@ -227,12 +228,6 @@ typedef struct StemsegDecoderWeights {
     const float* grid_t;         /* [T], [H4], [W4] linspace vectors (may be NULL if no act uses the grid) */
     const float* grid_y;
     const float* grid_x;
-    /* Optional (NULL = absent): branch i's first convolution (block_32x.0, block_16x.0, block_8x.0, block_4x.0) has already run --
-       first_conv_out[i] = its output WITH bias, dense [inter[i]][T][h_i][w_i]; first_conv_stats[i] = the GroupNorm statistics of that
-       output, [gn_groups][2] = (mean, rstd).  Produced by stemseg_hip_shared_convs_forward for decoders that read the same FPN maps:
-       pass the decoder's channel / group slice of the shared outputs.  conv_w / conv_b of that stage are then not read. */
-    const float* first_conv_out[4];
-    const float* first_conv_stats[4];
 } StemsegDecoderWeights;
 
 size_t stemseg_hip_decoder_workspace_bytes(const StemsegDecoderDesc* desc);
@@ -247,33 +242,6 @@ int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDec
 int stemseg_hip_decoder_join(int32_t concurrency, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * First-layer convolutions shared between decoders.  block_32x.0 / block_16x.0 / block_8x.0 / block_4x.0 of the embedding,
- * seediness and semseg decoders all read the same four FPN maps (embedding_decoder.py:111-127, seediness_decoder.py:92-108,
- * semseg_decoder.py:96-112): one 3x3x3 convolution per branch with the decoders' output channels CONCATENATED (weights
- * torch.cat(dim=0) of the decoders' weights, packed as one convolution; GroupNorm groups concatenated likewise, which needs the same
- * channels-per-group in every decoder sharing the branch) stages every input tile once and launches (sum of Cout) / 128 x the
- * workgroups.  Every output channel is the same dot product, in the same order, as in the decoder's own convolution whenever both
- * pick the same tile and K-split; results otherwise agree to fp32 rounding of the split-K partial sums.
- * ---------------------------------------------------------------------------------------------- */
-typedef struct StemsegSharedConvsDesc {
-    int32_t struct_bytes;        /* = sizeof(StemsegSharedConvsDesc), checked */
-    int32_t in_channels;         /* FPN channels (256) */
-    int32_t T, H4, W4;           /* as StemsegDecoderDesc */
-    int32_t precision;           /* STEMSEG_PRECISION_* ; conv_w packed for it */
-    int32_t cout[4];             /* concatenated output channels of branch 32x, 16x, 8x, 4x; 0 = branch not shared (skipped) */
-    int32_t gn_groups[4];        /* concatenated GroupNorm group count of the branch (1..64) */
-    float   gn_eps;
-} StemsegSharedConvsDesc;
-
-size_t stemseg_hip_shared_convs_workspace_bytes(const StemsegSharedConvsDesc* desc);
-/* feats_haloed[i]: the zero-haloed FPN map of branch i (decoder input_layout 2).  On return conv_out[i] / stats_out[i] point INTO the
- * workspace: dense [cout[i]][T][h_i][w_i] and [gn_groups[i]][2]; decoder k's slice starts at channel / group offset = the sum of the
- * decoders before it.  The workspace needs no initialisation and must stay untouched until the decoders that consume it have run. */
-int stemseg_hip_shared_convs_forward(const StemsegSharedConvsDesc* desc, const float* const conv_w[4], const float* const conv_b[4],
-                                     const float* const feats_haloed[4], void* workspace, size_t ws_bytes, float* conv_out[4],
-                                     float* stats_out[4], void* stream);
-
-/* ------------------------------------------------------------------------------------------------
  * 2-D encoder: ResNet-50/101 + FPN over the T frames of a clip (backbone/resnet.py:105-113, fpn.py:47-69,
  * model_builder.py:154-169).  FrozenBatchNorm (make_layers.py:51-63) is folded into conv weight / bias by the caller.
  * ---------------------------------------------------------------------------------------------- */
@@ -284,7 +252,7 @@ typedef struct StemsegEncoderDesc {
     int32_t blocks[4];           /* bottleneck blocks per stage: R-50 {3,4,6,3}, R-101 {3,4,23,3}       */
     int32_t T, H, W;             /* frames per call and padded frame size (multiples of 32)              */
     int32_t out_channels;        /* 256                                                                  */
-    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X3 | _BF16X6 | _F16X3 (all MFMA convs; the 7x7 stem stays fp32 VALU) */
+    int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X6 | _F16X3 (every 3x3 / 1x1 conv; the 7x7 stem is always fp32-input MFMA) */
     int32_t n_clips;             /* >= 1: the T frames are n_clips consecutive clips of T / n_clips frames; each clip's four maps
                                     go to their own output volumes (frames are independent in the encoder, so several clips
                                     share one pass: layer3 / layer4 launches grow from 0.4 to n_clips x 0.4 waves of the chip) */
@@ -294,6 +262,11 @@ typedef struct StemsegEncoderDesc {
                                     the encoder once (the reference's cross-clip feature cache, inference_model.py:83-108) and
                                     each clip's window of the FPN maps is copied to its output volumes */
     int32_t clip_stride;
+    int32_t plan_frames;         /* > 0: every convolution of the pass decides its tile shape and split-K factor as if the pass held
+                                    this many frames (StemsegConvEpilogue.plan_frames): a frame's four maps are then bit-identical
+                                    whatever T, n_clips and the windowing of the pass are -- one clip, a batch of clips, or the
+                                    union of overlapping windows -- which is what makes an N-rank sequence job reproduce the
+                                    one-rank labels.  0: decide on the real T (fastest for that T; results depend on it). */
 } StemsegEncoderDesc;
 
 typedef struct StemsegEncoderWeights {

@@ -295,180 +295,6 @@ __global__ __launch_bounds__(CL_THREADS) void cluster_final_kernel(const Cluster
     }
 }
 
-// ---- one-launch form: persistent workgroups, points resident in registers, grid barrier per round ------------------------
-// "one launch, one read-back".  CP_BLOCKS workgroups of CP_THREADS threads stay resident for
-// the whole call; thread t of workgroup w owns the points (j * CP_BLOCKS + w) * CP_THREADS + t, j < PPT, and keeps their
-// embedding / seediness / round in registers, so a round touches global memory only for the 16-byte per-workgroup partial
-// (best seed, its index, #unassigned) and the winning seed's centre.  Rounds are separated by an exchange of data-tagged 8-byte
-// granules (AGENT-scope atomics on both sides: write-through / L1-bypassing, valid across the eight non-coherent XCD L2s --
-// MI355X_MICROARCH.md "Valid forms"; measured with an arrival counter + poll first: 8 us per round, no better than a launch);
-// every spin is bounded.  Same arithmetic and the same
-// tie rules as the multi-launch form (better(): first maximal seediness), hence the same labels bit for bit.
-constexpr int CP_THREADS = 512;
-constexpr int CP_BLOCKS = 128;
-constexpr unsigned int CP_SPIN_LIMIT = 1u << 21;          // polls of ~1 us: seconds, then the call reports failure instead of hanging
-
-struct ClusterSync {                   // zeroed by cluster_persistent_init_kernel (the launch in front)
-    unsigned long long arrived;        // (unused by the granule form)
-    unsigned long long failed;
-    unsigned long long pad[6];
-    unsigned long long part[2][CP_BLOCKS][2];   // [round parity][workgroup] {seed bits | idx << 32, n_unassigned}
-};
-
-__global__ void cluster_persistent_init_kernel(ClusterSync* sy, StemsegClusterMeta* meta) {
-    for (int k = threadIdx.x; k < (int)(sizeof(StemsegClusterMeta) / 4); k += blockDim.x) reinterpret_cast<int*>(meta)[k] = 0;
-    for (int k = threadIdx.x; k < (int)(sizeof(ClusterSync) / 8); k += blockDim.x)       // (stale tags of an earlier call in the same memory)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(sy) + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int PPT>
-__global__ __launch_bounds__(CP_THREADS) void cluster_persistent_kernel(const ClusterKParams p, ClusterSync* sy) {
-    __shared__ float sh_s[CP_THREADS / 64];
-    __shared__ int sh_i[CP_THREADS / 64];
-    __shared__ int sh_c[CP_THREADS / 64];
-    __shared__ float sh_cen[STEMSEG_MAX_INSTANCES][STEMSEG_MAX_EMB_DIMS];
-    __shared__ float sh_bw[STEMSEG_MAX_INSTANCES][STEMSEG_MAX_EMB_DIMS];
-    __shared__ float sh_seedp[STEMSEG_MAX_INSTANCES];
-    const long long N = cl_n(p);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // ---- this thread's points ----
-    long long idx[PPT];
-    float sd[PPT], xv[PPT][STEMSEG_MAX_EMB_DIMS];
-    int ro[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        idx[j] = ((long long)j * CP_BLOCKS + blockIdx.x) * CP_THREADS + tid;
-        ro[j] = -1;
-        sd[j] = 0.f;
-#pragma unroll
-        for (int e = 0; e < STEMSEG_MAX_EMB_DIMS; ++e) xv[j][e] = 0.f;
-        if (idx[j] < N) {
-            sd[j] = p.seed[idx[j]];
-            if (p.E == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(p.emb + idx[j] * 4);
-                xv[j][0] = v.x; xv[j][1] = v.y; xv[j][2] = v.z; xv[j][3] = v.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < STEMSEG_MAX_EMB_DIMS; ++e) if (e < p.E) xv[j][e] = p.emb[idx[j] * p.E + e];
-            }
-        }
-    }
-    auto block_best = [&](float& bs, int& bi, int& cnt) {           // (bs, bi, cnt) of the workgroup, in every thread
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float s2 = __shfl_down(bs, o, 64);
-            const int i2 = __shfl_down(bi, o, 64);
-            const int c2 = __shfl_down(cnt, o, 64);
-            if (better(s2, i2, bs, bi)) { bs = s2; bi = i2; }
-            cnt += c2;
-        }
-        if (lane == 0) { sh_s[wv] = bs; sh_i[wv] = bi; sh_c[wv] = cnt; }
-        __syncthreads();
-        bs = sh_s[0]; bi = sh_i[0]; cnt = sh_c[0];
-#pragma unroll
-        for (int k = 1; k < CP_THREADS / 64; ++k) {
-            if (better(sh_s[k], sh_i[k], bs, bi)) { bs = sh_s[k]; bi = sh_i[k]; }
-            cnt += sh_c[k];
-        }
-        __syncthreads();
-    };
-    int K = 0, exhausted = 0;
-    long long n_un_last = 0;
-    bool failed = false;
-    for (int round = 0; round < p.max_instances; ++round) {
-        // ---- this workgroup's candidate for the round's seed + its unassigned count -> partial ----
-        float bs = 0.f; int bi = -1; int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            if (idx[j] < N && ro[j] < 0) {
-                if (better(sd[j], (int)idx[j], bs, bi)) { bs = sd[j]; bi = (int)idx[j]; }
-                ++cnt;
-            }
-        block_best(bs, bi, cnt);
-        // publish: two data-TAGGED 8-byte granules per workgroup (tag = round + 1; slots double-buffered by round parity, a
-        // workgroup cannot run two rounds ahead of the slowest reader) -- no separate arrival counter, no fence: a granule is
-        // one agent-scope atomic store, readers poll the granules themselves
-        const unsigned long long tag = (unsigned long long)(round + 1) << 56;
-        if (tid == 0) {
-            unsigned long long* slot = sy->part[round & 1][blockIdx.x];
-            __hip_atomic_store(slot, (unsigned long long)__float_as_uint(bs) | ((unsigned long long)((unsigned int)bi & 0xFFFFFFu) << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + 1, (unsigned long long)(unsigned int)cnt | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- loop header of clusterers.py:106-118, identically in every workgroup: thread w collects workgroup w's granules.
-        // Measured on the box (tools/cluster_probe.py, N = 207 360, K = 20, hipGraph replay): this all-to-all form 161 us per call,
-        // an arrival counter + poll 170 us, workgroup 0 reducing and re-publishing the decision (two hops) 177 us -- against
-        // 167 us for the 22-launch form: a hand-off between workgroups costs what a kernel boundary costs (~4-8 us per round). ----
-        bs = 0.f; bi = -1; cnt = 0;
-        int bad = 0;
-        if (tid < CP_BLOCKS) {
-            unsigned long long ga, gc;
-            unsigned int spins = 0;
-            for (;;) {
-                ga = __hip_atomic_load(&sy->part[round & 1][tid][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gc = __hip_atomic_load(&sy->part[round & 1][tid][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((ga >> 56) == (unsigned long long)(round + 1) && (gc >> 56) == (unsigned long long)(round + 1)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > CP_SPIN_LIMIT) { bad = 1; break; }           // bounded: report failure instead of hanging the GPU
-            }
-            bs = __uint_as_float((unsigned int)ga);
-            const unsigned int i24 = (unsigned int)(ga >> 32) & 0xFFFFFFu;
-            bi = i24 == 0xFFFFFFu ? -1 : (int)i24;
-            cnt = (int)(unsigned int)(gc & 0xFFFFFFFFull);
-        }
-        if (__syncthreads_or(bad)) { failed = true; break; }
-        block_best(bs, bi, cnt);
-        n_un_last = cnt;
-        if (cnt == 0 || bs < p.min_seed) break;                   // clusterers.py:109-110, 116-117
-        if (tid < p.E) {
-            sh_cen[round][tid] = p.emb[(long long)bi * p.E + tid];
-            sh_bw[round][tid] = (tid < p.Ev) ? p.bw[(long long)bi * p.Ev + tid] : p.free_bw[tid - p.Ev];
-        }
-        if (tid == 0) sh_seedp[round] = bs;
-        __syncthreads();
-        float center[STEMSEG_MAX_EMB_DIMS], bwv[STEMSEG_MAX_EMB_DIMS];
-#pragma unroll
-        for (int e = 0; e < STEMSEG_MAX_EMB_DIMS; ++e) {
-            center[e] = (e < p.E) ? sh_cen[round][e] : 0.f;
-            bwv[e] = (e < p.E) ? sh_bw[round][e] : 0.f;
-        }
-        K = round + 1;
-        if (round == p.max_instances - 1) exhausted = 1;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            if (idx[j] < N && ro[j] < 0 && cl_prob(cl_distance(xv[j], center, bwv, p.E)) > p.primary) ro[j] = round;      // clusterers.py:140
-    }
-    // ---- secondary assignment (clusterers.py:148-159), labels, record ----
-    if (blockIdx.x == 0 && tid == 0) {
-        p.meta->K = failed ? -1 : K;
-        p.meta->exhausted = exhausted;
-        p.meta->n_points = N;
-        p.meta->n_unassigned_last = n_un_last;
-    }
-    if (blockIdx.x == 0)
-        for (int k = tid; k < K * STEMSEG_MAX_EMB_DIMS; k += CP_THREADS) {
-            p.meta->centers[k / STEMSEG_MAX_EMB_DIMS][k % STEMSEG_MAX_EMB_DIMS] = sh_cen[k / STEMSEG_MAX_EMB_DIMS][k % STEMSEG_MAX_EMB_DIMS];
-            p.meta->bandwidths[k / STEMSEG_MAX_EMB_DIMS][k % STEMSEG_MAX_EMB_DIMS] = sh_bw[k / STEMSEG_MAX_EMB_DIMS][k % STEMSEG_MAX_EMB_DIMS];
-            if (k % STEMSEG_MAX_EMB_DIMS == 0) p.meta->seed_prob[k / STEMSEG_MAX_EMB_DIMS] = sh_seedp[k / STEMSEG_MAX_EMB_DIMS];
-        }
-    const bool secondary = (n_un_last > 0) && (K > 0);
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        if (idx[j] >= p.n_max) continue;
-        if (idx[j] >= N) { p.labels[idx[j]] = -1; continue; }
-        int r = ro[j];
-        const bool avail = (r < 0) || (exhausted && r == p.max_instances - 1);      // stale mask after the last round
-        if (secondary && avail) {
-            float m = -1.f; int a = 0;
-            for (int k = 0; k < K; ++k) {
-                const float d = cl_distance(xv[j], sh_cen[k], sh_bw[k], p.E);
-                if (d > m) { m = d; a = k; }               // QUIRK: max distance, first index on ties
-            }
-            if (cl_prob(m) > p.secondary) r = a;
-        }
-        p.labels[idx[j]] = (r >= 0) ? (long long)r + p.label_start : -1;
-    }
-}
-
 // ---- fg mask ---------------------------------------------------------------------------------------
 __global__ void seed_accumulate_kernel(float* acc, const float* plane, long long n, int first) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -831,8 +657,7 @@ extern "C" int stemseg_hip_cluster_batch(const StemsegClusterItem* items, int32_
         ClusterBatch b;
         int n_live = 0;
         for (int i = i0; i < n_items && i < i0 + CL_MAX_BATCH; ++i) n_live += items[i].n_max > 0 ? 1 : 0;
-        static const int ppt_env = [] { const char* e = getenv("STEMSEG_CLUSTER_PPT"); return e ? atoi(e) : 0; }();
-        const int ppt = ppt_env > 0 ? ppt_env : (n_live >= 3 ? 2 : 1);
+        const int ppt = n_live >= 3 ? 2 : 1;
         int n = 0, nblk = 1;
         long long n_largest = 1;
         double work = 0.0;
@@ -853,32 +678,6 @@ extern "C" int stemseg_hip_cluster_batch(const StemsegClusterItem* items, int32_
         if (n == 0) continue;
         for (int k = n; k < CL_MAX_BATCH; ++k) b.p[k] = b.p[0];      // (never selected: blockIdx.y < n)
         void* ev = profile_begin(46, work, s);
-        // One set alone may take the one-launch form (STEMSEG_CLUSTER_PERSISTENT=1: persistent workgroups + grid barrier per round)
-        // when its points fit the resident threads' registers and no per-round mask / probability output is asked for; measured
-        // (tools/cluster_probe.py) against the multi-launch form below, which stays the default -- see DESIGN.md
-        static const int persistent = [] { const char* e = getenv("STEMSEG_CLUSTER_PERSISTENT"); return e ? atoi(e) : 0; }();
-        const long long cap4 = (long long)CP_BLOCKS * CP_THREADS * 4, cap12 = (long long)CP_BLOCKS * CP_THREADS * 12;
-        // the grid barrier needs all CP_BLOCKS workgroups resident together: refuse the form where the device cannot hold them even
-        // when it is otherwise idle (a smaller part, a register-hungrier build); co-running kernels of other streams can still delay
-        // residency -- the kernel then spins up to CP_SPIN_LIMIT and reports K = -1, which every read-back path turns into an error
-        static const bool fits = [] {
-            int dev = 0, cus = 0, b4 = 0, b12 = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b4, cluster_persistent_kernel<4>, CP_THREADS, 0) != hipSuccess) return false;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, cluster_persistent_kernel<12>, CP_THREADS, 0) != hipSuccess) return false;
-            return (long long)std::min(b4, b12) * cus >= CP_BLOCKS;
-        }();
-        if (persistent && fits && n == 1 && !b.p[0].masks && !b.p[0].probs && b.p[0].n_max <= cap12) {
-            const ClusterKParams& p = b.p[0];
-            ClusterSync* sy = reinterpret_cast<ClusterSync*>(p.partials);
-            hipLaunchKernelGGL(cluster_persistent_init_kernel, dim3(1), dim3(256), 0, s, sy, p.meta);
-            SS_LAUNCH_CHECK();
-            if (p.n_max <= cap4) hipLaunchKernelGGL(cluster_persistent_kernel<4>, dim3(CP_BLOCKS), dim3(CP_THREADS), 0, s, p, sy);
-            else hipLaunchKernelGGL(cluster_persistent_kernel<12>, dim3(CP_BLOCKS), dim3(CP_THREADS), 0, s, p, sy);
-            profile_end(ev, s);
-            SS_LAUNCH_CHECK();
-            continue;
-        }
         for (int round = -1; round < params->max_instances; ++round) {
             hipLaunchKernelGGL(cluster_round_kernel, dim3(nblk, n), dim3(CL_THREADS), 0, s, b, round);
             SS_LAUNCH_CHECK();

@@ -89,7 +89,12 @@ struct ConvEpilogue {            // fused into the conv epilogue (or the split-K
     const float* res = nullptr;  // residual, addressed with (res_cs, res_ts, res_ys) at the output's (c, t, y, x)
     int64_t res_cs = 0, res_ts = 0, res_ys = 0;
     int dec_H = 0, dec_W = 0;    // > 0: 1x1x1 conv launched on a flat [C][V] input; voxel v -> (v / (H*W), (v / W) % H, v % W)
-    int precision = 0;           // 0: exact fp32 MFMA; 1: bf16x3 split (weights must be packed with ..._bf16x3)
+    int precision = 0;           // STEMSEG_PRECISION_F32 | _BF16X6 | _F16X3 (the weights packed for it)
+    // Planning shape (conv_igemm.hip, PlanCtx): this launch holds `frames` frames (its T axis, or its flat voxel count / the
+    // per-frame voxel count); tile shape and split-K factor are decided as if it held `plan_frames`, with `plan_scratch_floats` of
+    // split-K scratch to count on -- so the summation order of every output does not depend on the batch.  0: decide on the real shape.
+    int frames = 0, plan_frames = 0;
+    int64_t plan_scratch_floats = 0;
     // GroupNorm statistics of the output in the same pass (decoder stages): see launch_conv3d_gn
     double* gn_part = nullptr;   // [Cout / gn_cpg][gn_cap][2] partial (sum, sum of squares) table
     int gn_cpg = 0, gn_cap = 0;

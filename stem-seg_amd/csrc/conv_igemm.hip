@@ -22,16 +22,16 @@
 // The same template also serves the encoder's 2-D convolutions (KT = 1; the frames of a clip are the T axis) and every
 // 1x1 convolution (one flat row of voxels).  Variants, all selected per launch by launch_conv3d():
 //   PIPE  next chunk prefetched into registers under the current chunk's MFMA stream
-//   DB    2-channel chunks + two LDS buffers, one barrier per chunk            (big 3x3x3 tile)
+//   GL    (with DB: two LDS buffers) the next chunk goes global -> LDS directly (global_load_lds_dwordx4), no staging registers:
+//         the big 3x3x3 tile and every 1x1 tile of the fp32-input mode
 //   FLAT  N tile = a run of the zero-haloed plane instead of rows x 32 columns  (maps whose width wastes a 32-column tile)
-//   BF    bf16x3 split on v_mfma_f32_32x32x16_bf16, fp32 accumulate             (opt-in precision mode)
-// plus split-K with a deterministic slab reduce, an XCD-aware (and, for 3-D taps, t-fastest) tile order, and a launch
-// planner that cuts big launches into whole rows + split-K rows so that their workgroups fill whole rounds of the chip.
-//   GL    with DB: the next chunk goes global -> LDS directly (global_load_lds_dwordx4), no staging registers -> 3-4 workgroups per CU
-//         for the 1x1 tiles (default for the big 3x3x3 tile and every 1x1 tile: STEMSEG_GLDS bit mask, default 9)
-// and the GroupNorm statistics of the output (decoder stages) as per-tile fp64 partial sums left by the epilogue.
-// A/B switches (environment, read once; bench.py records them): STEMSEG_K3_DB, STEMSEG_FLAT, STEMSEG_PLANNER, STEMSEG_T_FASTEST,
-// STEMSEG_GN_EPILOGUE (= 0 to disable), STEMSEG_GLDS (bit mask: 1 big 3x3x3, 2 other 3x3x3, 4 1x3x3, 8 1x1), STEMSEG_TILE224 (= 1 to enable).
+//   BF_   2 = bf16x6, 3 = f16x3: operands split once when a chunk is staged, products on v_mfma_f32_32x32x16_{bf16,f16}
+// plus split-K with a deterministic slab reduce, an XCD-aware (and, for 3-D taps, t-fastest) tile order, a launch planner
+// (fp32-input mode) that cuts big launches into whole rows + split-K rows so that their workgroups fill whole rounds of the
+// chip, and the GroupNorm statistics of the output (decoder stages) as per-tile fp64 partial sums left by the epilogue.
+// Every launch decision (tile shape, split-K factor) is a function of the layer's PLANNING shape and the precision only: the
+// encoder passes its per-frame shape with a fixed planning frame count, so the K-partition -- and with it every output bit --
+// does not depend on how many frames share a launch (ConvEpilogue::plan_frames).
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -63,11 +63,6 @@
 #ifndef SS_X6_SPREAD_DIV
 #define SS_X6_SPREAD_DIV 2          // the spread loads go out over the first 1 / DIV of a phase's (k-group, mi) steps (A/B, step throughput vs DIV 2:
                                   // 1: +0.4 %, 3: -0.5 %, 4: -1.0 %)
-#endif
-#ifndef SS_X6_INDB
-#define SS_X6_INDB 0               // 1: two input tiles in LDS, the next chunk's split + ds_writes between the MFMAs of the running one.  Measured
-                                  // 0 ... -4 % in round 3 and -0.5 % in round 4 (the store section between the barriers is not what the kernel waits
-                                  // for): off, kept for the record
 #endif
 
 namespace stemseg {
@@ -111,16 +106,10 @@ struct ConvKParams {
     int* gn_used_host;           // host-side slot counter of the current conv (never dereferenced on the device)
 };
 
-// bf16x3 ("3xBF16") mode: every fp32 operand x is split as x = hi + lo (+ residual <= 2^-18 |x|) with hi, lo bf16, and
-// a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate):
-// ~2^-17 relative error per product -- the same order as fp32 accumulation round-off over K = 6912 -- at 16/3 = 5.3x the
-// fp32-MFMA rate.  k-groups of 16: lane half h carries CPH channels x TPG taps (CPH * TPG = 8).
-// DB: double-buffered LDS with a 2-channel chunk -- the next chunk is prefetched into registers under the MFMA stream and
-// written to the OTHER buffer, so a chunk costs one barrier and no exposed load latency (big 3x3x3 tile, fp32 only).
 // FLAT (PMAX > 0): the N tile is a run of NSEG * 32 consecutive positions of the zero-haloed PLANE (row pitch <= PMAX floats)
 // instead of ROWS x 32 columns: a tap is the flat offset dy * pitch + dx, so maps whose width is not a multiple of 32
 // (W = 54: 64 columns computed for 54; flat: 56 for 54) lose almost nothing to tile quantisation.  Junk positions (halo
-// columns) are computed and not stored.  fp32 only, scalar epilogue.
+// columns) are computed and not stored.  Scalar epilogue.
 // GL (with DB): the next chunk goes global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, LDS image
 // lane-linear = exactly the [piece] order of the staging loops), issued before the chunk's MFMA stream and retired by the
 // vmcnt(0) in front of the chunk's one barrier: no staging registers (-40 VGPRs on the big tile), no ds_write pass between
@@ -133,7 +122,7 @@ struct ConvKParams {
 // on v_mfma_f32_32x32x16_bf16 -- products exact, fp32 accumulate.  The three dropped products (mid*lo, lo*mid, lo*lo) are
 // <= 2^-23 |a*b|, i.e. below the rounding of the fp32 accumulation itself: the result carries fp32-level error (measured
 // against an fp64 convolution in tests/test_gpu_parity.py next to the fp32-MFMA path) at 16/6 = 2.7x the fp32-MFMA rate.
-// Unlike the x3 mode the split happens ONCE, when a chunk is staged: LDS holds three bf16 planes of the input tile with the
+// The split happens ONCE, when a chunk is staged: LDS holds three bf16 planes of the input tile with the
 // channels interleaved in PAIRS (one 32-bit word = the same position of channels 2p and 2p+1), so a lane's 8 k-values of a
 // k-group are four ds_read_b32 per plane and the k-loop is ds_read + MFMA only.  Weights arrive pre-split; their slab is
 // staged in two k-group phases that ping-pong with the MFMA stream (phase A's slots are refilled for the next chunk while
@@ -144,8 +133,9 @@ struct ConvCfg {
     // X6 = the split-staged path (operands split once, when a chunk is staged): BF_ 2 = bf16x6 (three bf16 planes, six products),
     // BF_ 3 = f16x3 (two fp16 planes of the SCALED operand, three products)
     static constexpr bool PIPE = PIPE_, BF = BF_ != 0, X6 = BF_ >= 2, F16 = BF_ == 3, DB = DB_, FLAT = PMAX_ > 0, GL = GL_;
+    static_assert(BF_ == 0 || BF_ == 2 || BF_ == 3, "precision: 0 fp32-input MFMA, 2 bf16x6, 3 f16x3");
     static constexpr int NPL = BF_ == 2 ? 3 : (BF_ == 3 ? SS_F16_WPLANES : 2);   // 16-bit planes of the staged weights (f16x3: hi, lo [, hi * 2^-11])
-    static constexpr int NPA = BF_ >= 2 ? 3 : 2;                        // A operands of a k-group step
+    static constexpr int NPA = 3;                                       // A operands of a k-group step
     static constexpr int NPX = BF_ == 2 ? 3 : 2;                        // 16-bit planes of the staged input tile (f16x3: hi, lo * 2^11)
     static constexpr int NPROD = BF_ == 2 ? 6 : 3;                      // MFMAs per (A fragment, B fragment) pair
     static constexpr int PMAX = PMAX_;
@@ -163,31 +153,29 @@ struct ConvCfg {
     static constexpr int IN_PAIR_STRIDE = PMAX_ > 0 ? KT * (WN_ * NI_ * 32 + 2 * PMAX_ + 8) : KT * RH * XP;   // X6: words of one channel pair of one plane (flat: KT runs of FL)
     static constexpr int IN_PLANE_STRIDE = (CK / 2) * IN_PAIR_STRIDE;   // X6: words of one bf16 plane
     static constexpr int IN_FLOATS = X6 ? NPX * IN_PLANE_STRIDE : CK * IN_CH_STRIDE;
-    // bf16x3 grouping: taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
+    // k-groups of 16 (split-staged modes): taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
     static constexpr int TPG = TAPS >= 27 ? 4 : (TAPS >= 9 ? 2 : 1);
     static constexpr int CPH = 8 / TPG;
     static constexpr int NTG = (TAPS + TPG - 1) / TPG;                  // tap groups
     static constexpr int NCG = BF ? CK / (2 * CPH) : 1;                 // channel groups per chunk
     static constexpr int G = NTG * NCG;                                 // 16-wide k-groups per chunk
-    static constexpr int W_FLOATS = BF ? NPL * G * 2 * MT * 4 : CK * TAPS * MT;   // bf16x3: [hi|lo][G][half][MT] x 16 B; x6: [G][hi|mid|lo][half][MT]
+    static constexpr int W_FLOATS = BF ? NPL * G * 2 * MT * 4 : CK * TAPS * MT;   // split-staged: [G][plane][half][MT] x 16 B
     static constexpr int GA = (G + 1) / 2;                              // X6: k-groups of weight phase A (phase B: the rest)
     // X6 weight staging of tiles with few k-groups per chunk (1x1 taps; a phase's MFMA stream is shorter than a global load):
     // 0 two phases, registers refilled per phase; 1 one phase, whole slab in registers; 2 two phases, one chunk of lookahead
     static constexpr int WMODE = (BF_ >= 2 && G <= 2) ? (SS_X6_WMODE_SMALLG >= 0 ? SS_X6_WMODE_SMALLG : (BF_ == 3 ? 1 : ((WM * WN >= 8 || MI * NI < 8) ? 2 : 0))) : 0;
     // (bf16x6, 128 co x 256 voxels on four waves: the second register set of mode 2 spills)
     static constexpr bool SP = WMODE == 1, LA = WMODE == 2;
-    // split-staged tiles keep TWO input tiles where LDS allows (160 KB for a lone eight-wave workgroup, 80 KB for two four-wave ones):
-    // the next chunk's tile is split and written into the idle one between the MFMAs of the running chunk instead of between barriers
-    static constexpr bool INDB = X6 && SS_X6_INDB && (2 * IN_FLOATS + W_FLOATS) * 4 <= ((WM * WN >= 8 || MI * NI > 8) ? 160 : 80) * 1024;
-    static constexpr int IN_ALL = IN_FLOATS * (INDB ? 2 : 1);
+    static constexpr int IN_ALL = IN_FLOATS;
     static constexpr int BUF_FLOATS = IN_ALL + W_FLOATS;
     static constexpr int LDS_FLOATS = BUF_FLOATS * (DB ? 2 : 1);
-    static_assert(!BF || CK % (2 * CPH) == 0, "bf16x3: chunk must hold whole k-groups");
+    static_assert(!BF || CK % (2 * CPH) == 0, "split-staged: a chunk holds whole k-groups");
     static_assert(NSEG % COLS == 0, "segments must fill whole rows");
-    static_assert(CK % 4 == 0 || (DB && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (DB)");
+    static_assert(CK % 4 == 0 || (DB && GL_ && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (GL)");
     static_assert(LDS_FLOATS * 4 <= (X6 ? 160 : 80) * 1024, "two workgroups per CU (x6 eight-wave tiles: one)");
     static_assert(!X6 || (!DB && !GL && G >= 2 && CK % 2 == 0), "x6: 2-D / 3-D tiles, two weight phases");
-    static_assert(!FLAT || ((!BF || X6) && (!DB || GL) && KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: 3x3 taps, fp32 or split-staged");
+    static_assert(!FLAT || (KH == 3 && KW == 3 && PMAX % 4 == 0), "flat tiles: 3x3 taps");
+    static_assert(DB == GL_, "two LDS buffers are the direct-to-LDS form");
     static_assert(!GL || (DB && !BF), "direct-to-LDS staging is the double-buffered fp32 form");
     // workgroups per CU the register allocator must leave room for: the GL forms carry no staging registers, so the tiles whose
     // two LDS buffers fit three times into the CU's 160 KB are held to 168 VGPRs (3 waves per SIMD instead of 2)
@@ -256,12 +244,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                             : in_lds + half * C::IN_CH_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
     }
 
-    const float* b_ptr_bf[C::NI];      // bf16x3: lane half h owns channels [h*CPH, (h+1)*CPH) of every k-group
-#pragma unroll
-    for (int ni = 0; ni < C::NI; ++ni) {
-        const int s = wn * C::NI + ni;
-        b_ptr_bf[ni] = in_lds + half * (C::CPH * C::IN_CH_STRIDE) + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
-    }
     const unsigned int* b_ptr6[C::NI];  // x6: word (channel pair) planes; lane half h owns the pairs [h*CPH/2, (h+1)*CPH/2) of every k-group
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
@@ -276,7 +258,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     constexpr int XQ = C::XP / 4;
     constexpr int NQ = C::FLAT ? C::IN_FLOATS / 4 : C::CK * C::KT * C::RH * XQ;   // 16-B pieces of the input halo tile
     constexpr int MQ = C::MT / 4;
-    constexpr int NWQ = C::BF ? 2 * C::G * 2 * C::MT : C::CK * C::TAPS * MQ;   // 16-B pieces of the weight slab
+    constexpr int NWQ = C::BF ? C::NPL * C::G * 2 * C::MT : C::CK * C::TAPS * MQ;   // 16-B pieces of the weight slab
     constexpr int IN_PT = (NQ + C::NTHREADS - 1) / C::NTHREADS, W_PT = (NWQ + C::NTHREADS - 1) / C::NTHREADS;
     auto fetch_in = [&](int c0, int q) -> float4 {            // piece q of the input tile for chunk c0 (vec4 layout)
         if constexpr (C::FLAT) {                              // [c][dt][FL]: flat run of the plane from F0 - pitch - 4
@@ -302,15 +284,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         return v;
     };
     auto fetch_w = [&](int c0, int q) -> float4 {             // rows (sub, tap, c4) x MT output channels
-        if constexpr (C::BF) {                                // piece q = ((hl*G + grp)*2 + half)*MT + co : 8 bf16 of one channel
-            const int col = q % C::MT, r = q / C::MT;
-            const int hl = r / (2 * C::G), gh = r - hl * (2 * C::G);
-            const float4* wsrc = reinterpret_cast<const float4*>(p.wpk) +
-                                 ((int64_t)((c0 / C::CK) * 2 + hl) * (2 * C::G) + gh) * p.Cout + co0 + col;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 < p.Cin && co0 + col < p.Cout) v = *wsrc;
-            return v;
-        }
         const int mq = q % MQ;
         if constexpr (C::CK == 2) {                           // one channel pair: LDS rows (tap, e) <- packed rows (tap, cp*2 + e)
             const int row2 = q / MQ, tap = row2 >> 1, e = row2 & 1;
@@ -474,32 +447,31 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         v0 = *reinterpret_cast<const f32x4*>(base + (c0 < in6_clim[k] ? in6_voff[k] : 0u));
         v1 = *reinterpret_cast<const f32x4*>(base + (c0 + 1 < in6_clim[k] ? in6_voff[k] + cs4 : 0u));
     };
-    int ibuf = 0;                                                    // INDB: word offset of the input tile the MFMA stream reads (0 or IN_FLOATS)
-    auto store_in6 = [&](int q, const float4& v0, const float4& v1, const int wbuf = 0) { // split both channels, interleave, 16-B stores into the tile at word offset wbuf
+    auto store_in6 = [&](int q, const float4& v0, const float4& v1) { // split both channels, interleave, 16-B stores into the tile
         unsigned int h0, m0, l0, h1, m1, l1;
         uint4 ph, pm, pl;
         split3(v0.x, h0, m0, l0); split3(v1.x, h1, m1, l1); ph.x = h0 | (h1 << 16); pm.x = m0 | (m1 << 16); pl.x = l0 | (l1 << 16);
         split3(v0.y, h0, m0, l0); split3(v1.y, h1, m1, l1); ph.y = h0 | (h1 << 16); pm.y = m0 | (m1 << 16); pl.y = l0 | (l1 << 16);
         split3(v0.z, h0, m0, l0); split3(v1.z, h1, m1, l1); ph.z = h0 | (h1 << 16); pm.z = m0 | (m1 << 16); pl.z = l0 | (l1 << 16);
         split3(v0.w, h0, m0, l0); split3(v1.w, h1, m1, l1); ph.w = h0 | (h1 << 16); pm.w = m0 | (m1 << 16); pl.w = l0 | (l1 << 16);
-        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + wbuf + q * 4;
+        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
         *reinterpret_cast<uint4*>(d) = ph;
         *reinterpret_cast<uint4*>(d + C::IN_PLANE_STRIDE) = pm;
         if constexpr (C::NPX == 3) *reinterpret_cast<uint4*>(d + 2 * C::IN_PLANE_STRIDE) = pl;
     };
-    auto store_in6_masked = [&](int c0, int k, const f32x4& r0, const f32x4& r1, const int wbuf = 0) __attribute__((always_inline)) {
+    auto store_in6_masked = [&](int c0, int k, const f32x4& r0, const f32x4& r1) __attribute__((always_inline)) {
         const bool ok0 = c0 < in6_clim[k], ok1 = c0 + 1 < in6_clim[k];
         float4 v0, v1;
         v0.x = ok0 ? r0.x : 0.f; v0.y = ok0 ? r0.y : 0.f; v0.z = ok0 ? r0.z : 0.f; v0.w = ok0 ? r0.w : 0.f;
         v1.x = ok1 ? r1.x : 0.f; v1.y = ok1 ? r1.y : 0.f; v1.z = ok1 ? r1.z : 0.f; v1.w = ok1 ? r1.w : 0.f;
-        store_in6(tid + k * C::NTHREADS, v0, v1, wbuf);
+        store_in6(tid + k * C::NTHREADS, v0, v1);
     };
-    auto stage_in6_direct = [&](int c0, const int wbuf = 0) {        // global -> split -> LDS without overlap (prologue, odd strides)
+    auto stage_in6_direct = [&](int c0) {        // global -> split -> LDS without overlap (prologue, odd strides)
         if (p.vec4) {
             for (int q = tid; q < NQ6; q += C::NTHREADS) {
                 float4 v0, v1;
                 fetch_in6(c0, q, v0, v1);
-                store_in6(q, v0, v1, wbuf);
+                store_in6(q, v0, v1);
             }
         } else if constexpr (!C::FLAT) {                              // (flat tiles are only launched on 16-B aligned volumes)
             constexpr int NE6 = (C::CK / 2) * C::KT * C::RH * C::XP;     // one word (pair, position) per iteration
@@ -518,7 +490,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 unsigned int h0, m0, l0, h1, m1, l1;
                 split3(a0, h0, m0, l0);
                 split3(a1, h1, m1, l1);
-                unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + wbuf + q;
+                unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q;
                 d[0] = h0 | (h1 << 16);
                 d[C::IN_PLANE_STRIDE] = m0 | (m1 << 16);
                 if constexpr (C::NPX == 3) d[2 * C::IN_PLANE_STRIDE] = l0 | (l1 << 16);
@@ -633,45 +605,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     };
     // ---- MFMA stream over one staged chunk: every tap is a shifted LDS read ------------------------------
     auto compute = [&](const int buf_off = 0) {
-        if constexpr (C::BF) {
-            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-            const char* a_base = reinterpret_cast<const char*>(w_lds) + (half * C::MT + wm * (C::MI * 32) + l31) * 16;
-            constexpr int HL_BYTES = C::G * 2 * C::MT * 16;   // offset of the lo planes
-#pragma unroll
-            for (int grp = 0; grp < C::G; ++grp) {
-                const int cg = grp / C::NTG, tg = grp % C::NTG;
-                bf16x8 ah[C::MI], al[C::MI], bh[C::NI], bl[C::NI];
-#pragma unroll
-                for (int mi = 0; mi < C::MI; ++mi) {
-                    ah[mi] = *reinterpret_cast<const bf16x8*>(a_base + ((grp * 2) * C::MT + mi * 32) * 16);
-                    al[mi] = *reinterpret_cast<const bf16x8*>(a_base + HL_BYTES + ((grp * 2) * C::MT + mi * 32) * 16);
-                }
-#pragma unroll
-                for (int ni = 0; ni < C::NI; ++ni) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int tapi = j / C::CPH, chl = j % C::CPH;
-                        int tap = tg * C::TPG + tapi;
-                        tap = tap < C::TAPS ? tap : C::TAPS - 1;       // padded taps: any valid address (their weights are zero)
-                        const int dt = tap / (C::KH * C::KW), dy = (tap / C::KW) % C::KH, dx = tap % C::KW;
-                        const int off = (cg * 2 * C::CPH + chl) * C::IN_CH_STRIDE + (dt * C::RH + dy) * C::XP + dx;
-                        const float x = b_ptr_bf[ni][off];
-                        const __bf16 hi = (__bf16)x;
-                        bh[ni][j] = hi;
-                        bl[ni][j] = (__bf16)(x - (float)hi);
-                    }
-                }
-#pragma unroll
-                for (int mi = 0; mi < C::MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < C::NI; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    }
-            }
-            return;
-        }
         constexpr int NSUB = C::CK >= 4 ? C::CK / 4 : 1, NCP = C::CK >= 4 ? 2 : 1, WROWS = C::CK >= 4 ? 4 : 2;
         const float* bdy[C::NI][3];                           // FLAT: row dy of the taps = + dy * pitch (runtime), rest immediates
         if constexpr (C::FLAT) {
@@ -743,33 +676,18 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     #pragma unroll
             for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if ((k + 1) * C::NTHREADS <= q1 - q0 || (k * C::NTHREADS < q1 - q0 && q < q1)) *reinterpret_cast<f32x4*>(w_lds + q * 4) = r[k]; }
         };
-        // the tile the next chunk's input goes to: the idle one of two (INDB), else the only one (then only between barriers)
+        // the next chunk's input tile, written between barriers (the one tile is what the MFMA stream reads)
         auto store_in6_all = [&](int c0) __attribute__((always_inline)) {
-            const int wbuf = C::INDB ? C::IN_FLOATS - ibuf : 0;
             if (p.vec4) {
-                if constexpr (!C::INDB) {
 #pragma unroll
-                    for (int k = 0; k < IN_PT6; ++k) {
-                        const int q = tid + k * C::NTHREADS;
-                        if ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1], wbuf);
-                    }
+                for (int k = 0; k < IN_PT6; ++k) {
+                    const int q = tid + k * C::NTHREADS;
+                    if ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1]);
                 }
-            } else stage_in6_direct(c0, wbuf);
-        };
-        auto store_in6_k = [&](int c0, const int k) __attribute__((always_inline)) {      // INDB: piece k, inside the MFMA stream
-            const int q = tid + k * C::NTHREADS;
-            if (p.vec4 && ((k + 1) * C::NTHREADS <= NQ6 || q < NQ6)) store_in6_masked(c0, k, rin[2 * k], rin[2 * k + 1], C::IN_FLOATS - ibuf);
-        };
-        auto swap_in6 = [&]() __attribute__((always_inline)) {
-            if constexpr (C::INDB) {
-                const int nb = C::IN_FLOATS - ibuf;
-#pragma unroll
-                for (int ni = 0; ni < C::NI; ++ni) b_ptr6[ni] += nb - ibuf;
-                ibuf = nb;
-            }
+            } else stage_in6_direct(c0);
         };
         // side work of one phase, spread over its (k-group, mi) steps: global loads of the next chunk (input-tile piece pairs, then
-        // weight pieces) over the steps [0, NL), then (INDB) the split + LDS writes of the input pieces over the steps [NL, NS)
+        // weight pieces) over the steps [0, NL)
         auto side_items = [&](const int st, auto nspread_c, auto n_in_c, auto n_w_c, auto&& f_in, auto&& f_w) __attribute__((always_inline)) {
             constexpr int nspread = decltype(nspread_c)::value, n_in = decltype(n_in_c)::value, n_w = decltype(n_w_c)::value, n = n_in + n_w;
             if (st >= nspread || st < 0) return;
@@ -797,16 +715,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         typedef std::true_type Yes;
         typedef std::false_type No;
         auto f_in_at = [&](const int cn) { return [&, cn](const int k) __attribute__((always_inline)) { if (p.vec4) fetch_in6_fast(cn, k, rin[2 * k], rin[2 * k + 1]); }; };
-        // INDB: the input pieces are split and written over the LAST steps of the chunk's last phase (their loads went out in its first)
-        auto in_stores = [&](const int st, const int ns, const int cn) __attribute__((always_inline)) {
-            if constexpr (C::INDB) {
-                constexpr int n = IN_PT6;
-                const int s0 = ns - min(ns, n);                        // one piece per step over the last min(ns, n) steps; the rest at the last one
-#pragma unroll
-                for (int k = 0; k < n; ++k)
-                    if (st == min(s0 + k, ns - 1)) store_in6_k(cn, k);
-            }
-        };
         if constexpr (C::SP) {
             // few k-groups per chunk (1x1 taps): one phase; the whole next chunk (weights + input tile) gathers in registers under
             // the chunk's MFMA stream.  Two barriers per chunk.
@@ -817,7 +725,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     if constexpr (more) {
                         side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, INc{}, std::integral_constant<int, NPALL>{}, f_in_at(cn),
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
-                        in_stores(st, NSALL, cn);
                     }
                 });
                 __syncthreads();
@@ -825,7 +732,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     store_w6(Q0{}, QE{}, rw6);
                     store_in6_all(cn);
                     __syncthreads();
-                    swap_in6();
                 }
             };
             int c0 = c_begin;
@@ -851,14 +757,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPA>{}, [](const int) {},
                                           [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cnn, Q0{}, QA{}, rw6, k); });
-                    if constexpr (more) in_stores(st, NSB, cn);
                 });
                 __syncthreads();
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6b);
                     store_in6_all(cn);
                     __syncthreads();
-                    swap_in6();
                 }
             };
             int c0 = c_begin;
@@ -882,7 +786,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     if constexpr (more) {
                         side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPB>{}, [](const int) {},
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
-                        in_stores(st, NSB, cn);
                     }
                 });
                 __syncthreads();                                   // everyone is done with phase B's slots and this chunk's input tile
@@ -890,7 +793,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     store_w6(QA{}, QE{}, rw6);
                     store_in6_all(cn);
                     __syncthreads();
-                    swap_in6();
                 }
             };
             int c0 = c_begin;
@@ -929,37 +831,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             cur = C::BUF_FLOATS - cur;
-            __syncthreads();
-        }
-    } else if constexpr (C::DB) {
-        // double-buffered LDS (launcher guarantees vec4): prefetch chunk i+1 into registers, run chunk i's MFMA stream from
-        // buffer i % 2, write the registers to the other buffer, ONE barrier per chunk
-        float4 rin[IN_PT], rw[W_PT];
-        auto fetch_regs = [&](int c0) {
-#pragma unroll
-            for (int k = 0; k < IN_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ) rin[k] = fetch_in(c0, q); }
-#pragma unroll
-            for (int k = 0; k < W_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NWQ) rw[k] = fetch_w(c0, q); }
-        };
-        auto regs_to_lds = [&](const int off) {
-#pragma unroll
-            for (int k = 0; k < IN_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NQ) *reinterpret_cast<float4*>(in_lds + off + q * 4) = rin[k]; }
-#pragma unroll
-            for (int k = 0; k < W_PT; ++k) { const int q = tid + k * C::NTHREADS; if (q < NWQ) *reinterpret_cast<float4*>(w_lds + off + q * 4) = rw[k]; }
-        };
-        if (c_begin < c_end) {
-            fetch_regs(c_begin);
-            regs_to_lds(0);
-        }
-        __syncthreads();
-        int cur = 0;                                          // float offset of the buffer being read
-        for (int c0 = c_begin; c0 < c_end; c0 += C::CK) {
-            const bool more = c0 + C::CK < c_end;
-            if (more) fetch_regs(c0 + C::CK);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(cur);
-            cur = C::BUF_FLOATS - cur;
-            if (more) regs_to_lds(cur);
             __syncthreads();
         }
     } else if (C::PIPE && p.vec4) {
@@ -1268,43 +1139,9 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-// bf16x3 packing: [Cout][Cin][taps] fp32 -> per chunk [hi|lo][G][half][Cout][8 bf16]; element j of (grp, half) is
-// channel cg*2*CPH + half*CPH + j % CPH of the chunk, tap tg*TPG + j / CPH (zero beyond the last tap / channel)
-__global__ void pack_conv_weight_bf16x3_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int Cin, int taps,
-                                                int CK, int TPG) {
-    const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
-    const int nchunks = (Cin + CK - 1) / CK;
-    const int64_t n = (int64_t)nchunks * 2 * G * 2 * Cout;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        int64_t r = i / Cout;
-        const int h = (int)(r & 1);
-        r >>= 1;
-        const int grp = (int)(r % G);
-        r /= G;
-        const int hl = (int)(r & 1);
-        const int chunk = (int)(r >> 1);
-        const int cg = grp / NTG, tg = grp % NTG;
-        unsigned short v[8];
-        for (int j = 0; j < 8; ++j) {
-            const int tapi = j / CPH, chl = j % CPH;
-            const int tap = tg * TPG + tapi, ci = chunk * CK + cg * 2 * CPH + h * CPH + chl;
-            float x = 0.f;
-            if (tap < taps && ci < Cin) x = w[((int64_t)co * Cin + ci) * taps + tap];
-            const __bf16 hi = (__bf16)x;
-            const __bf16 lo = (__bf16)(x - (float)hi);
-            const __bf16 pick = hl ? lo : hi;
-            v[j] = *reinterpret_cast<const unsigned short*>(&pick);
-        }
-        uint4 o;
-        o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
-        o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
-        packed[i] = o;
-    }
-}
-
-// bf16x6 packing: [Cout][Cin][taps] fp32 -> per chunk [G][hi|mid|lo][half][Cout][8 bf16] (same k-group element order as bf16x3;
-// group-major so that a weight PHASE -- a run of k-groups -- is one contiguous LDS image)
+// bf16x6 packing: [Cout][Cin][taps] fp32 -> per chunk [G][hi|mid|lo][half][Cout][8 bf16]; element j of (grp, half) is channel
+// cg*2*CPH + half*CPH + j % CPH of the chunk, tap tg*TPG + j / CPH (zero beyond the last tap / channel); group-major so that a
+// weight PHASE -- a run of k-groups -- is one contiguous LDS image
 __global__ void pack_conv_weight_bf16x6_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout, int Cin, int taps,
                                                 int CK, int TPG) {
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH), G = NTG * NCG;
@@ -1406,69 +1243,32 @@ __global__ void pack_conv_weight_f16x3_kernel(const float* __restrict__ w, uint4
 
 // tile shapes --------------------------------------------------------------------------------------
 //                       KT KH KW  CK  MI NI WM WN COLS
-using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;   // 128 co x (8 rows x 32 cols)
-using K3BigDB = ConvCfg<3, 3, 3, 2, 4, 2, 1, 4, 1, false, false, true>;   // same tile, 2-channel chunks, double-buffered LDS
-// (measured: the double-buffered form only pays for this tile -- the smaller 3x3x3 tiles and the 2-D tiles already prefetch
-// through registers (PIPE); their DB twins were 2-9 % slower: more registers, fewer resident workgroups)
-using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
-using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
-using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, true>;  // 128 co x 256 voxels
+// fp32-input MFMA mode (STEMSEG_PRECISION_F32)
+using K3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1>;          // 128 co x (8 rows x 32 cols): the big tile's generic form (unaligned volumes, Cout % 128 != 0)
+using K3BigGL = ConvCfg<3, 3, 3, 2, 4, 2, 1, 4, 1, false, 0, true, 0, true>;   // same tile, 2-channel chunks, two LDS buffers filled by LDS-DMA
+using K3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true>;    // 128 co x (4 rows x 32 cols)
+using K3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true>;  // 128 co x (2 rows x 32 cols)
+using K1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, true>;   // 128 co x 256 voxels
 using K1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, true>; // 128 co x 128 voxels
-using K1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, true>;  //  64 co x 256 voxels
+using K1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, true>;   //  64 co x 256 voxels
+using K1BigGL = ConvCfg<1, 1, 1, 16, 4, 2, 1, 4, 8, false, 0, true, 0, true>;     // direct-to-LDS twins of the 1x1 tiles (half the chunk: two buffers in the same LDS)
+using K1SmallGL = ConvCfg<1, 1, 1, 16, 2, 2, 2, 2, 4, false, 0, true, 0, true>;
+using K1M64GL = ConvCfg<1, 1, 1, 16, 2, 2, 1, 4, 8, false, 0, true, 0, true>;
 // 2-D convolutions of the encoder: the frames of a clip are the T axis, KT = 1
-using K2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, true>;   // 128 co x (8 rows x 32 cols)
-using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true>;   // 128 co x (4 rows x 32 cols)
-using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true>; // 128 co x (2 rows x 32 cols)
-using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true>;   //  64 co x (8 rows x 32 cols)
-
-// flat-tile forms for maps whose width wastes >= 10 % of a 32-column tile (8x / 16x maps: pitch 112 / 56)
-using K2FlatBig = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, false, false, 112>;   // 128 co x 256 flat positions
-using K2FlatMed = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, false, false, 112>;   // 128 co x 128
-using K3FlatMed = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 112>;   // 128 co x 128
-using K3FlatSmall = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 112>; // 128 co x 64
-// (pitch <= 56: 16x maps -- the staged run is tile + 2 * PMAX + 8 floats per channel plane, so a tighter PMAX stages less)
-using K2FlatBig56 = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, false, false, 56>;
-// 224-position twins (7 segments: 4 waves x 32 channels, each across all 7): chosen when they divide the launch into fewer
-// rounds of the chip than the 256-position tile (a 16x plane of 32 x 56 positions = exactly 8 such tiles; 32 frames x 2
-// channel tiles = 512 workgroups = two per CU, where the 256-position tile gives 448 = 1.75 per CU -> two uneven rounds)
-using K2Flat7_56 = ConvCfg<1, 3, 3, 8, 1, 7, 4, 1, 7, true, false, false, 56>;
-using K1N7 = ConvCfg<1, 1, 1, 32, 1, 7, 4, 1, 7, true>;                              // 128 co x 224 voxels
-using K1N7GL = ConvCfg<1, 1, 1, 16, 1, 7, 4, 1, 7, false, false, true, 0, true>;
-using K2FlatMed56 = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, false, false, 56>;
-using K3FlatMed56 = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, false, false, 56>;
-using K3FlatSmall56 = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, false, false, 56>;
-
-// direct-to-LDS twins (double-buffered, half the channel chunk so the two buffers fit the same LDS budget as the register-
-// staged form they replace); STEMSEG_GLDS is a bit mask: 1 = big 3x3x3 tile, 2 = other 3x3x3 tiles, 4 = 1x3x3 tiles (0 = off)
-using K3BigGL = ConvCfg<3, 3, 3, 2, 4, 2, 1, 4, 1, false, false, true, 0, true>;
-using K3MedGL = ConvCfg<3, 3, 3, 2, 2, 2, 2, 2, 1, false, false, true, 0, true>;
-using K3SmallGL = ConvCfg<3, 3, 3, 2, 2, 1, 2, 2, 1, false, false, true, 0, true>;
-using K3FlatMedGL = ConvCfg<3, 3, 3, 2, 2, 2, 2, 2, 4, false, false, true, 112, true>;
-using K3FlatSmallGL = ConvCfg<3, 3, 3, 2, 2, 1, 2, 2, 2, false, false, true, 112, true>;
-using K3FlatMed56GL = ConvCfg<3, 3, 3, 2, 2, 2, 2, 2, 4, false, false, true, 56, true>;
-using K3FlatSmall56GL = ConvCfg<3, 3, 3, 2, 2, 1, 2, 2, 2, false, false, true, 56, true>;
-using K2BigGL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 1, false, false, true, 0, true>;
-using K2MedGL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 1, false, false, true, 0, true>;
-using K2SmallGL = ConvCfg<1, 3, 3, 4, 2, 1, 2, 2, 1, false, false, true, 0, true>;
-using K2FlatBigGL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 8, false, false, true, 112, true>;
-using K2FlatMedGL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 4, false, false, true, 112, true>;
-using K2FlatBig56GL = ConvCfg<1, 3, 3, 4, 4, 2, 1, 4, 8, false, false, true, 56, true>;
-using K2FlatMed56GL = ConvCfg<1, 3, 3, 4, 2, 2, 2, 2, 4, false, false, true, 56, true>;
-using K1BigGL = ConvCfg<1, 1, 1, 16, 4, 2, 1, 4, 8, false, false, true, 0, true>;     // (STEMSEG_GLDS bit 8)
-using K1SmallGL = ConvCfg<1, 1, 1, 16, 2, 2, 2, 2, 4, false, false, true, 0, true>;
-using K1M64GL = ConvCfg<1, 1, 1, 16, 2, 2, 1, 4, 8, false, false, true, 0, true>;
-
-// bf16x3 twins of the tile shapes (register prefetch only where the wider fragments still fit 256 VGPRs)
-using X3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, true>;
-using X3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 1, true, true>;
-using X3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 1, true, true>;
-using X1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, true>;
-using X1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, true, true>;
-using X1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, true, true>;
-using X2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, false, true>;
-using X2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true, true>;
-using X2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true, true>;
-using X2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true, true>;
+using K2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, true>;    // 128 co x (8 rows x 32 cols)
+using K2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, true>;    // 128 co x (4 rows x 32 cols)
+using K2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, true>;  // 128 co x (2 rows x 32 cols)
+using K2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, true>;    //  64 co x (8 rows x 32 cols)
+// flat-tile forms for maps whose width wastes >= 10 % of a 32-column tile (8x / 16x maps: pitch 112 / 56; the staged run is
+// tile + 2 * PMAX + 8 floats per channel plane, so a tighter PMAX stages less)
+using K2FlatBig = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, 0, false, 112>;     // 128 co x 256 flat positions
+using K2FlatMed = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, 0, false, 112>;     // 128 co x 128
+using K3FlatMed = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, 0, false, 112>;     // 128 co x 128
+using K3FlatSmall = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, 0, false, 112>;   // 128 co x 64
+using K2FlatBig56 = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, true, 0, false, 56>;
+using K2FlatMed56 = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 4, true, 0, false, 56>;
+using K3FlatMed56 = ConvCfg<3, 3, 3, 4, 2, 2, 2, 2, 4, true, 0, false, 56>;
+using K3FlatSmall56 = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, 0, false, 56>;
 
 // Split-staged tiles (BFV 2 = bf16x6, 3 = f16x3).  3x3x3: eight waves share one weight slab (86 KB in bf16x6, 57 KB in f16x3; one
 // workgroup per CU, two waves per SIMD); 2-D and 1x1 tiles keep four-wave shapes (two workgroups per CU) except the big ones
@@ -1485,58 +1285,72 @@ struct SplitTiles {
     using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, BFV>; // 128 co x 128 voxels
     using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, BFV>;  //  64 co x 256 voxels
     using Y1Wide = ConvCfg<1, 1, 1, 32, 4, 2, 2, 4, 8, false, BFV>; // 256 co x 256 voxels, 512 threads: an input element is split once per 256 output channels
-    // flat (ragged-width) forms of the big tiles: 128 co x 512 flat positions of the zero-haloed plane (3-D: per t-plane) or of the whole
-    // [T][H + 2][pitch] run (2-D: across the frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
-    template <int PMAX> using Y3Flat = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
+    // flat (ragged-width) form of the big 2-D tile: 128 co x 512 flat positions of the whole [T][H + 2][pitch] run (across the
+    // frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
     template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
 };
 
-// sustained per-CU rate while the chip is full, for the launch cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
+// sustained per-CU rate while the chip is full, for the row planner's cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
 // MFMA peak)
 constexpr double CU_FLOPS_F32 = 0.46e12;
-constexpr double CU_FLOPS_X6 = 1.0e12;      // bf16x6: fp32-equivalent FLOP/s of one CU while its MFMA stream runs (first measurements)
-#ifndef STEMSEG_GLDS_DEFAULT
-#define STEMSEG_GLDS_DEFAULT 9
-#endif
+
+// A launch DECIDES (tile shape, split-K factor, row cut) on its planning shape and RUNS on its real one.  The two are the same
+// for a caller that gives no planning frames (the decoders: a clip is a clip).  The encoder's launches hold as many frames as the
+// caller batched -- one clip, four clips of a step, the union of eight overlapping windows -- and the K-partition of a split-K
+// launch is a summation order: decided on the real shape, the last bits of every embedding would depend on the batch, and a
+// world-N job would not reproduce the world-1 labels (clusterers.py:106-146 is a chain of hard thresholds).  So the encoder
+// plans every layer for `plan_frames` frames of its per-frame shape, whatever the launch holds.
+struct PlanCtx {
+    ConvKParams shape;           // the planning twin of the launch's parameters (T, or the flat voxel count, scaled to plan_frames)
+    int64_t scratch_floats;      // split-K scratch the plan may count on (the real scratch must then hold real / plan times that)
+};
+
+// workgroups tile shape C makes of shape d (flat_t: the flat run crosses the frames)
+template <class C>
+static int64_t cfg_workgroups(const ConvKParams& d, int flat_t) {
+    int64_t tx = C::FLAT ? ceil_div((int64_t)d.H * d.in_ys, C::NT) : ceil_div(d.W, C::COLS * 32);
+    const int64_t ty = C::FLAT ? 1 : ceil_div(d.H, C::ROWS);
+    int64_t T = d.T;
+    if (C::FLAT && flat_t) { tx = ceil_div((int64_t)d.T * d.in_ts, C::NT); T = 1; }
+    return tx * ty * T * ceil_div(d.Cout, C::MT);
+}
 
 template <class C>
-static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0) {
+static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0, const PlanCtx* plan = nullptr) {
     p.tiles_x = C::FLAT ? (int)ceil_div((int64_t)p.H * p.in_ys, C::NT) : (int)ceil_div(p.W, C::COLS * 32);
     p.tiles_y = C::FLAT ? 1 : (int)ceil_div(p.H, C::ROWS);
     p.T_all = p.T;
-    if (C::FLAT && p.flat_t) {                           // one run of flat positions over all frames: [T][H + 2][pitch]
+    const int flat_t = (C::FLAT && p.flat_t) ? 1 : 0;
+    if (flat_t) {                                        // one run of flat positions over all frames: [T][H + 2][pitch]
         p.tiles_x = (int)ceil_div((int64_t)p.T * p.in_ts, C::NT);
         p.T = 1;
-    } else p.flat_t = 0;
+    }
+    p.flat_t = flat_t;
     const int out_vec = p.vec_epi;                       // true output rows are 16-B aligned (decides the reduce kernel's form)
     if (C::FLAT) p.vec_epi = 0;
-    // split-K over the input-channel chunks when the layer alone cannot give every CU two workgroups
+    // split-K over the input-channel chunks when the layer alone cannot fill the chip: split until the PLANNED launch holds ~2.5
+    // workgroups per CU for the tiles that share a CU, ~1.25 for the eight-wave split-staged tiles that own one (256 workgroups of
+    // those already fill the chip: splitting them only adds slab traffic -- measured, L3 conv2)
     const int nchunks = (int)ceil_div(p.Cin, C::CK);
-    const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * p.T * ceil_div(p.Cout, C::MT);
     const int64_t slab = (int64_t)p.Cout * p.T_all * p.H * p.W;
     int ksplit = 1;
-    // split until the launch holds ~2.5 workgroups per CU for the tiles that share a CU, ~1.25 for the eight-wave split-staged tiles
-    // that own one (256 workgroups of those already fill the chip: splitting them only adds slab traffic -- measured, L3 conv2)
-    static const int wg_target_env = [] { const char* e = getenv("STEMSEG_SPLITK_WGS"); return e ? atoi(e) : 0; }();
-    const int64_t wg_target = wg_target_env > 0 ? wg_target_env : ((C::X6 && C::NWAVES >= 8) ? 320 : 640);
-    while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= wg_target && slab * ksplit * 2 <= scratch_floats) ksplit *= 2;
-    // uneven rounds (STEMSEG_AUTOSPLIT=1, off by default until measured): a launch of a few hundred long-running 3x3(x3)
-    // workgroups -- 424 on 256 CUs = two rounds for 1.66 rounds of work -- splits K by the k in {2, 3, 4} whose
-    // ceil(workgroups * k / 256) / k rounds, plus the slab round trip at ~4 TB/s, beat the plain launch by > 7 %
-    static const bool autosplit = [] { const char* e = getenv("STEMSEG_AUTOSPLIT"); return e && e[0] == '1'; }();
-    if (autosplit && force_ksplit == 0 && ksplit == 1 && scratch && C::TAPS > 1 && wgs > 256 && wgs <= 1024) {
-        const double t_wg = 2.0 * C::MT * C::NT * (double)p.Cin * C::TAPS / CU_FLOPS_F32;        // one workgroup alone on a CU
-        double best = (double)ceil_div(wgs, 256) * t_wg;
-        const double plain = best;
-        for (int k = 2; k <= 4; ++k) {
-            if (k * 4 > nchunks || (int64_t)k * slab > scratch_floats) continue;
-            const double t = (double)ceil_div(wgs * k, 256) * t_wg / k + 2.0 * k * slab * 4.0 / 4.0e12 + 6e-6;
-            if (t < 0.93 * plain && t < best) { best = t; ksplit = k; }
-        }
+    {
+        const ConvKParams& d = plan ? plan->shape : p;
+        const int64_t d_T = plan ? d.T : p.T_all;
+        ConvKParams dd = d;
+        dd.T = (int)d_T;
+        const int64_t wgs = cfg_workgroups<C>(dd, flat_t);
+        const int64_t slab_plan = (int64_t)d.Cout * d_T * d.H * d.W;
+        const int64_t plan_scratch = plan ? plan->scratch_floats : scratch_floats;
+        const int64_t wg_target = (C::X6 && C::NWAVES >= 8) ? 320 : 640;
+        while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= wg_target && slab_plan * ksplit * 2 <= plan_scratch) ksplit *= 2;
     }
     if (force_ksplit > 0) ksplit = (scratch && (int64_t)force_ksplit * slab <= scratch_floats) ? std::min(force_ksplit, nchunks) : 1;
     p.chunks_per_split = (int)ceil_div(nchunks, ksplit);
     ksplit = (int)ceil_div(nchunks, p.chunks_per_split);
+    // (a planned launch never shrinks its K-partition to fit: that would be a batch-dependent summation order again)
+    SS_CHECK_ARG(ksplit == 1 || (int64_t)ksplit * slab <= scratch_floats, "conv3d: split-K scratch too small (%lld floats needed, %lld given)",
+                 (long long)((int64_t)ksplit * slab), (long long)scratch_floats);
     SplitReduceParams rp;
     // 16-B reduce: the true output (and residual) rows are aligned (vec_epi as computed by the caller) and W % 4 == 0
     const bool rp_vec = out_vec && p.dec_W == 0 && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) && (slab % 4 == 0);
@@ -1581,36 +1395,34 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     return STEMSEG_OK;
 }
 
-// Tail balancing for launches of a few big workgroups per CU.  An MFMA-bound CU works through its workgroups at a fixed
-// rate, so a launch costs ceil(workgroups / 256) "units"; 840 workgroups (block_4x at 480p) cost 4 units for 3.28 units of
-// work.  Here the output rows are cut in two: the first nA row-tiles run whole (a multiple of 256 workgroups, or close),
-// the remaining rows run split-K by k with the deterministic slab reduce, which cuts their units into k-ths:
+// Tail balancing for launches of a few big workgroups per CU (fp32-input mode).  An MFMA-bound CU works through its workgroups
+// at a fixed rate, so a launch costs ceil(workgroups / 256) "units"; 840 workgroups (block_4x at 480p) cost 4 units for 3.28
+// units of work.  Here the output rows are cut in two: the first nA row-tiles run whole (a multiple of 256 workgroups, or
+// close), the remaining rows run split-K by k with the deterministic slab reduce, which cuts their units into k-ths:
 // 504 + 3 x 336 workgroups cost 2 + 4/3 = 3.33 units.  The split is chosen by a cost model (units x time per unit +
 // slab traffic) and only taken when it beats the plain launch by > 3 %.  Sub-launches are ordinary launches on row
 // sub-volumes (pointer offsets), so results are bit-identical to the plain launch wherever k = 1 and equal to a plain
-// split-K launch elsewhere (fixed summation order).
+// split-K launch elsewhere (fixed summation order).  The cut is in rows of the FRAME, so it does not depend on the frame count
+// of the launch once it is decided on the planning shape.
 struct RowPlan { double cost; int nA, k; };
 
-// Cost of the best (whole rows, split-K rows) cut for tile shape C: rounds x time per round + slab traffic.  `occ`
+// Cost of the best (whole rows, split-K rows) cut for tile shape C on shape d: rounds x time per round + slab traffic.  `occ`
 // workgroups share a CU (LDS-limited), so the chip has 256 * occ slots and one round of co-resident workgroups takes
 // occ x (flops per workgroup / sustained per-CU rate x eff); eff = relative MFMA efficiency of the tile shape
 // (measured with tools/conv_sweep.py: 4-row tiles reach 0.92 of the 8-row tile's rate).
 template <class C>
-static RowPlan plan_rows(const ConvKParams& p0, bool have_scratch, int64_t scratch_floats, double cu_flops, int occ, double eff) {
+static RowPlan plan_rows(const ConvKParams& d, bool have_scratch, int64_t scratch_floats, double cu_flops, int occ, double eff) {
     const int64_t slots = 256 * occ;
-    // 1x1 convs see their volume as ONE row of V voxels: there the cut runs along that row, in tiles of COLS * 32 voxels
-    const bool along_w = C::TAPS == 1 && p0.H == 1 && p0.T == 1;
-    const int tiles_x = (int)ceil_div(p0.W, C::COLS * 32);
-    const int n = along_w ? tiles_x : (int)ceil_div(p0.H, C::ROWS);
-    const int64_t c = along_w ? ceil_div(p0.Cout, C::MT) : (int64_t)tiles_x * p0.T * ceil_div(p0.Cout, C::MT);
-    const int nchunks = (int)ceil_div(p0.Cin, C::CK);
-    const double t_round = occ * 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * p0.Cin * C::TAPS / (cu_flops * eff);
+    const int tiles_x = (int)ceil_div(d.W, C::COLS * 32);
+    const int n = (int)ceil_div(d.H, C::ROWS);
+    const int64_t c = (int64_t)tiles_x * d.T * ceil_div(d.Cout, C::MT);
+    const int nchunks = (int)ceil_div(d.Cin, C::CK);
+    const double t_round = occ * 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * d.Cin * C::TAPS / (cu_flops * eff);
     RowPlan best{(double)ceil_div(n * c, slots) * t_round, n, 1};
     const double t_plain = best.cost;
     static const int ks[] = {2, 3, 4, 6, 8};
     for (int nA = 0; nA < n && have_scratch; ++nA) {
-        const int64_t slabB = along_w ? (int64_t)p0.Cout * (p0.W - (int64_t)nA * C::COLS * 32)
-                                      : (int64_t)p0.Cout * p0.T * (p0.H - (int64_t)nA * C::ROWS) * p0.W;
+        const int64_t slabB = (int64_t)d.Cout * d.T * (d.H - (int64_t)nA * C::ROWS) * d.W;
         for (int k : ks) {
             if (k > nchunks || k * slabB > scratch_floats) continue;
             const double rounds = (double)ceil_div(nA * c, slots) + (double)ceil_div((n - nA) * c * k, slots) / k;
@@ -1619,32 +1431,12 @@ static RowPlan plan_rows(const ConvKParams& p0, bool have_scratch, int64_t scrat
         }
     }
     if (best.cost > 0.97 * t_plain) best = RowPlan{t_plain, n, 1};      // not worth the extra launches
-    // STEMSEG_PLANNER=0: plain launches only (A/B measurements; with several steps in flight the other steps' kernels fill
-    // the tail rounds anyway and the cut only costs slab traffic)
-    static const bool off = [] { const char* e = getenv("STEMSEG_PLANNER"); return e && e[0] == '0'; }();
-    if (off) best = RowPlan{t_plain, n, 1};
     return best;
 }
 
 template <class C>
-static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int64_t scratch_floats, const RowPlan& plan) {
-    if (plan.k <= 1) return launch_cfg<C>(p0, s, scratch, scratch_floats);
-    if (C::TAPS == 1 && p0.H == 1 && p0.T == 1) {           // cut along the flat voxel row (see plan_rows)
-        auto span = [&](int64_t x0, int64_t x1) {
-            ConvKParams q = p0;
-            q.in += x0; q.in_limit -= x0;
-            q.out += x0;
-            if (q.res) q.res += x0;
-            q.W = (int)(x1 - x0);
-            return q;
-        };
-        const int64_t xA = (int64_t)plan.nA * C::COLS * 32;
-        if (xA > 0) {
-            const int rc = launch_cfg<C>(span(0, xA), s, nullptr, 0);
-            if (rc) return rc;
-        }
-        return launch_cfg<C>(span(xA, p0.W), s, scratch, scratch_floats, plan.k);
-    }
+static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int64_t scratch_floats, const RowPlan& plan, const PlanCtx* pc) {
+    if (plan.k <= 1) return launch_cfg<C>(p0, s, scratch, scratch_floats, 0, pc);
     auto rows = [&](int r0, int r1) {
         ConvKParams q = p0;
         q.in += (int64_t)r0 * p0.in_ys; q.in_limit -= (int64_t)r0 * p0.in_ys; q.in_H = (r1 - r0) + C::KH - 1;
@@ -1658,155 +1450,118 @@ static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int
         const int rc = launch_cfg<C>(rows(0, rA), s, nullptr, 0);
         if (rc) return rc;
     }
-    return launch_cfg<C>(rows(rA, p0.H), s, scratch, scratch_floats, plan.k);
+    const ConvKParams qB = rows(rA, p0.H);
+    SS_CHECK_ARG((int64_t)plan.k * qB.Cout * qB.T * qB.H * qB.W <= scratch_floats, "conv3d: split-K scratch too small for the planned row cut");
+    return launch_cfg<C>(qB, s, scratch, scratch_floats, plan.k);
 }
 
 // big launches (>= 512 workgroups of the 8-row tile): 8-row tile vs 4-row tile, each with its best row cut
 template <class Big, class Med>
-static int launch_planned(const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, int occ_big, int occ_med,
-                          double cu_flops = CU_FLOPS_F32) {
-    const RowPlan a = plan_rows<Big>(p, scratch != nullptr, scratch_floats, cu_flops, occ_big, 1.0);
-    const RowPlan b = plan_rows<Med>(p, scratch != nullptr, scratch_floats, cu_flops, occ_med, 0.92);
-    if (b.cost < 0.97 * a.cost) return launch_rows<Med>(p, s, scratch, scratch_floats, b);
-    return launch_rows<Big>(p, s, scratch, scratch_floats, a);
+static int launch_planned(const ConvKParams& p, const ConvKParams& d, const PlanCtx* pc, hipStream_t s, float* scratch, int64_t scratch_floats, int occ_big, int occ_med) {
+    const int64_t plan_scratch = pc ? pc->scratch_floats : scratch_floats;
+    const RowPlan a = plan_rows<Big>(d, scratch != nullptr, plan_scratch, CU_FLOPS_F32, occ_big, 1.0);
+    const RowPlan b = plan_rows<Med>(d, scratch != nullptr, plan_scratch, CU_FLOPS_F32, occ_med, 0.92);
+    if (b.cost < 0.97 * a.cost) return launch_rows<Med>(p, s, scratch, scratch_floats, b, pc);
+    return launch_rows<Big>(p, s, scratch, scratch_floats, a, pc);
 }
 
-// fraction of the computed N positions that are real outputs, 2-D tile vs flat tile
+// fraction of the computed N positions that are real outputs, 2-D tile vs flat tile (per frame: no dependence on T)
 template <class C>
 static double tile_efficiency(const ConvKParams& p) {
     if (C::FLAT) return (double)p.H * p.W / ((double)C::NT * ceil_div((int64_t)p.H * p.in_ys, C::NT));
     return (double)p.H * p.W / ((double)C::ROWS * ceil_div(p.H, C::ROWS) * C::COLS * 32.0 * ceil_div(p.W, C::COLS * 32));
 }
 template <class Flat, class Tile2D>
-static bool prefer_flat(const ConvKParams& p, int tile_cfg, bool bf) {
-    static const bool off = [] { const char* e = getenv("STEMSEG_FLAT"); return e && e[0] == '0'; }();
-    if (off || bf || !p.vec4 || tile_cfg > 0 || p.dec_W > 0 || p.in_ys > Flat::PMAX || p.in_ys % 4 != 0 || p.W + 2 > p.in_ys) return false;
+static bool prefer_flat(const ConvKParams& p, int tile_cfg) {
+    if (!p.vec4 || tile_cfg > 0 || p.dec_W > 0 || p.in_ys > Flat::PMAX || p.in_ys % 4 != 0 || p.W + 2 > p.in_ys) return false;
     return tile_efficiency<Flat>(p) > 1.08 * tile_efficiency<Tile2D>(p);
 }
 
-// rounds of the chip x work per workgroup: the time of an MFMA-bound launch whose workgroups all take equally long
-template <class C>
-static double rounds_cost(const ConvKParams& p) {
-    const int64_t tiles = C::FLAT ? ceil_div((int64_t)p.H * p.in_ys, C::NT) : ceil_div(p.W, C::COLS * 32) * ceil_div(p.H, C::ROWS);
-    const int64_t wgs = tiles * p.T * ceil_div(p.Cout, C::MT);
-    return (double)ceil_div(wgs, 256) * C::NT * C::MT;
-}
-static bool tile224_on() {
-    // measured (round 2): 42.99 / 43.09 clips/s with, 43.60 / 43.40 without -- the rounds saved are eaten by the narrower wave
-    // tile (one A fragment per 7 MFMAs instead of 4 per 8) and the other lanes' kernels already fill uneven rounds: off
-    static const bool on = [] { const char* e = getenv("STEMSEG_TILE224"); return e && e[0] == '1'; }();
-    return on;
-}
-
-static int glds_mask() {
-    static const int m = [] { const char* e = getenv("STEMSEG_GLDS"); return e ? atoi(e) : STEMSEG_GLDS_DEFAULT; }();
-    return m;
-}
-// GL twin when its class is switched on and the launch meets its contract, else the register-staged form
+// GL twin when the launch meets its contract, else the register-staged form
 template <class GLCfg, class Cfg>
-static int launch_gl(int bit, const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats) {
-    if ((glds_mask() & bit) && p.vec4 && p.Cin % GLCfg::CK == 0 && p.Cout % GLCfg::MT == 0) return launch_cfg<GLCfg>(p, s, scratch, scratch_floats);
-    return launch_cfg<Cfg>(p, s, scratch, scratch_floats);
+static int launch_gl(const ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, const PlanCtx* pc) {
+    if (p.vec4 && p.Cin % GLCfg::CK == 0 && p.Cout % GLCfg::MT == 0) return launch_cfg<GLCfg>(p, s, scratch, scratch_floats, 0, pc);
+    return launch_cfg<Cfg>(p, s, scratch, scratch_floats, 0, pc);
 }
 
 template <class C>
-static int64_t num_workgroups(int Cout, int T, int H, int W) {
-    return ceil_div(W, C::COLS * 32) * ceil_div(H, C::ROWS) * T * ceil_div(Cout, C::MT);
+static int64_t num_workgroups(const ConvKParams& d) {
+    return ceil_div(d.W, C::COLS * 32) * ceil_div(d.H, C::ROWS) * d.T * ceil_div(d.Cout, C::MT);
 }
 
 // split-staged precisions: the weights were packed with stemseg_hip_pack_conv_weight_prec(..., precision).  Tile = the largest whose
-// launch (with split-K where scratch is given) still covers the chip; tile_cfg 1 / 2 / 3 force big / medium / small.
+// PLANNED launch (with split-K where scratch is given) still covers the chip; tile_cfg 1 / 2 / 3 force big / medium / small, 5 the
+// flat form of the big 2-D tile (f16x3; tests and sweeps).  p: the launch, d: its planning shape.
 template <int BFV>
-static int launch_split_family(ConvKParams& p, hipStream_t s, float* scratch, int64_t scratch_floats, int tile_cfg, bool k3, bool k2, bool k1) {
+static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanCtx* pc, hipStream_t s, float* scratch, int64_t scratch_floats, int tile_cfg,
+                               bool k3, bool k2) {
     typedef SplitTiles<BFV> F;
     using Y3Big = typename F::Y3Big; using Y3Med = typename F::Y3Med; using Y3Small = typename F::Y3Small;
     using Y2Big = typename F::Y2Big; using Y2Med = typename F::Y2Med; using Y2Small = typename F::Y2Small; using Y2M64 = typename F::Y2M64;
-    using Y1Big = typename F::Y1Big; using Y1Small = typename F::Y1Small; using Y1M64 = typename F::Y1M64; using Y1Wide = typename F::Y1Wide;
-    int cfg = tile_cfg;
-    // STEMSEG_X6_TILES (debug / A-B): bit 0 no big 3x3x3 tile, bit 1 no big 2-D tile, bit 2 no big 1x1 tile, bit 3 no split-K
-    static const int x6_off = [] { const char* e = getenv("STEMSEG_X6_TILES"); return e ? atoi(e) : 0; }();
-    if (x6_off & 8) { scratch = nullptr; scratch_floats = 0; }
-    if (cfg <= 0 || cfg > 3) {
-        if (k3 && (x6_off & 1)) cfg = 2;
-        if (k2 && (x6_off & 2) && p.Cout > 64) cfg = 2;
-        if (k1 && (x6_off & 4) && p.Cout > 64) cfg = 2;
-    }
-    // flat tiles (f16x3 only: the default mode; STEMSEG_X6_FLAT=0 switches them off, tile_cfg 5 forces them where the contract holds):
-    // maps whose width wastes a 32-column tile, or whose height a 16-row one, lose that share of their MFMAs to positions that are
-    // never stored (216 x 120: 10 %, 54 x 30: 21 %); a flat tile computes the halo columns instead (4 of 220, 2 of 56)
-    // measured (4-clip steps, three lanes): 2-D flat tiles 98.5 -> 100.3 clips/s (layer-3 3x3: 256 -> 224 workgroups, 207 -> 191 us); 3-D flat
-    // tiles nothing (block_4x 448 -> 416 workgroups is two rounds of the chip either way and the flat epilogue stores 4 B per lane): default 2
-    static const int flat_mode = [] { const char* e = getenv("STEMSEG_X6_FLAT"); return e ? atoi(e) : 2; }();      // 0 off, 1 both classes, 2 only 2-D, 3 only 3-D
-    const bool flat_off = flat_mode == 0 || (flat_mode == 2 && k3) || (flat_mode == 3 && k2);
-    const bool flat_ok = BFV == 3 && !flat_off && p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0;
+    using Y1Small = typename F::Y1Small; using Y1Big = typename F::Y1Big; using Y1M64 = typename F::Y1M64; using Y1Wide = typename F::Y1Wide;
+    const bool auto_cfg = tile_cfg <= 0 || tile_cfg > 3;
+    int cfg = auto_cfg ? 0 : tile_cfg;
     if constexpr (BFV == 3) {
-    if ((flat_ok || (tile_cfg == 5 && flat_mode != 0 && BFV == 3 && p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0)) && k3 && (tile_cfg == 5 || ((tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384))) {
-        const double e2d = (double)p.H * p.W / ((double)Y3Big::ROWS * ceil_div(p.H, Y3Big::ROWS) * 32.0 * ceil_div(p.W, 32));
-        const double efl = (double)p.H * p.W / (512.0 * ceil_div((int64_t)p.H * p.in_ys, 512));
-        if (tile_cfg == 5 || efl > 1.04 * e2d) {
-            if (p.in_ys <= 112) return launch_cfg<typename F::template Y3Flat<112>>(p, s, scratch, scratch_floats);
-            return launch_cfg<typename F::template Y3Flat<224>>(p, s, scratch, scratch_floats);
+        // Flat tiles (f16x3: the default mode): a 2-D tile of 16 rows x 32 columns computes 128 x 224 positions for a 120 x 216 map and
+        // 32 x 64 for layer 3's 30 x 54: 13-21 % of the MFMAs feed positions that are never stored; the flat tile computes the halo
+        // columns instead (2 of 56).  Measured (tools/conv_sweep.py, T = 32): a flat workgroup is 6 % slower than a 2-D one at pitch
+        // 56 -- by-element epilogue -- and 15-25 % slower at pitch 112 / 224, where the staged run is 1.15x / 1.49x the 2-D tile's
+        // piece: the 13-21 % fewer workgroups only pay at pitch <= 56 (layer-3 3x3: 256 -> 224 workgroups, 207 -> 191 us).
+        const bool flat_ok = p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0;
+        if (flat_ok && k2 && !p.gn_part && p.in_ts == (int64_t)p.in_H * p.in_ys && p.in_H == p.H + 2 &&
+            (tile_cfg == 5 || (auto_cfg && num_workgroups<Y2Big>(d) >= (scratch ? 96 : 384)))) {
+            const double e2d = (double)p.H * p.W / ((double)Y2Big::ROWS * ceil_div(p.H, Y2Big::ROWS) * 32.0 * ceil_div(p.W, 32));
+            const double efl = (double)d.T * p.H * p.W / (512.0 * ceil_div((int64_t)d.T * p.in_ts, 512));
+            if (tile_cfg == 5 || (efl > 1.04 * e2d && p.in_ys <= 56)) {
+                p.flat_t = 1;
+                if (p.in_ys <= 56) return launch_cfg<typename F::template Y2Flat<56>>(p, s, scratch, scratch_floats, 0, pc);
+                if (p.in_ys <= 112) return launch_cfg<typename F::template Y2Flat<112>>(p, s, scratch, scratch_floats, 0, pc);
+                return launch_cfg<typename F::template Y2Flat<224>>(p, s, scratch, scratch_floats, 0, pc);
+            }
         }
-    }
-    if (flat_ok && k2 && !p.gn_part && p.in_ts == (int64_t)p.in_H * p.in_ys && p.in_H == p.H + 2 &&
-        (tile_cfg == 5 || ((tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 384)))) {
-        const double e2d = (double)p.H * p.W / ((double)Y2Big::ROWS * ceil_div(p.H, Y2Big::ROWS) * 32.0 * ceil_div(p.W, 32));
-        const double efl = (double)p.T * p.H * p.W / (512.0 * ceil_div((int64_t)p.T * p.in_ts, 512));
-        // (measured, tools/conv_sweep.py T = 32: a flat workgroup is 6 % slower than a 2-D one at pitch 56 -- by-element epilogue -- and 15-25 %
-        // slower at pitch 112 / 224, where the staged run is 1.15x / 1.49x the 2-D tile's piece: the 13-21 % fewer workgroups only pay at 56)
-        if (tile_cfg == 5 || (efl > 1.04 * e2d && p.in_ys <= 56)) {
-            p.flat_t = 1;
-            if (p.in_ys <= 56) return launch_cfg<typename F::template Y2Flat<56>>(p, s, scratch, scratch_floats);
-            if (p.in_ys <= 112) return launch_cfg<typename F::template Y2Flat<112>>(p, s, scratch, scratch_floats);
-            return launch_cfg<typename F::template Y2Flat<224>>(p, s, scratch, scratch_floats);
-        }
-    }
     }
     if (k3) {
-        if (cfg <= 0 || cfg > 3) cfg = num_workgroups<Y3Big>(p.Cout, p.T, p.H, p.W) >= 384 ? 1 : (num_workgroups<Y3Med>(p.Cout, p.T, p.H, p.W) >= (scratch ? 32 : 256) ? 2 : 3);
-        // big launches: the row planner (whole rows + split-K rows, see plan_rows) with one eight-wave workgroup per CU
-        static const bool plan6 = [] { const char* e = getenv("STEMSEG_X6_PLANNER"); return e && e[0] == '1'; }();   // (measured: 63.6 clips/s with, 64.7 without)
-        if (cfg == 1 && plan6 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<Y3Big, Y3Med>(p, s, scratch, scratch_floats, 1, 1, CU_FLOPS_X6);
-        if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats);
-        if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats);
-        return launch_cfg<Y3Small>(p, s, scratch, scratch_floats);
+        if (cfg == 0) cfg = num_workgroups<Y3Big>(d) >= 384 ? 1 : (num_workgroups<Y3Med>(d) >= (scratch ? 32 : 256) ? 2 : 3);
+        if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats, 0, pc);
+        return launch_cfg<Y3Small>(p, s, scratch, scratch_floats, 0, pc);
     }
     if (k2) {
-        if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats);
-        if (cfg <= 0 || cfg > 3) {
+        if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 0) {
             const int64_t need = scratch ? 96 : 384;
-            cfg = num_workgroups<Y2Big>(p.Cout, p.T, p.H, p.W) >= need ? 1 : (num_workgroups<Y2Med>(p.Cout, p.T, p.H, p.W) >= need ? 2 : 3);
+            cfg = num_workgroups<Y2Big>(d) >= need ? 1 : (num_workgroups<Y2Med>(d) >= need ? 2 : 3);
         }
-        if (cfg == 1) return launch_cfg<Y2Big>(p, s, scratch, scratch_floats);
-        if (cfg == 2) return launch_cfg<Y2Med>(p, s, scratch, scratch_floats);
-        return launch_cfg<Y2Small>(p, s, scratch, scratch_floats);
+        if (cfg == 1) return launch_cfg<Y2Big>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 2) return launch_cfg<Y2Med>(p, s, scratch, scratch_floats, 0, pc);
+        return launch_cfg<Y2Small>(p, s, scratch, scratch_floats, 0, pc);
     }
-    if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats);
-    if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats);
+    if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats, 0, pc);
+    if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats, 0, pc);
     // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
     // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
-    if ((tile_cfg <= 0 || tile_cfg > 3) && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(p.Cout, p.T, p.H, p.W) >= 128)
-        return launch_cfg<Y1Wide>(p, s, nullptr, 0);
-    if (cfg <= 0 || cfg > 2) {
-        cfg = (num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
-        if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
-        // f16x3 (tools/conv_sweep.py, T = 32): every x4 expansion of the encoder is ~10 % faster on the 128-voxel tile (64 -> 256 444 ->
-        // 403 us, 128 -> 512 263 -> 236, 512 -> 2048 128 -> 115)
-        if (BFV == 3 && p.Cout >= 4 * p.Cin) cfg = 2;
-        // ... and with the one-phase weight schedule (WMODE 1) the 128-voxel tile wins on every other 1x1 shape of the step too (T = 32:
-        // 512 -> 128 133 vs 146 us, 2048 -> 512 115 vs 123, 2048 -> 256 70 vs 75; the decoders' fuse convs likewise)
-        if (BFV == 3) cfg = 2;
+    if (auto_cfg && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(d) >= 128)
+        return launch_cfg<Y1Wide>(p, s, nullptr, 0, 0, pc);
+    if (cfg == 0 || cfg > 2) {
+        if (BFV == 3) {
+            // f16x3 with the one-phase weight schedule (WMODE 1): the 128-voxel tile wins on every 1x1 shape of the step (tools/conv_sweep.py,
+            // T = 32: 64 -> 256 444 -> 403 us, 128 -> 512 263 -> 236, 512 -> 2048 128 -> 115, 512 -> 128 146 -> 133, 2048 -> 512 123 -> 115)
+            cfg = 2;
+        } else {
+            cfg = (num_workgroups<Y1Big>(d) >= (scratch ? 96 : 512)) ? 1 : 2;
+            if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<Y1Big>(d) < 2048) cfg = 2;
+        }
     }
-    if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats);
-    return launch_cfg<Y1Small>(p, s, scratch, scratch_floats);
+    if (cfg == 1) return launch_cfg<Y1Big>(p, s, scratch, scratch_floats, 0, pc);
+    return launch_cfg<Y1Small>(p, s, scratch, scratch_floats, 0, pc);
 }
 
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* scratch, int64_t scratch_floats, const ConvEpilogue* epi) {
     SS_CHECK_ARG(in.ptr && out.ptr && packed_w, "conv3d: null pointer");
-    const bool bf = epi && epi->precision == 1;
-    const bool x6 = epi && epi->precision == 2, f16x3 = epi && epi->precision == 3;
-    SS_CHECK_ARG(!epi || (epi->precision >= 0 && epi->precision <= 3), "conv3d: precision %d (0 f32, 1 bf16x3, 2 bf16x6, 3 f16x3)", epi ? epi->precision : 0);
+    const int prec = epi ? epi->precision : STEMSEG_PRECISION_F32;
+    SS_CHECK_ARG(prec == STEMSEG_PRECISION_F32 || prec == STEMSEG_PRECISION_BF16X6 || prec == STEMSEG_PRECISION_F16X3,
+                 "conv3d: precision %d (0 f32, 2 bf16x6, 3 f16x3)", prec);
     const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1), k2 = (kt == 1 && kh == 3 && kw == 3);
     SS_CHECK_ARG(k3 || k1 || k2, "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3 or 1x1x1)", kt, kh, kw);
     const bool flat = epi && epi->dec_W > 0;
@@ -1839,113 +1594,86 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.vec_epi = (!flat && p.W % 4 == 0 && al16(p.out, p.out_cs, p.out_ts, p.out_ys, p.T, p.H) &&
                  (!p.res || al16(p.res, p.res_cs, p.res_ts, p.res_ys, p.T, p.H))) ? 1 : 0;
     p.tiles_x = p.tiles_y = 0;
-    static const bool t_fast = [] { const char* e = getenv("STEMSEG_T_FASTEST"); return !(e && e[0] == '0'); }();
-    p.t_fastest = t_fast ? 1 : 0;
+    p.t_fastest = 1;
     p.flat_t = 0; p.T_all = p.T;
     const bool aligned = (reinterpret_cast<uintptr_t>(in.ptr) % 16 == 0) && (in.c_stride % 4 == 0) &&
                          (in.T == 1 || in.t_stride % 4 == 0) && (in.H == 1 || in.y_stride % 4 == 0);
     p.vec4 = aligned ? 1 : 0;
     SS_CHECK_ARG(reinterpret_cast<uintptr_t>(packed_w) % 16 == 0, "conv3d: packed weights must be 16-byte aligned");
-    if (x6) return launch_split_family<2>(p, s, scratch, scratch_floats, tile_cfg, k3, k2, k1);
-    if (f16x3) return launch_split_family<3>(p, s, scratch, scratch_floats, tile_cfg, k3, k2, k1);
+    // planning shape (see PlanCtx): `frames` frames in this launch, planned as `plan_frames`
+    PlanCtx pc_store;
+    const PlanCtx* pc = nullptr;
+    if (epi && epi->plan_frames > 0) {
+        SS_CHECK_ARG(epi->frames > 0 && epi->plan_scratch_floats >= 0, "conv3d: plan_frames needs the launch's own frame count");
+        pc_store.shape = p;
+        pc_store.scratch_floats = epi->plan_scratch_floats;
+        if (p.T == 1 && p.H == 1) {                        // a flat [C][V] launch: V = frames x (voxels per frame)
+            SS_CHECK_ARG(p.W % epi->frames == 0, "conv3d: flat volume of %d voxels is not %d whole frames", p.W, epi->frames);
+            const int64_t Wp = (int64_t)(p.W / epi->frames) * epi->plan_frames;
+            SS_CHECK_ARG(Wp < (1ll << 31), "conv3d: planning volume too large");
+            pc_store.shape.W = (int)Wp;
+        } else {
+            SS_CHECK_ARG(p.T == epi->frames, "conv3d: launch of %d t-planes announced as %d frames", p.T, epi->frames);
+            pc_store.shape.T = epi->plan_frames;
+        }
+        pc_store.shape.T_all = pc_store.shape.T;
+        pc = &pc_store;
+    }
+    const ConvKParams& d = pc ? pc->shape : p;
+    if (prec == STEMSEG_PRECISION_BF16X6) return launch_split_family<2>(p, d, pc, s, scratch, scratch_floats, tile_cfg, k3, k2);
+    if (prec == STEMSEG_PRECISION_F16X3) return launch_split_family<3>(p, d, pc, s, scratch, scratch_floats, tile_cfg, k3, k2);
+    const bool auto_cfg = tile_cfg <= 0 || tile_cfg > 3;
     if (k3) {
         int cfg = tile_cfg;
-        if (cfg <= 0 || cfg > 3) {
+        if (auto_cfg) {
             // largest tile that still gives every CU two workgroups
-            if (num_workgroups<K3Big>(p.Cout, p.T, p.H, p.W) >= 512) cfg = 1;
-            else if (num_workgroups<K3Med>(p.Cout, p.T, p.H, p.W) >= 384) cfg = 2;
+            if (num_workgroups<K3Big>(d) >= 512) cfg = 1;
+            else if (num_workgroups<K3Med>(d) >= 384) cfg = 2;
             else cfg = 3;
         }
-        if (cfg == 2 && prefer_flat<K3FlatMed56, K3Med>(p, tile_cfg, bf)) return launch_gl<K3FlatMed56GL, K3FlatMed56>(2, p, s, scratch, scratch_floats);
-        if (cfg == 3 && prefer_flat<K3FlatSmall56, K3Small>(p, tile_cfg, bf)) return launch_gl<K3FlatSmall56GL, K3FlatSmall56>(2, p, s, scratch, scratch_floats);
-        if (cfg == 2 && prefer_flat<K3FlatMed, K3Med>(p, tile_cfg, bf)) return launch_gl<K3FlatMedGL, K3FlatMed>(2, p, s, scratch, scratch_floats);
-        if (cfg == 3 && prefer_flat<K3FlatSmall, K3Small>(p, tile_cfg, bf)) return launch_gl<K3FlatSmallGL, K3FlatSmall>(2, p, s, scratch, scratch_floats);
-        if (bf) {
-            if (cfg == 1) return launch_cfg<X3Big>(p, s, scratch, scratch_floats);   // (row balancing measured slower here)
-            if (cfg == 2) return launch_cfg<X3Med>(p, s, scratch, scratch_floats);
-            return launch_cfg<X3Small>(p, s, scratch, scratch_floats);
+        if (cfg == 2 && prefer_flat<K3FlatMed56, K3Med>(p, tile_cfg)) return launch_cfg<K3FlatMed56>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 3 && prefer_flat<K3FlatSmall56, K3Small>(p, tile_cfg)) return launch_cfg<K3FlatSmall56>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 2 && prefer_flat<K3FlatMed, K3Med>(p, tile_cfg)) return launch_cfg<K3FlatMed>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 3 && prefer_flat<K3FlatSmall, K3Small>(p, tile_cfg)) return launch_cfg<K3FlatSmall>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 1 && p.vec4 && p.Cout % 128 == 0) {          // (Cin % 2 == 0 holds: Cin % 4 == 0 above)
+            if (auto_cfg) return launch_planned<K3BigGL, K3Med>(p, d, pc, s, scratch, scratch_floats, 2, 2);
+            return launch_cfg<K3BigGL>(p, s, scratch, scratch_floats, 0, pc);
         }
-        // the big tile runs double-buffered (measured 4.06 -> 3.66 ms on block_4x); STEMSEG_K3_DB=0 selects the single-buffer
-        // form for A/B measurements
-        static const bool use_db = [] { const char* e = getenv("STEMSEG_K3_DB"); return !(e && e[0] == '0'); }();
-        if (cfg == 1 && (glds_mask() & 1) && p.vec4 && p.Cin % 2 == 0 && p.Cout % 128 == 0) {
-            if (tile_cfg <= 0 || tile_cfg > 3) return launch_planned<K3BigGL, K3Med>(p, s, scratch, scratch_floats, 2, 2);
-            return launch_cfg<K3BigGL>(p, s, scratch, scratch_floats);
-        }
-        if (cfg == 1 && use_db && p.vec4) {
-            if (tile_cfg <= 0 || tile_cfg > 3) return launch_planned<K3BigDB, K3Med>(p, s, scratch, scratch_floats, 2, 2);
-            return launch_cfg<K3BigDB>(p, s, scratch, scratch_floats);
-        }
-        if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3)) return launch_planned<K3Big, K3Med>(p, s, scratch, scratch_floats, 2, 2);
-        if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats);
-        if (cfg == 2) return launch_gl<K3MedGL, K3Med>(2, p, s, scratch, scratch_floats);
-        return launch_gl<K3SmallGL, K3Small>(2, p, s, scratch, scratch_floats);
+        if (cfg == 1 && auto_cfg) return launch_planned<K3Big, K3Med>(p, d, pc, s, scratch, scratch_floats, 2, 2);
+        if (cfg == 1) return launch_cfg<K3Big>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 2) return launch_cfg<K3Med>(p, s, scratch, scratch_floats, 0, pc);
+        return launch_cfg<K3Small>(p, s, scratch, scratch_floats, 0, pc);
     }
     if (k2) {
-        if (p.Cout <= 64) return bf ? launch_cfg<X2M64>(p, s, scratch, scratch_floats) : launch_cfg<K2M64>(p, s, scratch, scratch_floats);
+        if (p.Cout <= 64) return launch_cfg<K2M64>(p, s, scratch, scratch_floats, 0, pc);
         int cfg = tile_cfg;
-        if (cfg <= 0 || cfg > 3) {   // biggest tile (best weight reuse) that split-K can still spread over the chip
+        if (auto_cfg) {   // biggest tile (best weight reuse) that split-K can still spread over the chip
             const int64_t need = scratch ? 96 : 384;
-            if (num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= need) cfg = 1;
-            else if (num_workgroups<K2Med>(p.Cout, p.T, p.H, p.W) >= need) cfg = 2;
+            if (num_workgroups<K2Big>(d) >= need) cfg = 1;
+            else if (num_workgroups<K2Med>(d) >= need) cfg = 2;
             else cfg = 3;
         }
-        if (tile_cfg == 4 && !bf && p.vec4 && p.dec_W == 0 && p.in_ys <= 56 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys)   // (tests / sweeps)
-            return launch_cfg<K2Flat7_56>(p, s, scratch, scratch_floats);
-        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg, bf)) {
-            if (tile224_on() && rounds_cost<K2FlatBig56>(p) > 1.5 * K2FlatBig56::NT * K2FlatBig56::MT && rounds_cost<K2Flat7_56>(p) < 0.97 * rounds_cost<K2FlatBig56>(p)) return launch_cfg<K2Flat7_56>(p, s, scratch, scratch_floats);
-            return launch_gl<K2FlatBig56GL, K2FlatBig56>(4, p, s, scratch, scratch_floats);
-        }
-        if (cfg >= 2 && prefer_flat<K2FlatMed56, K2Med>(p, tile_cfg, bf)) return launch_gl<K2FlatMed56GL, K2FlatMed56>(4, p, s, scratch, scratch_floats);
-        if (cfg == 1 && prefer_flat<K2FlatBig, K2Big>(p, tile_cfg, bf)) return launch_gl<K2FlatBigGL, K2FlatBig>(4, p, s, scratch, scratch_floats);
-        if (cfg >= 2 && prefer_flat<K2FlatMed, K2Med>(p, tile_cfg, bf)) return launch_gl<K2FlatMedGL, K2FlatMed>(4, p, s, scratch, scratch_floats);
-        if (bf) {
-            if (cfg == 1) return launch_cfg<X2Big>(p, s, scratch, scratch_floats);
-            if (cfg == 2) return launch_cfg<X2Med>(p, s, scratch, scratch_floats);
-            return launch_cfg<X2Small>(p, s, scratch, scratch_floats);
-        }
-        const bool gl2 = (glds_mask() & 4) && p.vec4 && p.Cin % 4 == 0 && p.Cout % 128 == 0;
-        if (cfg == 1 && (tile_cfg <= 0 || tile_cfg > 3) && num_workgroups<K2Big>(p.Cout, p.T, p.H, p.W) >= 512)
-            return gl2 ? launch_planned<K2BigGL, K2MedGL>(p, s, scratch, scratch_floats, 3, 3) : launch_planned<K2Big, K2Med>(p, s, scratch, scratch_floats, 3, 3);
-        if (cfg == 1) return launch_gl<K2BigGL, K2Big>(4, p, s, scratch, scratch_floats);
-        if (cfg == 2) return launch_gl<K2MedGL, K2Med>(4, p, s, scratch, scratch_floats);
-        return launch_gl<K2SmallGL, K2Small>(4, p, s, scratch, scratch_floats);
+        if (cfg == 1 && prefer_flat<K2FlatBig56, K2Big>(p, tile_cfg)) return launch_cfg<K2FlatBig56>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg >= 2 && prefer_flat<K2FlatMed56, K2Med>(p, tile_cfg)) return launch_cfg<K2FlatMed56>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 1 && prefer_flat<K2FlatBig, K2Big>(p, tile_cfg)) return launch_cfg<K2FlatBig>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg >= 2 && prefer_flat<K2FlatMed, K2Med>(p, tile_cfg)) return launch_cfg<K2FlatMed>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 1 && auto_cfg && num_workgroups<K2Big>(d) >= 512) return launch_planned<K2Big, K2Med>(p, d, pc, s, scratch, scratch_floats, 3, 3);
+        if (cfg == 1) return launch_cfg<K2Big>(p, s, scratch, scratch_floats, 0, pc);
+        if (cfg == 2) return launch_cfg<K2Med>(p, s, scratch, scratch_floats, 0, pc);
+        return launch_cfg<K2Small>(p, s, scratch, scratch_floats, 0, pc);
     }
-    if (p.Cout <= 64) return bf ? launch_cfg<X1M64>(p, s, scratch, scratch_floats) : launch_gl<K1M64GL, K1M64>(8, p, s, scratch, scratch_floats);
+    if (p.Cout <= 64) return launch_gl<K1M64GL, K1M64>(p, s, scratch, scratch_floats, pc);
     int cfg = tile_cfg;
     if (cfg <= 0 || cfg > 2) {
-        cfg = (num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= (scratch ? 96 : 512)) ? 1 : 2;
+        cfg = (num_workgroups<K1Big>(d) >= (scratch ? 96 : 512)) ? 1 : 2;
         // expansion convs with a short K (<= 8 channel chunks) are bound by their output / residual traffic: the 128-voxel
         // tile keeps twice as many workgroups in flight (measured, tools/conv_sweep.py: 64->256 +res 233 -> 167 us)
         // -- up to ~2000 workgroups of the big tile; beyond that (several clips per encoder pass) the big tile wins again
         // (T = 32 sweep: 64->256 +res 532 vs 570 us, 128->512 +res 372 vs 438 us)
-        if (!bf && p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) < 2048) cfg = 2;
+        if (p.Cin <= 256 && p.Cout >= 4 * p.Cin && num_workgroups<K1Big>(d) < 2048) cfg = 2;
     }
-    if (bf) {
-        if (cfg == 1) return launch_cfg<X1Big>(p, s, scratch, scratch_floats);
-        return launch_cfg<X1Small>(p, s, scratch, scratch_floats);
-    }
-    if (tile_cfg == 4) return launch_gl<K1N7GL, K1N7>(8, p, s, scratch, scratch_floats);                                      // (tests / sweeps)
-    // big un-decoded 1x1 launches: same round-based cut as the 3x3 convs, along the flat voxel row
-    // ... but only where the conv is matrix-core bound: the cut trades slab traffic for MFMA rounds, and a short-K expansion
-    // (64 -> 256, 128 -> 512 + residual: ~14-25 FLOP per byte of its own tensors) is bound by exactly that traffic
-    const double flop_per_byte = 2.0 * p.Cin * p.Cout / (4.0 * (p.Cin + p.Cout * (p.res ? 2.0 : 1.0)));
-    const bool plan1 = !flat && (tile_cfg <= 0 || tile_cfg > 2) && scratch != nullptr && flop_per_byte >= 40.0;
-    const bool gl1 = (glds_mask() & 8) && p.vec4 && p.Cin % 16 == 0 && p.Cout % 128 == 0;
-    if (cfg == 1) {
-        if (plan1 && num_workgroups<K1Big>(p.Cout, p.T, p.H, p.W) >= 512) {
-            if (gl1) return launch_rows<K1BigGL>(p, s, scratch, scratch_floats, plan_rows<K1BigGL>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
-            return launch_rows<K1Big>(p, s, scratch, scratch_floats, plan_rows<K1Big>(p, true, scratch_floats, CU_FLOPS_F32, 3, 1.0));
-        }
-        if (tile224_on() && (tile_cfg <= 0 || tile_cfg > 2) && rounds_cost<K1Big>(p) > 1.5 * K1Big::NT * K1Big::MT && rounds_cost<K1N7>(p) < 0.97 * rounds_cost<K1Big>(p))
-            return launch_gl<K1N7GL, K1N7>(8, p, s, scratch, scratch_floats);
-        return launch_gl<K1BigGL, K1Big>(8, p, s, scratch, scratch_floats);
-    }
-    if (plan1 && num_workgroups<K1Small>(p.Cout, p.T, p.H, p.W) >= 1024) {
-        if (gl1) return launch_rows<K1SmallGL>(p, s, scratch, scratch_floats, plan_rows<K1SmallGL>(p, true, scratch_floats, CU_FLOPS_F32, 5, 0.85));
-        return launch_rows<K1Small>(p, s, scratch, scratch_floats, plan_rows<K1Small>(p, true, scratch_floats, CU_FLOPS_F32, 5, 0.85));
-    }
-    return launch_gl<K1SmallGL, K1Small>(8, p, s, scratch, scratch_floats);
+    if (cfg == 1) return launch_gl<K1BigGL, K1Big>(p, s, scratch, scratch_floats, pc);
+    return launch_gl<K1SmallGL, K1Small>(p, s, scratch, scratch_floats, pc);
 }
 
 int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
@@ -1954,11 +1682,10 @@ int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float
     SS_CHECK_ARG(stats && gn_scratch && groups > 0 && out.C % groups == 0, "conv3d_gn: bad GroupNorm arguments");
     const int cpg = out.C / groups;
     const int64_t S = (int64_t)out.T * out.H * out.W;
-    static const bool off = [] { const char* e = getenv("STEMSEG_GN_EPILOGUE"); return e && e[0] == '0'; }();
     const bool dense = out.t_stride == (int64_t)out.H * out.W && out.y_stride == out.W && out.c_stride == S;
     // upper bound of the slots any tile choice can need: smallest 2-D tile (2 rows x 32 columns) + a fully split-K launch
     const int64_t slot_bound = ceil_div(out.W, 32) * ceil_div(out.H, 2) * out.T + (int64_t)cpg * ceil_div(S, 256);
-    if (off || (cpg != 4 && cpg != 8) || slot_bound > GN_SLOT_CAP || (epi && (epi->relu || epi->res || epi->dec_W > 0))) {
+    if ((cpg != 4 && cpg != 8) || slot_bound > GN_SLOT_CAP || (epi && (epi->relu || epi->res || epi->dec_W > 0))) {
         SS_CHECK_ARG(dense, "conv3d_gn: the separate statistics pass needs a dense output");
         const int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, epi);
         return rc ? rc : launch_gn_stats(out.ptr, out.C, S, groups, eps, stats, gn_scratch, s);
@@ -1999,65 +1726,36 @@ extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32
     return STEMSEG_OK;
 }
 
-extern "C" int stemseg_hip_pack_conv_weight_bf16x3(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, void* stream) {
-    using namespace stemseg;
-    SS_CHECK_ARG(w && packed, "pack_conv_weight_bf16x3: null pointer");
-    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_bf16x3: taps must be 27, 9 or 1");
-    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
-    SS_CHECK_ARG(Cin % CK == 0 && Cout % 32 == 0, "pack_conv_weight_bf16x3: Cin %% %d, Cout %% 32 (got %d, %d)", CK, Cin, Cout);
-    const int64_t n = stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps) / 16;
-    const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
-    hipLaunchKernelGGL(pack_conv_weight_bf16x3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
-                       taps, CK, TPG);
-    SS_LAUNCH_CHECK();
-    return STEMSEG_OK;
-}
-
-extern "C" int64_t stemseg_hip_packed_weight_bytes_bf16x3(int32_t Cout, int32_t Cin, int32_t taps) {
+// bytes of the split-staged packing with `planes` 16-bit planes: per channel chunk [k-group][plane][lane half][Cout] x 16 B
+static int64_t split_packed_bytes(int32_t Cout, int32_t Cin, int32_t taps, int planes) {
     const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH);
-    return (int64_t)((Cin + CK - 1) / CK) * 2 * (NTG * NCG) * 2 * Cout * 16;
-}
-
-extern "C" int64_t stemseg_hip_packed_weight_bytes_split(int32_t Cout, int32_t Cin, int32_t taps, int32_t planes) {
-    if (planes == 2) return stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps);
-    if (planes != 3) return 0;
-    return stemseg_hip_packed_weight_bytes_bf16x3(Cout, Cin, taps) / 2 * 3;
-}
-
-extern "C" int stemseg_hip_pack_conv_weight_split(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t planes, void* stream) {
-    using namespace stemseg;
-    if (planes == 2) return stemseg_hip_pack_conv_weight_bf16x3(w, packed, Cout, Cin, taps, stream);
-    SS_CHECK_ARG(planes == 3, "pack_conv_weight_split: planes must be 2 (bf16x3) or 3 (bf16x6)");
-    SS_CHECK_ARG(w && packed, "pack_conv_weight_split: null pointer");
-    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_split: taps must be 27, 9 or 1");
-    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
-    SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_split: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
-    const int64_t n = stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3) / 16;
-    const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
-    hipLaunchKernelGGL(pack_conv_weight_bf16x6_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
-                       taps, CK, TPG);
-    SS_LAUNCH_CHECK();
-    return STEMSEG_OK;
+    return (int64_t)((Cin + CK - 1) / CK) * planes * (NTG * NCG) * 2 * Cout * 16;
 }
 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
-    if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 2);
-    if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, 3);
-    if (precision == STEMSEG_PRECISION_F16X3) return stemseg_hip_packed_weight_bytes_split(Cout, Cin, taps, SS_F16_WPLANES) + 8 * (int64_t)Cout;      // planes + per output channel: float 1 / scale, uint32 bits of max|w|
+    if (Cout <= 0 || Cin <= 0 || !(taps == 27 || taps == 9 || taps == 1)) return 0;
+    if (precision == STEMSEG_PRECISION_BF16X6) return split_packed_bytes(Cout, Cin, taps, 3);
+    if (precision == STEMSEG_PRECISION_F16X3) return split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES) + 8 * (int64_t)Cout;      // planes + per output channel: float 1 / scale, uint32 bits of max|w|
     return 0;
 }
 
 extern "C" int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t taps, int32_t precision, void* stream) {
     using namespace stemseg;
-    if (precision == STEMSEG_PRECISION_BF16X3) return stemseg_hip_pack_conv_weight_split(w, packed, Cout, Cin, taps, 2, stream);
-    if (precision == STEMSEG_PRECISION_BF16X6) return stemseg_hip_pack_conv_weight_split(w, packed, Cout, Cin, taps, 3, stream);
-    SS_CHECK_ARG(precision == STEMSEG_PRECISION_F16X3, "pack_conv_weight_prec: precision must be 1 (bf16x3), 2 (bf16x6) or 3 (f16x3)");
+    SS_CHECK_ARG(precision == STEMSEG_PRECISION_BF16X6 || precision == STEMSEG_PRECISION_F16X3, "pack_conv_weight_prec: precision must be 2 (bf16x6) or 3 (f16x3)");
     SS_CHECK_ARG(w && packed, "pack_conv_weight_prec: null pointer");
     SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_prec: taps must be 27, 9 or 1");
     const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
     SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_prec: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
-    const int64_t n = (stemseg_hip_packed_weight_bytes_prec(Cout, Cin, taps, precision) - 8 * (int64_t)Cout) / 16;
+    if (precision == STEMSEG_PRECISION_BF16X6) {
+        const int64_t n = split_packed_bytes(Cout, Cin, taps, 3) / 16;
+        const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+        hipLaunchKernelGGL(pack_conv_weight_bf16x6_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
+                           taps, CK, TPG);
+        SS_LAUNCH_CHECK();
+        return STEMSEG_OK;
+    }
+    const int64_t n = split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES) / 16;
     unsigned int* max_bits = reinterpret_cast<unsigned int*>(reinterpret_cast<float*>(reinterpret_cast<uint4*>(packed) + n) + Cout);
     hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)Cout), dim3(256), 0, as_stream(stream), w, (int64_t)Cin * taps, max_bits);
     SS_LAUNCH_CHECK();

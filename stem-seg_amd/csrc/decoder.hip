@@ -160,9 +160,7 @@ static inline StemsegVolume flat_volume(float* base, int C, int64_t V) {
 
 static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b, const float* gw, const float* gb, int Cout, int T, int H,
                    int W, int pool, const StemsegVolume& dst, float* D, float* stats, double* scratch, int G, float eps, hipStream_t s,
-                   float* splitk, int64_t splitk_floats, int precision, const float* ext_D = nullptr, const float* ext_stats = nullptr) {
-    // the convolution already ran beside its twins of the other decoders (stemseg_hip_shared_convs_forward): only GN + ReLU (+ pool) is left
-    if (ext_D) return launch_gn_relu_pool(ext_D, Cout, T, H, W, G, ext_stats, gw, gb, pool, dst, s);
+                   float* splitk, int64_t splitk_floats, int precision) {
     StemsegVolume d = dense_volume(D, Cout, T, H, W);
     ConvEpilogue e;
     e.precision = precision;
@@ -261,13 +259,11 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     for (int i = 0; i < 3; ++i) SS_CHECK_ARG(wts->fuse_w[i], "decoder_forward: null fuse weight %d", i);
     SS_CHECK_ARG(wts->head_w, "decoder_forward: null head weight");
     for (int i = 0; i < 4; ++i) SS_CHECK_ARG(feats[i], "decoder_forward: null feature map %d", i);
-    for (int i = 0; i < 4; ++i)
-        SS_CHECK_ARG(!wts->first_conv_out[i] || (wts->first_conv_stats[i] && desc->gn_groups > 0),
-                     "decoder_forward: first_conv_out[%d] needs first_conv_stats[%d] and a GroupNorm decoder", i, i);
 
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
-    SS_CHECK_ARG(desc->precision >= 0 && desc->precision <= 3, "decoder: precision must be 0 (f32), 1 (bf16x3), 2 (bf16x6) or 3 (f16x3)");
+    SS_CHECK_ARG(desc->precision == STEMSEG_PRECISION_F32 || desc->precision == STEMSEG_PRECISION_BF16X6 || desc->precision == STEMSEG_PRECISION_F16X3,
+                 "decoder: precision must be 0 (f32), 2 (bf16x6) or 3 (f16x3)");
     ConvEpilogue fuse_epi;
     fuse_epi.precision = desc->precision;
     const float eps = desc->gn_eps;
@@ -303,7 +299,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     }
     // 1. block_32x on s32: three conv/GN/ReLU(/pool) stages (embedding_decoder.py:20-35), then upsample into cat16[0:c32]
     rc = conv_gn(padded_halo_view(pin[0], p.cin, T, p.h[0], p.w[0]), wts->conv_w[0], wts->conv_b[0], wts->gn_w[0], wts->gn_b[0], p.c32, T,
-                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision, wts->first_conv_out[0], wts->first_conv_stats[0]);
+                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), wts->conv_w[1], wts->conv_b[1], wts->gn_w[1], wts->gn_b[1], p.c32,
                  p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
@@ -317,7 +313,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[0], s32));
     // 2. block_16x on s16 into cat16[c32:], join 32x, 1x1x1 fuse, upsample into cat8[0:c16]  (:112-117)
     rc = conv_gn(padded_halo_view(pin[1], p.cin, T, p.h[1], p.w[1]), wts->conv_w[3], wts->conv_b[3], wts->gn_w[3], wts->gn_b[3], p.c16, T,
-                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision, wts->first_conv_out[1], wts->first_conv_stats[1]);
+                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), wts->conv_w[4], wts->conv_b[4], wts->gn_w[4], wts->gn_b[4], p.c16,
                  p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision);
@@ -332,7 +328,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[1], s16));
     // 3. block_8x on s8 into cat8[c16:], join 16x, fuse, upsample into cat4[0:c8]  (:119-123)
     rc = conv_gn(padded_halo_view(pin[2], p.cin, T, p.h[2], p.w[2]), wts->conv_w[5], wts->conv_b[5], wts->gn_w[5], wts->gn_b[5], p.c8, T, p.h[2],
-                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision, wts->first_conv_out[2], wts->first_conv_stats[2]);
+                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(s8, bs->done[1], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, ws + p.S[2], p.Sfloats[2], &fuse_epi);
@@ -342,7 +338,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision, wts->first_conv_out[3], wts->first_conv_stats[3]);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
@@ -375,79 +371,5 @@ extern "C" int stemseg_hip_decoder_join(int32_t concurrency, void* stream) {
     BranchStreams* bs = get_streams(concurrency - 1);
     SS_CHECK_ARG(bs, "decoder_join: no stream set");
     for (int i = 0; i < 4; ++i) SS_HIP(hipStreamWaitEvent(as_stream(stream), bs->done[i], 0));
-    return STEMSEG_OK;
-}
-
-// ---- first-layer convolutions shared between decoders -------------------------------------------------------------------
-// block_32x.0 / block_16x.0 / block_8x.0 / block_4x.0 of every decoder read the SAME four FPN maps (embedding_decoder.py:111-127,
-// seediness_decoder.py:92-108, semseg_decoder.py:96-112).  One convolution per branch with the decoders' output channels
-// concatenated stages each input tile once and gives the chip (Cout_a + Cout_b) / 128 x as many workgroups per launch: the 4x branch
-// of the DAVIS pair is 896 workgroups (3.5 rounds of one per CU) instead of 2 x 448 (2 x 2 rounds).
-namespace stemseg {
-struct SharedPlan {
-    int h[4], w[4];
-    int64_t D[4], S[4], Sfloats[4], stats[4], gn_scratch[4], total;
-};
-static int make_shared_plan(const StemsegSharedConvsDesc* d, SharedPlan& p) {
-    SS_CHECK_ARG(d, "shared_convs: null descriptor");
-    SS_CHECK_ARG(d->struct_bytes == (int32_t)sizeof(StemsegSharedConvsDesc), "shared_convs: descriptor size mismatch (%d vs %d): ABI skew",
-                 d->struct_bytes, (int)sizeof(StemsegSharedConvsDesc));
-    SS_CHECK_ARG(d->T >= 1 && d->H4 >= 8 && d->W4 >= 8 && d->H4 % 8 == 0 && d->W4 % 8 == 0, "shared_convs: T=%d H4=%d W4=%d", d->T, d->H4, d->W4);
-    SS_CHECK_ARG(d->in_channels % 4 == 0 && d->in_channels > 0, "shared_convs: in_channels %% 4");
-    SS_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "shared_convs: precision");
-    int64_t off = 0;
-    auto take = [&](int64_t floats) { int64_t o = off; off += round_up(floats, 64); return o; };
-    static const int slabs[4] = {16, 4, 4, 2};            // as the decoders' own plans
-    for (int i = 0; i < 4; ++i) {
-        p.h[i] = d->H4 >> (3 - i); p.w[i] = d->W4 >> (3 - i);
-        p.D[i] = p.S[i] = p.stats[i] = p.gn_scratch[i] = 0; p.Sfloats[i] = 0;
-        if (d->cout[i] == 0) continue;
-        SS_CHECK_ARG(d->cout[i] > 0 && d->cout[i] % 32 == 0 && d->gn_groups[i] >= 1 && d->gn_groups[i] <= 64 && d->cout[i] % d->gn_groups[i] == 0,
-                     "shared_convs: branch %d: cout=%d (multiple of 32), gn_groups=%d (1..64, dividing cout)", i, d->cout[i], d->gn_groups[i]);
-        const int64_t n = (int64_t)d->cout[i] * d->T * p.h[i] * p.w[i];
-        p.D[i] = take(n);
-        p.Sfloats[i] = slabs[i] * n;
-        p.S[i] = take(p.Sfloats[i]);
-        p.stats[i] = take(2 * 64);
-        p.gn_scratch[i] = take(2 * gn_scratch_doubles(d->cout[i], d->gn_groups[i]));
-    }
-    p.total = off > 0 ? off : 64;
-    return STEMSEG_OK;
-}
-}  // namespace stemseg
-
-extern "C" size_t stemseg_hip_shared_convs_workspace_bytes(const StemsegSharedConvsDesc* desc) {
-    SharedPlan p;
-    if (make_shared_plan(desc, p) != STEMSEG_OK) return 0;
-    return (size_t)p.total * sizeof(float);
-}
-
-extern "C" int stemseg_hip_shared_convs_forward(const StemsegSharedConvsDesc* desc, const float* const conv_w[4], const float* const conv_b[4],
-                                                const float* const feats_haloed[4], void* workspace, size_t ws_bytes, float* conv_out[4],
-                                                float* stats_out[4], void* stream) {
-    SharedPlan p;
-    int rc = make_shared_plan(desc, p);
-    if (rc) return rc;
-    SS_CHECK_ARG(conv_w && conv_b && feats_haloed && workspace && conv_out && stats_out, "shared_convs_forward: null pointer");
-    SS_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 256 == 0, "shared_convs: workspace must be 256-byte aligned");
-    if (ws_bytes < (size_t)p.total * sizeof(float)) {
-        set_error("shared_convs: workspace too small (%zu < %zu bytes)", ws_bytes, (size_t)p.total * sizeof(float));
-        return STEMSEG_E_WORKSPACE;
-    }
-    hipStream_t s = as_stream(stream);
-    float* ws = reinterpret_cast<float*>(workspace);
-    ConvEpilogue e;
-    e.precision = desc->precision;
-    for (int i = 0; i < 4; ++i) {
-        conv_out[i] = nullptr; stats_out[i] = nullptr;
-        if (desc->cout[i] == 0) continue;
-        SS_CHECK_ARG(conv_w[i] && conv_b[i] && feats_haloed[i], "shared_convs_forward: null weight / bias / feature map of branch %d", i);
-        rc = launch_conv3d_gn(padded_halo_view(const_cast<float*>(feats_haloed[i]), desc->in_channels, desc->T, p.h[i], p.w[i]), conv_w[i], conv_b[i],
-                              dense_volume(ws + p.D[i], desc->cout[i], desc->T, p.h[i], p.w[i]), 3, 3, 3, 0, s, ws + p.S[i], p.Sfloats[i], &e,
-                              desc->gn_groups[i], desc->gn_eps, ws + p.stats[i], reinterpret_cast<double*>(ws + p.gn_scratch[i]));
-        if (rc) return rc;
-        conv_out[i] = ws + p.D[i];
-        stats_out[i] = ws + p.stats[i];
-    }
     return STEMSEG_OK;
 }

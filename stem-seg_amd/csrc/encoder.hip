@@ -42,9 +42,16 @@ static inline StemsegVolume interior2d_view(float* base, int C, int T, int H, in
 }
 static inline StemsegVolume flat_view(float* base, int C, int64_t V) { return make_volume(base, V, 0, 0, C, 1, 1, (int)V, (int64_t)C * V); }
 
-// ---- stem: conv 7x7 stride 2 pad 3 (3 -> 64) + bias + ReLU, direct VALU kernel (1 % of the encoder FLOPs) ----------
-// block = 8 x 64 output pixels of one frame, all 64 channels; thread = 2 pixels (x, x+32) x 64 channels.
-constexpr int ST_ROWS = 8, ST_COLS = 64, ST_PR = 2 * ST_ROWS + 5, ST_PC = 2 * ST_COLS + 5, ST_PCP = 136;
+// stem tile: 8 x 64 output pixels of one frame, all 64 channels
+constexpr int ST_ROWS = 8, ST_COLS = 64, ST_PR = 2 * ST_ROWS + 5, ST_PC = 2 * ST_COLS + 5;
+#ifdef SS_EXPERIMENTS
+constexpr int ST_PCP = 136;
+// ---- stem as a direct VALU kernel (rounds 1-3).  NOT in the product library: under several concurrently replaying hipGraphs a
+// few of its outputs per ~10^3 launches came back wrong -- 16 lanes of one accumulator register off by a product or two
+// (tools/soak_probe.py, DESIGN.md section 10: every one of 253 differing lane-rounds started here, none in an MFMA kernel).  The
+// mechanism is unknown: rebuilding it without the AGPR-parked accumulators of its first version changed nothing, two stand-alone
+// reproducers stay clean.  Built only with -DSS_EXPERIMENTS (STEMSEG_BUILD_DEFINES), where STEMSEG_STEM=valu selects it for the
+// probes that study the effect.  thread = 2 pixels (x, x+32) x 64 channels.
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(const float* __restrict__ frames, const float* __restrict__ w_tap_major,
                                                             const float* __restrict__ bias, float* __restrict__ out, int T, int H, int W) {
     __shared__ __attribute__((aligned(16))) float lds[3 * ST_PR * ST_PCP + 147 * 64];
@@ -72,11 +79,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(const float* __res
     const int py = threadIdx.x >> 5, px = threadIdx.x & 31;    // pixels (py, px) and (py, px + 32)
     const int oy = oy0 + py;
     const int64_t plane = (int64_t)Ho * Wo;
-    // Two passes of 32 output channels: 64 accumulators per pass stay in architectural VGPRs.  (The one-pass form -- 128
-    // accumulators -- made the register allocator park 20 of them in AGPRs (v_accvgpr_write / _read); under several HIP streams,
-    // i.e. with other kernels' MFMA waves on the same SIMDs, a few outputs of that kernel per ~10^3 launches came back with a
-    // stale partial sum, 16 lanes of one register at a time: tools/soak_probe.py, DESIGN.md section 10.  Same summation order,
-    // bit-identical results.)
+    // Two passes of 32 output channels: 64 accumulators per pass stay in architectural VGPRs (the one-pass form parked 20 of its
+    // 128 accumulators in AGPRs; both forms showed the wrong words, at the same rate: the parking is NOT the cause).
 #pragma unroll 1
     for (int hc = 0; hc < 2; ++hc) {
         float acc0[32], acc1[32];
@@ -113,16 +117,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_kernel(const float* __res
     }
 }
 
-// ---- stem on the matrix cores: the same 7x7 stride-2 convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32
+#endif  // SS_EXPERIMENTS
+
+// ---- stem on the matrix cores: the 7x7 stride-2 convolution (3 -> 64, + bias + ReLU) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32
 // products, fp32 accumulation).  M = 64 output channels, N = 8 rows x 64 columns of outputs per workgroup, K = 3 x 7 x 8 taps (the
 // eighth column tap is zero padding): an MFMA consumes TWO taps per issue -- lane half 0 an even dx, lane half 1 the odd dx next to
 // it -- so the input patch is staged DE-INTERLEAVED by column parity: plane p holds the input columns x = 2 i + p, and tap
 // (c, dy, dx = 2 q + p) of output column ox is plane[p][c][2 oy + dy][ox + q]: consecutive lanes read consecutive LDS words and
 // every tap is a compile-time immediate on one per-lane base (stride-2 reads of an interleaved patch would be 2-way bank
 // conflicts).  Four waves; wave w owns output rows 2w, 2w + 1 (four 32-column blocks) x both 32-channel halves: 8 accumulator
-// tiles, 6 LDS reads per 8 MFMAs.  Why it exists: the VALU form above is the step's only VALU-bound kernel, and under several HIP
-// streams a few of ITS outputs per ~10^3 launches came back wrong -- 16 lanes of one accumulator off by a product or two -- while
-// no MFMA convolution ever did (tools/soak_probe.py).  It is also 3x faster.
+// tiles, 6 LDS reads per 8 MFMAs.  (Through round 3 the stem was a VALU kernel -- the step's only VALU-bound one, and the only kernel
+// whose results were not bit-stable under concurrently replaying graphs; this form is also 1.5x faster.)
 constexpr int SM_PW = 68, SM_ROWS_IN = 2 * ST_ROWS + 6;          // plane row pitch (words); staged input rows (one spare for nothing: 21 used)
 constexpr int SM_PLANE = 3 * SM_ROWS_IN * SM_PW;                  // words per parity plane
 constexpr int SM_KSTEPS = 3 * 7 * 4;                              // (c, dy, q): two taps each
@@ -319,7 +324,10 @@ struct EncoderPlan {
     int h[4], w[4];            // 4x, 8x, 16x, 32x
     int64_t V[4];
     int64_t S0, X1, A, B, Cst[4], M1[4], M2, DS, XS, L[4], FO[4], SK, SKfloats, total;
+    int plan_frames;           // 0: launches decide on their real shape
+    int64_t plan_SKfloats;     // split-K scratch a planned launch may count on
 };
+constexpr int64_t ENC_PLAN_SK_FLOATS = 32ll << 20;
 
 static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     SS_CHECK_ARG(d, "encoder: null descriptor");
@@ -361,7 +369,11 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     // overlapping windows: the FPN output convs run ONCE over all frames into dense maps, each clip's window is then copied out
     const bool shared_out = d->clip_frames > 0 && d->clip_stride < d->clip_frames && d->n_clips > 1;
     for (int i = 0; i < 4; ++i) p.FO[i] = shared_out ? take(256 * p.V[i]) : -1;
-    p.SKfloats = 32ll << 20;
+    SS_CHECK_ARG(d->plan_frames >= 0 && d->plan_frames <= 4096, "encoder: plan_frames=%d", d->plan_frames);
+    p.plan_frames = d->plan_frames;
+    p.plan_SKfloats = ENC_PLAN_SK_FLOATS;
+    // a pass of more frames than planned keeps the plan's K-partition, so its slabs are T / plan_frames times the planned ones
+    p.SKfloats = ENC_PLAN_SK_FLOATS * (d->plan_frames > 0 ? std::max<int64_t>(1, ceil_div(d->T, d->plan_frames)) : 1);
     p.SK = take(p.SKfloats);
     p.total = off;
     return STEMSEG_OK;
@@ -409,11 +421,20 @@ extern "C" int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc
     return STEMSEG_OK;
 }
 
-// STEMSEG_STEM=valu selects the VALU form (A/B measurements, the co-residency probes); default: the MFMA form
+#ifdef SS_EXPERIMENTS
+// (experiment builds only) STEMSEG_STEM=valu selects the VALU form for the co-residency probes
 static bool stem_on_mfma() {
     static const bool on = [] { const char* e = getenv("STEMSEG_STEM"); return !(e && e[0] == 'v'); }();
     return on;
 }
+#define SS_LAUNCH_STEM(blocks, s, ...)                                                                                   \
+    do {                                                                                                                 \
+        if (stem_on_mfma()) hipLaunchKernelGGL(stem_conv7x7_mfma_kernel, dim3((unsigned)(blocks)), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL(stem_conv7x7_kernel, dim3((unsigned)(blocks)), dim3(256), 0, s, __VA_ARGS__);             \
+    } while (0)
+#else
+#define SS_LAUNCH_STEM(blocks, s, ...) hipLaunchKernelGGL(stem_conv7x7_mfma_kernel, dim3((unsigned)(blocks)), dim3(256), 0, s, __VA_ARGS__)
+#endif
 
 extern "C" int stemseg_hip_stem_conv(const float* frames, const float* w_tap_major, const float* bias, float* out, int32_t T, int32_t H, int32_t W,
                                      void* stream) {
@@ -422,8 +443,7 @@ extern "C" int stemseg_hip_stem_conv(const float* frames, const float* w_tap_maj
     const int Ho = H / 2, Wo = W / 2;
     const int64_t blocks = ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T;
     SS_CHECK_ARG(blocks < (1ll << 31), "stem_conv: too many tiles");
-    if (stem_on_mfma()) hipLaunchKernelGGL(stem_conv7x7_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), frames, w_tap_major, bias, out, T, H, W);
-    else hipLaunchKernelGGL(stem_conv7x7_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), frames, w_tap_major, bias, out, T, H, W);
+    SS_LAUNCH_STEM(blocks, as_stream(stream), frames, w_tap_major, bias, out, T, H, W);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
@@ -449,8 +469,16 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         SS_CHECK_ARG(wts->fpn_inner_w[i] && wts->fpn_inner_b[i] && wts->fpn_layer_w[i] && wts->fpn_layer_b[i], "encoder_forward: null FPN weights %d", i);
     }
     SS_CHECK_ARG(desc->out_channels == 256, "encoder: out_channels must be 256");
-    SS_CHECK_ARG(desc->precision >= 0 && desc->precision <= 3, "encoder: precision must be 0 (f32), 1 (bf16x3), 2 (bf16x6) or 3 (f16x3)");
+    SS_CHECK_ARG(desc->precision == STEMSEG_PRECISION_F32 || desc->precision == STEMSEG_PRECISION_BF16X6 || desc->precision == STEMSEG_PRECISION_F16X3,
+                 "encoder: precision must be 0 (f32), 2 (bf16x6) or 3 (f16x3)");
     const int prec = desc->precision;
+    // every convolution of the pass: this precision, and its launch decisions on the planning frame count (conv_igemm.hip, PlanCtx)
+    auto epi_for = [&](int frames) {
+        ConvEpilogue e;
+        e.precision = prec;
+        if (p.plan_frames > 0) { e.frames = frames; e.plan_frames = p.plan_frames; e.plan_scratch_floats = p.plan_SKfloats; }
+        return e;
+    };
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
     const int T = p.T;
@@ -460,8 +488,7 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         const int Ho = p.H / 2, Wo = p.W / 2;
         const int blocks = (int)(ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T);
         void* ev = profile_begin(47, 4.0 * ((double)3 * T * p.H * p.W + 64.0 * T * Ho * Wo), s);
-        if (stem_on_mfma()) hipLaunchKernelGGL(stem_conv7x7_mfma_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
-        else hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(blocks), dim3(256), 0, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        SS_LAUNCH_STEM(blocks, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
         profile_end(ev, s);
         SS_LAUNCH_CHECK();
         ev = profile_begin(48, 4.0 * 64.0 * T * ((double)Ho * Wo + (double)p.V[0] / T), s);
@@ -499,27 +526,26 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
                 xin = ws + p.XS;
             }
             float* y = (b == p.nblk[st] - 1) ? ws + p.Cst[st] : ((b & 1) ? ws + p.B : ws + p.A);
-            ConvEpilogue e1;                    // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
-            e1.relu = 1; e1.dec_H = h; e1.dec_W = w; e1.precision = prec;
+            ConvEpilogue e1 = epi_for(T);       // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
+            e1.relu = 1; e1.dec_H = h; e1.dec_W = w;
             rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1[st], mid, T, h, w), 1, 1, 1, 0, s,
                                ws + p.SK, p.SKfloats, &e1);
             if (rc) return rc;
-            ConvEpilogue e2;                    // conv2 (3x3) + bn2 + relu -> dense
-            e2.relu = 1; e2.precision = prec;
+            ConvEpilogue e2 = epi_for(T);       // conv2 (3x3) + bn2 + relu -> dense
+            e2.relu = 1;
             rc = launch_conv3d(halo2d_view(ws + p.M1[st], mid, T, h, w), wts->conv2_w[bi], wts->conv2_b[bi], dense_volume(ws + p.M2, mid, T, h, w), 1, 3, 3, 0, s,
                                ws + p.SK, p.SKfloats, &e2);
             if (rc) return rc;
             const float* idt = xin;
-            ConvEpilogue ed;
-            ed.precision = prec;
+            ConvEpilogue ed = epi_for(T);
             if (first) {                        // projection shortcut: 1x1 (stride folded into xin) + bn
                 rc = launch_conv3d(flat_view(xin, cin, V), wts->down_w[bi], wts->down_b[bi], flat_view(ws + p.DS, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats,
                                    &ed);
                 if (rc) return rc;
                 idt = ws + p.DS;
             }
-            ConvEpilogue e3;                    // conv3 + bn3 + identity + relu
-            e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0; e3.precision = prec;
+            ConvEpilogue e3 = epi_for(T);       // conv3 + bn3 + identity + relu
+            e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0;
             rc = launch_conv3d(flat_view(ws + p.M2, mid, V), wts->conv3_w[bi], wts->conv3_b[bi], flat_view(y, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats, &e3);
             if (rc) return rc;
             x = y;
@@ -529,8 +555,8 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
     // FPN (fpn.py:47-69), coarsest level first
     for (int k = 3; k >= 0; --k) {
         const int h = p.h[k], w = p.w[k];
-        ConvEpilogue e, el;
-        e.dec_H = h; e.dec_W = w; e.precision = prec; el.precision = prec;
+        ConvEpilogue e = epi_for(T), el = epi_for(T);
+        e.dec_H = h; e.dec_W = w;
         rc = launch_conv3d(flat_view(ws + p.Cst[k], 256 << k, p.V[k]), wts->fpn_inner_w[k], wts->fpn_inner_b[k], interior2d_view(ws + p.L[k], 256, T, h, w), 1, 1, 1, 0, s,
                            ws + p.SK, p.SKfloats, &e);
         if (rc) return rc;
@@ -562,7 +588,8 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             in.ptr += (int64_t)c * Ts * in.t_stride;
             in.limit -= (int64_t)c * Ts * in.t_stride;
             in.T = Tc;
-            rc = launch_conv3d(in, wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[4 * c + k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &el);
+            const ConvEpilogue ec = epi_for(Tc);
+            rc = launch_conv3d(in, wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[4 * c + k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &ec);
             if (rc) return rc;
         }
     }

@@ -1,5 +1,5 @@
 """The handful of configuration keys the hot path reads ('Config / flags'),
-with the three dataset presets of the reference (config/defaults.yaml, davis_1.yaml, youtube_vis.yaml,
+with the dataset presets of the reference (config/defaults.yaml, davis_1.yaml, davis_2.yaml, youtube_vis.yaml,
 kitti_mots_2.yaml).  ``cfg`` is a process-global like the reference's, but plain and mutable:
 decoder topology is fixed from ``cfg.INPUT.NUM_FRAMES`` at module construction (modeling/common.py:15-24).
 """
@@ -29,8 +29,9 @@ def _defaults():
 
 
 def _apply(c, preset):
-    if preset == "davis":           # config/davis_1.yaml (NUM_FRAMES 8; davis_2.yaml is the T=16 variant)
-        c.INPUT.MIN_DIM, c.INPUT.MAX_DIM, c.INPUT.NUM_FRAMES = 736, 1248, 8
+    if preset in ("davis", "davis_2"):   # config/davis_1.yaml (NUM_FRAMES 8) / davis_2.yaml (NUM_FRAMES 16: what inference/main.py:188-195 loads
+        # for --dataset davis when the checkpoint directory holds no config.yaml); the hot-path keys differ in NUM_FRAMES only
+        c.INPUT.MIN_DIM, c.INPUT.MAX_DIM, c.INPUT.NUM_FRAMES = 736, 1248, (16 if preset == "davis_2" else 8)
         c.MODEL.EMBEDDING_DIM_MODE, c.MODEL.USE_SEEDINESS_HEAD, c.MODEL.USE_SEMSEG_HEAD = "xyff", True, False
         c.MODEL.EMBEDDINGS.EMBEDDING_SIZE = 4
         c.TRAINING.LOSSES.EMBEDDING.FREE_DIM_STDS = [0.3, 0.3]
@@ -45,7 +46,7 @@ def _apply(c, preset):
         c.MODEL.EMBEDDING_DIM_MODE, c.MODEL.USE_SEEDINESS_HEAD, c.MODEL.USE_SEMSEG_HEAD = "xyt", False, True
         c.CLUSTERING.MIN_SEEDINESS_PROB = 0.95
     elif preset not in (None, "defaults"):
-        raise ValueError("unknown preset '%s' (davis | ytvis | kittimots | defaults)" % preset)
+        raise ValueError("unknown preset '%s' (davis | davis_2 | ytvis | kittimots | defaults)" % preset)
     return c
 
 

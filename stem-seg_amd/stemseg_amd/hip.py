@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Volume(C.Structure):
@@ -34,13 +34,7 @@ class DecoderDesc(C.Structure):
 class DecoderWeights(C.Structure):
     _fields_ = [("conv_w", C.c_void_p * 7), ("conv_b", C.c_void_p * 7), ("gn_w", C.c_void_p * 7), ("gn_b", C.c_void_p * 7),
                 ("fuse_w", C.c_void_p * 3), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
-                ("grid_t", C.c_void_p), ("grid_y", C.c_void_p), ("grid_x", C.c_void_p),
-                ("first_conv_out", C.c_void_p * 4), ("first_conv_stats", C.c_void_p * 4)]
-
-
-class SharedConvsDesc(C.Structure):
-    _fields_ = [("struct_bytes", C.c_int32), ("in_channels", C.c_int32), ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32),
-                ("precision", C.c_int32), ("cout", C.c_int32 * 4), ("gn_groups", C.c_int32 * 4), ("gn_eps", C.c_float)]
+                ("grid_t", C.c_void_p), ("grid_y", C.c_void_p), ("grid_x", C.c_void_p)]
 
 
 MAX_ENCODER_BLOCKS = 40
@@ -48,13 +42,14 @@ MAX_ENCODER_BLOCKS = 40
 
 class ConvEpilogue(C.Structure):
     _fields_ = [("relu", C.c_int32), ("residual", C.c_void_p), ("res_c_stride", C.c_int64), ("res_t_stride", C.c_int64),
-                ("res_y_stride", C.c_int64), ("decode_H", C.c_int32), ("decode_W", C.c_int32), ("precision", C.c_int32)]
+                ("res_y_stride", C.c_int64), ("decode_H", C.c_int32), ("decode_W", C.c_int32), ("precision", C.c_int32),
+                ("frames", C.c_int32), ("plan_frames", C.c_int32), ("plan_scratch_floats", C.c_int64)]
 
 
 class EncoderDesc(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("blocks", C.c_int32 * 4), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("out_channels", C.c_int32), ("precision", C.c_int32), ("n_clips", C.c_int32), ("clip_frames", C.c_int32),
-                ("clip_stride", C.c_int32)]
+                ("clip_stride", C.c_int32), ("plan_frames", C.c_int32)]
 
 
 _BLK = C.c_void_p * MAX_ENCODER_BLOCKS
@@ -94,10 +89,6 @@ SIGNATURES = {
     "stemseg_hip_profile_read": (C.c_int, [C.POINTER(C.c_double), _I32]),
     "stemseg_hip_padded_geometry": (C.c_int, [_I32, _I32, _I32, _I32, C.POINTER(_I64)]),
     "stemseg_hip_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
-    "stemseg_hip_packed_weight_bytes_bf16x3": (C.c_int64, [_I32, _I32, _I32]),
-    "stemseg_hip_pack_conv_weight_bf16x3": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
-    "stemseg_hip_packed_weight_bytes_split": (C.c_int64, [_I32, _I32, _I32, _I32]),
-    "stemseg_hip_pack_conv_weight_split": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "stemseg_hip_encoder_plan_offsets": (C.c_int, [_P, _P]),
     "stemseg_hip_packed_weight_bytes_prec": (C.c_int64, [_I32, _I32, _I32, _I32]),
     "stemseg_hip_pack_conv_weight_prec": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
@@ -118,9 +109,6 @@ SIGNATURES = {
     "stemseg_hip_decoder_init_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_forward": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(_P), _P, _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_join": (C.c_int, [_I32, _P]),
-    "stemseg_hip_shared_convs_workspace_bytes": (C.c_size_t, [C.POINTER(SharedConvsDesc)]),
-    "stemseg_hip_shared_convs_forward": (C.c_int, [C.POINTER(SharedConvsDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, C.c_size_t,
-                                                   C.POINTER(_P), C.POINTER(_P), _P]),
     "stemseg_hip_seediness_accumulate": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "stemseg_hip_fg_mask": (C.c_int, [_P, _F, _F, _P, _I64, _P]),
     "stemseg_hip_fg_mask_frames": (C.c_int, [_P, _P, _F, _P, _I32, _I64, _P]),
@@ -264,24 +252,31 @@ def pack_conv_weight(w):
     return out
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
+PRECISIONS = {"f32": 0, "bf16x6": 2, "f16x3": 3}
+# what the matrix products of a mode compute with (bench.py's ``dtype`` names these, never a bare "f32"):
+#   operand_significand_bits -- significand bits each fp32 operand keeps (fp32 has 24); products are exact, accumulation is fp32
+PRECISION_INFO = {
+    "f32": dict(operand_significand_bits=24, products_per_fp32_product=1, mfma="v_mfma_f32_32x32x2_f32", exponent_range="fp32"),
+    "bf16x6": dict(operand_significand_bits=24, products_per_fp32_product=6, mfma="v_mfma_f32_32x32x16_bf16", exponent_range="fp32"),
+    "f16x3": dict(operand_significand_bits=22, products_per_fp32_product=3, mfma="v_mfma_f32_32x32x16_f16",
+                  exponent_range="2.5e-4 <= |activation| < 2.6e5 at full width; beyond: non-finite output, flagged, re-run in bf16x6"),
+}
 # MFMA mode of every convolution unless a module's ``precision`` is set (InferenceModel.set_precision).  "f16x3" (default) =
 # operands scaled by powers of two and split into two fp16 terms, three products, fp32 accumulation; "bf16x6" = every fp32 operand
 # split EXACTLY into three bf16 terms, six products (fp32's full exponent range, twice the matrix work).  Both give fp32-level
 # results: error vs an fp64 convolution = that of the fp32-input MFMA kernel on every kernel class (tests/test_gpu_bf16x6.py),
-# labels identical on every reference flow.  "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands; "bf16x3" = two-term bf16 split
-# (~1e-4, opt-in).  STEMSEG_PRECISION overrides the default.
+# labels identical on every reference flow.  "f32" = v_mfma_f32_32x32x2_f32 on fp32 operands.  STEMSEG_PRECISION overrides the default.
 DEFAULT_PRECISION = os.environ.get("STEMSEG_PRECISION", "f16x3")
 assert DEFAULT_PRECISION in PRECISIONS, DEFAULT_PRECISION
 
 
 def pack_conv_weight_any(w, precision="f32"):
-    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA), 'bf16x3' (two bf16 terms per operand, 3 products), 'bf16x6'
-    (exact three-term split, 6 products: fp32-level results) or 'f16x3' (two fp16 terms of the power-of-two-scaled operands, 3
-    products: fp32-level results for |activation| < 2.6e5); fp32 accumulate throughout."""
+    """Pack for the given MFMA mode: 'f32' (exact fp32 MFMA), 'bf16x6' (exact three-term split, 6 products: fp32-level results) or
+    'f16x3' (two fp16 terms of the power-of-two-scaled operands, 3 products: fp32-level results for |activation| < 2.6e5); fp32
+    accumulate throughout."""
     if precision == "f32":
         return pack_conv_weight(w)
-    assert precision in ("bf16x3", "bf16x6", "f16x3"), precision
+    assert precision in ("bf16x6", "f16x3"), precision
     code = PRECISIONS[precision]
     w = w.contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
@@ -305,7 +300,8 @@ def stem_conv(frames, w, bias):
 
 
 def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None, epilogue=None):
-    """k: int (k x k x k) or a (kt, kh, kw) tuple; epilogue: dict(relu=, residual=tensor, res_strides=(c,t,y), decode=(H,W))."""
+    """k: int (k x k x k) or a (kt, kh, kw) tuple; epilogue: dict(relu=, residual=tensor, res_strides=(c,t,y), decode=(H,W),
+    precision=, plan=(frames, plan_frames, plan_scratch_floats): decide tile / split-K as if the launch held plan_frames frames)."""
     n = 0 if splitk_scratch is None else splitk_scratch.numel()
     kt, kh, kw = (k, k, k) if isinstance(k, int) else k
     e = None
@@ -318,6 +314,7 @@ def conv3d(vin, packed_w, bias, vout, k, tile_cfg=0, splitk_scratch=None, epilog
             e.res_c_stride, e.res_t_stride, e.res_y_stride = epilogue["res_strides"]
         e.decode_H, e.decode_W = epilogue.get("decode", (0, 0))
         e.precision = PRECISIONS[epilogue.get("precision", "f32")]
+        e.frames, e.plan_frames, e.plan_scratch_floats = epilogue.get("plan", (0, 0, 0))
     check(lib().stemseg_hip_conv3d(C.byref(vin), ptr(packed_w), ptr(bias), C.byref(vout), kt, kh, kw, tile_cfg,
                                    ptr(splitk_scratch), n, C.byref(e) if e is not None else None, stream()))
 
@@ -530,10 +527,7 @@ def read_cluster_meta(meta_dev, status=None):
     if sbuf is not None and bool(sbuf.any()):
         raise NonFiniteError("a head output of this clip holds inf / NaN (an operand left the convolution mode's range): not clustered "
                              "results -- re-run the clip with precision 'bf16x6'")
-    meta = ClusterMeta.from_buffer_copy(buf.numpy().tobytes())
-    if meta.K < 0:
-        raise RuntimeError("stemseg_hip_cluster: the one-launch clusterer's grid barrier timed out (STEMSEG_CLUSTER_PERSISTENT)")
-    return meta
+    return ClusterMeta.from_buffer_copy(buf.numpy().tobytes())
 
 
 def overlap_counts(labels_a, labels_b, lut_a, lut_b, Ka, Kb):

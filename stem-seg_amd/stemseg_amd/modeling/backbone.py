@@ -100,9 +100,16 @@ class ResNetFPN(nn.Module):
         self.body = _Body(self.stage_blocks)
         self.fpn = _FPN(out_channels)
         self.out_channels, self.is_3d = out_channels, False
-        self._packed, self._sig, self._ws = None, None, {}
-        self.precision = hip.DEFAULT_PRECISION    # "f32" | "bf16x3" (see stemseg_hip.h)
+        self._packed, self._ws = {}, {}           # precision -> (parameter signature, packed weights); workspaces by shape / lane
+        self.precision = hip.DEFAULT_PRECISION    # hip.PRECISIONS: "f16x3" | "bf16x6" | "f32"
         self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
+        # Every convolution of a pass decides its tile shape and split-K factor as if the pass held this many frames
+        # (StemsegEncoderDesc.plan_frames): a frame's maps are then bit-identical whether it passes alone, in a batch of clips or in
+        # the union of overlapping windows -- the K-partition of a split-K launch is a summation order, and the clusterer downstream is
+        # a chain of hard thresholds (clusterers.py:106-146).  32 = four 8-frame clips per pass, the shape bench.py and
+        # ClipPipeline.embed_many run; a job whose ranks must agree bit for bit keeps ONE value on all of them.  0: plan every pass on
+        # its own frame count (fastest for a lone small pass; results then depend on the batch).
+        self.plan_frames = 32
 
     # ---- FrozenBN folding: w' = w * scale[:, None, None, None], b' = shift (exact: eps == 0) -------------------
     def _signature(self):
@@ -136,9 +143,10 @@ class ResNetFPN(nn.Module):
         return f
 
     def _pack(self):
-        sig = (self._signature(), self.precision)
-        if self._sig == sig:
-            return self._packed
+        sig = self._signature()
+        hit = self._packed.get(self.precision)
+        if hit is not None and hit[0] == sig:      # (one packing per precision: an overflow re-run in bf16x6 keeps the f16x3 one)
+            return hit[1]
         hip.require_gpu()
         f = self.folded_state()
         keep = []                           # device tensors referenced by raw pointers below
@@ -166,8 +174,8 @@ class ResNetFPN(nn.Module):
         for k in (1, 2, 3, 4):
             w.fpn_inner_w[k - 1], w.fpn_inner_b[k - 1] = packed("fpn_inner%d" % k)
             w.fpn_layer_w[k - 1], w.fpn_layer_b[k - 1] = packed("fpn_layer%d" % k)
-        self._packed, self._sig = (w, keep), sig
-        return self._packed
+        self._packed[self.precision] = (sig, (w, keep))
+        return w, keep
 
     def _desc(self, T, H, W, n_clips=1, clip_frames=0, clip_stride=0):
         d = hip.EncoderDesc()
@@ -177,6 +185,7 @@ class ResNetFPN(nn.Module):
         d.T, d.H, d.W, d.out_channels = T, H, W, self.out_channels
         d.precision = hip.PRECISIONS[self.precision]
         d.n_clips, d.clip_frames, d.clip_stride = n_clips, clip_frames, clip_stride
+        d.plan_frames = int(self.plan_frames)
         return d
 
     @torch.no_grad()
@@ -197,7 +206,7 @@ class ResNetFPN(nn.Module):
         else:
             assert (n - 1) * window[1] + window[0] == T, "windows do not cover the pass"
             d = self._desc(T, H, W, n, int(window[0]), int(window[1]))
-        key = (T, H, W, frames.device.index, self.lane, None if window is None else (n, int(window[0]), int(window[1])))
+        key = (T, H, W, frames.device.index, self.lane, None if window is None else (n, int(window[0]), int(window[1])), int(self.plan_frames))
         ws = self._ws.get(key)
         if ws is None:
             nbytes = hip.lib().stemseg_hip_encoder_workspace_bytes(C.byref(d))

@@ -62,12 +62,12 @@ class SqueezeExpandTrunk(nn.Module):
         self.conv_16 = nn.Conv3d(c32 + c16, c16, 1, bias=False)
         self.conv_8 = nn.Conv3d(c16 + c8, c8, 1, bias=False)
         self.conv_4 = nn.Conv3d(c8 + c4, c4, 1, bias=False)
-        self._cache = {}          # packed weights keyed by parameter versions
+        self._cache = {}          # precision -> packed weights (valid while the parameter versions match)
         self._workspaces = {}     # (T, H4, W4, layout) -> (tensor, desc)
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
         self.detached = False     # True: the call does not join; ``join()`` must follow (twin-decoder overlap)
-        self.precision = hip.DEFAULT_PRECISION    # "f32": exact fp32 MFMA | "bf16x3": 3-term bf16 split MFMA with fp32 accumulation
+        self.precision = hip.DEFAULT_PRECISION    # hip.PRECISIONS: "f16x3" | "bf16x6" | "f32"
         self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
 
     # ---- to be provided by the concrete decoder ---------------------------------------------------
@@ -80,8 +80,10 @@ class SqueezeExpandTrunk(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _packed(self):
-        sig = (self._param_signature(), self.precision)
-        c = self._cache
+        # one packing per precision: an overflow re-run in bf16x6 (ClipPipeline.step_checked, GraphedStep.run_checked) must not
+        # throw the f16x3 packing away and pack it again on the way back
+        sig = self._param_signature()
+        c = self._cache.setdefault(self.precision, {})
         if c.get("sig") != sig:
             dev = next(self.parameters()).device
             conv_w, conv_b, gn_w, gn_b = [], [], [], []
@@ -124,10 +126,9 @@ class SqueezeExpandTrunk(nn.Module):
         hip.check(hip.lib().stemseg_hip_decoder_join(int(self.concurrency), hip.stream()))
 
     @torch.no_grad()
-    def run_hip(self, feats, input_layout=None, act_override=None, first=None):
+    def run_hip(self, feats, input_layout=None, act_override=None):
         """feats: 4 device tensors (32x,16x,8x,4x) for ONE sample: dense [C,T,h,w] (layout 0), dense [T,C,h,w]
         (layout 1) or zero-haloed flat buffers (layout 2, then T/H4/W4 must be given via ``feats_shape``).
-        ``first``: this decoder's slices of a SharedFirstConvs run -- ([conv output address | None] * 4, [stats address | None] * 4).
         Returns [n_out, T, H4, W4]."""
         hip.require_gpu()
         layout = self.input_layout if input_layout is None else input_layout
@@ -165,10 +166,6 @@ class SqueezeExpandTrunk(nn.Module):
         for i in range(3):
             w.fuse_w[i] = c["fuse"][i].data_ptr()
         w.head_w, w.head_b = c["head_w"].data_ptr(), c["head_b"].data_ptr()
-        if first is not None:
-            for i in range(4):
-                if first[0][i]:
-                    w.first_conv_out[i], w.first_conv_stats[i] = first[0][i], first[1][i]
         gt, gy, gx = self._grid(c, T, H4, W4, dev)
         if gt is not None:
             w.grid_t, w.grid_y, w.grid_x = gt.data_ptr(), gy.data_ptr(), gx.data_ptr()
@@ -176,96 +173,3 @@ class SqueezeExpandTrunk(nn.Module):
         fp = (C.c_void_p * 4)(*[b.data_ptr() for b in bufs])
         hip.check(hip.lib().stemseg_hip_decoder_forward(C.byref(d), C.byref(w), fp, hip.ptr(out), hip.ptr(ws), ws.numel(), hip.stream()))
         return out
-
-
-class SharedFirstConvs(object):
-    """block_32x.0 / block_16x.0 / block_8x.0 / block_4x.0 of decoders that read the same FPN maps (embedding_decoder.py:111-127,
-    seediness_decoder.py:92-108, semseg_decoder.py:96-112), run as ONE convolution per branch with the output channels concatenated
-    (stemseg_hip_shared_convs_forward).  A branch is shared when every decoder normalises with GroupNorm of the same channels per
-    group and the groups together are <= 64; the others run inside the decoders as before."""
-
-    _FIRST = (0, 3, 5, 6)                 # the branches' first convolutions in _BLOCK_CONVS order
-
-    def __init__(self, decoders):
-        self.decoders = list(decoders)
-        assert len(self.decoders) >= 2
-        self._cache, self._workspaces = {}, {}
-
-    def shared_branches(self):
-        ds = self.decoders
-        d0 = ds[0]
-        same = all(d.in_channels == d0.in_channels and d.num_frames == d0.num_frames and d.precision == d0.precision and d.gn_groups > 0
-                   and d.gn_eps == d0.gn_eps for d in ds)
-        out = []
-        for i in range(4):
-            cpg = [d.inter_channels[i] // d.gn_groups for d in ds] if same else [0, 1]
-            out.append(same and len(set(cpg)) == 1 and cpg[0] in (4, 8) and sum(d.gn_groups for d in ds) <= 64)
-        return out
-
-    def _packed(self, branches):
-        ds = self.decoders
-        sig = (tuple(d._param_signature() for d in ds), ds[0].precision, tuple(branches))
-        c = self._cache
-        if c.get("sig") != sig:
-            w, b = [], []
-            for i, k in enumerate(self._FIRST):
-                if not branches[i]:
-                    w.append(None)
-                    b.append(None)
-                    continue
-                convs = [getattr(d, _BLOCK_CONVS[k][0])[_BLOCK_CONVS[k][1]] for d in ds]
-                w.append(hip.pack_conv_weight_any(torch.cat([m.weight.detach().float() for m in convs], 0).contiguous(), ds[0].precision))
-                b.append(torch.cat([m.bias.detach().float() for m in convs], 0).contiguous())
-            c.clear()
-            c.update(sig=sig, w=w, b=b)
-        return c
-
-    @torch.no_grad()
-    def run(self, feats, lane=0):
-        """feats = ([zero-haloed 32x, 16x, 8x, 4x buffers], (T, H4, W4)) -- decoder input layout 2.  -> one ``first`` argument of
-        ``run_hip`` per decoder (None when no branch can be shared)."""
-        hip.require_gpu()
-        branches = self.shared_branches()
-        if not any(branches):
-            return [None] * len(self.decoders)
-        bufs, (T, H4, W4) = feats
-        ds = self.decoders
-        dev = bufs[0].device
-        c = self._packed(branches)
-        d = hip.SharedConvsDesc()
-        d.struct_bytes = C.sizeof(hip.SharedConvsDesc)
-        d.in_channels, d.T, d.H4, d.W4 = ds[0].in_channels, T, H4, W4
-        d.precision, d.gn_eps = hip.PRECISIONS[ds[0].precision], ds[0].gn_eps
-        for i in range(4):
-            d.cout[i] = sum(x.inter_channels[i] for x in ds) if branches[i] else 0
-            d.gn_groups[i] = sum(x.gn_groups for x in ds) if branches[i] else 0
-        key = (T, H4, W4, dev.index, lane, tuple(branches))
-        ws = self._workspaces.get(key)
-        if ws is None:
-            nbytes = hip.lib().stemseg_hip_shared_convs_workspace_bytes(C.byref(d))
-            if nbytes == 0:
-                raise RuntimeError("shared_convs: " + hip.lib().stemseg_hip_last_error().decode())
-            ws = self._workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        arr = C.c_void_p * 4
-        wp = arr(*[(t.data_ptr() if t is not None else None) for t in c["w"]])
-        bp = arr(*[(t.data_ptr() if t is not None else None) for t in c["b"]])
-        fp = arr(*[t.data_ptr() for t in bufs])
-        outp, statp = arr(), arr()
-        hip.check(hip.lib().stemseg_hip_shared_convs_forward(C.byref(d), wp, bp, fp, hip.ptr(ws), ws.numel(), outp, statp, hip.stream()))
-        firsts = []
-        ch = [0] * 4
-        g0 = 0
-        for x in ds:
-            o, st = [], []
-            for i in range(4):
-                if not branches[i]:
-                    o.append(None)
-                    st.append(None)
-                    continue
-                V = T * (H4 >> (3 - i)) * (W4 >> (3 - i))
-                o.append(outp[i] + 4 * ch[i] * V)
-                st.append(statp[i] + 4 * 2 * g0)
-                ch[i] += x.inter_channels[i]
-            g0 += x.gn_groups
-            firsts.append((o, st))
-        return firsts

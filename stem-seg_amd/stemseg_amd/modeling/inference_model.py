@@ -12,7 +12,6 @@ result, with three deliberate differences:
     again in the chainer).
 """
 import math
-import os
 from collections import namedtuple
 
 import numpy as np
@@ -24,7 +23,6 @@ from .. import config as _config
 from ..config import cfg
 from .embedding_utils import get_nb_free_dims  # noqa: F401  (re-export, as in the reference's import surface)
 from .model_builder import build_model
-from .decoder_base import SharedFirstConvs
 
 EmbeddingMapEntry = namedtuple("EmbeddingMapEntry", ["subseq_frames", "embeddings", "bandwidths", "seediness"])
 
@@ -79,11 +77,6 @@ class InferenceModel(nn.Module):
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
         self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
-        # the decoders' first-layer convolutions read the same FPN maps: one launch per branch with the channels concatenated
-        # (SharedFirstConvs).  Off by default: measured 99.7 vs 100.8 clips/s on the DAVIS pair -- the merged 4x-branch launch is 896
-        # one-per-CU workgroups = 3.5 -> 4 rounds of the 256 CUs, exactly the 2 x (1.75 -> 2) rounds of the separate launches.
-        self.share_first_convs = os.environ.get("STEMSEG_SHARE_FIRST_CONVS", "0") == "1"
-        self._shared, self._semseg_first = {}, {}
         self.lane = 0
         self.eval()
 
@@ -121,12 +114,21 @@ class InferenceModel(nn.Module):
                 mod.lane = self.lane
 
     def set_precision(self, precision):
-        """MFMA mode of every convolution: 'f16x3' (default), 'bf16x6', 'f32', 'bf16x3' (hip.PRECISIONS)."""
+        """MFMA mode of every convolution: 'f16x3' (default), 'bf16x6', 'f32' (hip.PRECISIONS)."""
         assert precision in hip.PRECISIONS, precision
         m = self._model
         for mod in (m.backbone, m.embedding_head, m.seediness_head, m.semseg_head):
             if mod is not None:
                 mod.precision = precision
+
+    def precisions(self):
+        """{module name: its MFMA mode} -- to put back with ``restore_precisions`` after a fallback re-run."""
+        m = self._model
+        return {n_: getattr(m, n_).precision for n_ in ("backbone", "embedding_head", "seediness_head", "semseg_head") if getattr(m, n_) is not None}
+
+    def restore_precisions(self, before):
+        for n_, v in before.items():
+            getattr(self._model, n_).precision = v
 
     # ---- one clip ----------------------------------------------------------------------------------
     def _padded_feature_buffers(self, T, H, W, dev, slot=0):
@@ -165,15 +167,6 @@ class InferenceModel(nn.Module):
         vols = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads, (32, 16, 8, 4))}
         m.backbone.run_backbone_into(frames, [vols[s] for s in (4, 8, 16, 32)])
         return self._run_heads(pads, T, H, W, dev)
-
-    def _shared_first(self, feats, decoders, slot):
-        """-> the ``first`` argument of each decoder's forward_single (None when sharing is off or no branch qualifies)."""
-        if not self.share_first_convs:
-            return [None] * len(decoders)
-        key = tuple(id(d) for d in decoders)
-        if key not in self._shared:
-            self._shared[key] = SharedFirstConvs(decoders)
-        return self._shared[key].run(feats, lane=(self.lane, slot))
 
     @torch.no_grad()
     def embed_frames_batch(self, frames, n_clips):
@@ -221,15 +214,9 @@ class InferenceModel(nn.Module):
         eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
         seed = None
         eh.concurrency = 1 if self.overlap_decoders else 0
-        # block_{32,16,8,4}x.0 of the decoders that will run on these maps, as one convolution per branch
-        twin = m.seediness_head if eh.seediness_channels == 0 else m.semseg_head
-        first_e, first_t = self._shared_first(feats, [eh, twin], slot) if twin is not None else (None, None)
-        self._semseg_first.pop((T, H, W, slot, self.lane), None)
-        if twin is m.semseg_head and first_t is not None:
-            self._semseg_first[(T, H, W, slot, self.lane)] = first_t                   # consumed by semseg_logits_clip of the same clip
         if eh.seediness_channels == 0 and not self.overlap_decoders:
             m.seediness_head.concurrency, m.seediness_head.detached = 0, False
-            seed = m.seediness_head.forward_single(feats, 2, first_t)
+            seed = m.seediness_head.forward_single(feats, 2)
             if self.resize_scale != 1.0:
                 seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
             main = None
@@ -240,9 +227,9 @@ class InferenceModel(nn.Module):
             assert m.seediness_head is not None
             sh = m.seediness_head
             sh.concurrency, sh.detached = 2, True
-            seed = sh.forward_single(feats, 2, first_t)
+            seed = sh.forward_single(feats, 2)
             main = sh
-        out = eh.forward_single(feats, 2, first_e)
+        out = eh.forward_single(feats, 2)
         E, Ev = eh.embedding_size, eh.variance_channels
         emb, bw = out[:E], out[E:E + Ev]
         if seed is None:
@@ -260,8 +247,7 @@ class InferenceModel(nn.Module):
         ``resize=False``: at the head's own resolution."""
         sh = self._model.semseg_head
         sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
-        first = self._semseg_first.pop((T, H, W, slot, self.lane), None)               # its first-layer convolutions ran beside the embedding decoder's
-        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2, first)
+        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2)
         if self.resize_scale != 1.0 and resize:
             logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return logits.contiguous()
@@ -357,14 +343,13 @@ class InferenceModel(nn.Module):
         # < 2.6e5) and answer an overflow with non-finite outputs, which every ReLU / pool on the way keeps.  A sequence whose head
         # outputs are not all finite is re-run ONCE in bf16x6 (fp32's exponent range); never hand NaN maps to the clusterer.
         if overflow and bool(torch.cat([o.reshape(-1) for o in overflow]).any().item()):
-            before = {n_: getattr(m, n_).precision for n_ in ("backbone", "embedding_head", "seediness_head", "semseg_head") if getattr(m, n_) is not None}
+            before = self.precisions()
             if self.overflow_fallback is None or all(v == self.overflow_fallback for v in before.values()):
                 raise hip.NonFiniteError("head outputs hold inf / NaN (convolution mode %s)" % sorted(set(before.values())))
             self.set_precision(self.overflow_fallback)
             try:
                 return self.forward(frames, subseq_idxes)
             finally:
-                for n_, v in before.items():
-                    getattr(m, n_).precision = v
+                self.restore_precisions(before)
         fg_masks, multiclass_masks = self.get_semseg_masks(acc, counts)
         return {"fg_masks": fg_masks, "multiclass_masks": multiclass_masks, "embeddings": maps, "clip_fg_logits": clip_fg_logits}

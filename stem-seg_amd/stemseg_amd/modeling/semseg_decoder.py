@@ -47,6 +47,6 @@ class SqueezeExpandDecoder(SqueezeExpandTrunk):
         return torch.stack([self.run_hip([f[n] for f in x], 0)[:self.out_channels] for n in range(x[0].shape[0])], 0)
 
     @torch.no_grad()
-    def forward_single(self, feats, input_layout, first=None):
+    def forward_single(self, feats, input_layout):
         """feats in the trunk's order (32x, 16x, 8x, 4x)."""
-        return self.run_hip(feats, input_layout, None, first)[:self.out_channels]
+        return self.run_hip(feats, input_layout, None)[:self.out_channels]

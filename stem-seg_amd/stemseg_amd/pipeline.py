@@ -8,8 +8,8 @@
   trunk once) AND clusters it with label_start = 1; two small all-gathers (RCCL over xGMI on the GPU box, gloo in the CPU tests)
   carry the foreground evidence (seediness planes, or the semseg head's foreground probability) and then one byte per voxel of
   clip-local label codes + the clustering records; the Hungarian chain runs on label-pair tables, so every rank ends with the
-  single-process result bit for bit.  ``run_sequence_replicated`` keeps the round-2 form (all head outputs gathered, chain
-  replicated) for A/B runs.
+  single-process result bit for bit -- embeddings included: the encoder plans its launches for a fixed frame count
+  (ResNetFPN.plan_frames), so a clip's maps do not depend on how many clips shared its encoder pass.
 """
 import torch
 
@@ -92,17 +92,15 @@ class ClipPipeline(object):
         try:
             return out, hip.read_cluster_meta(out["meta"], out["status"])
         except hip.NonFiniteError:
-            m = self.model._model
-            before = {name: getattr(m, name).precision for name in ("backbone", "embedding_head", "seediness_head", "semseg_head") if getattr(m, name) is not None}
+            before = self.model.precisions()
             if all(v == fallback_precision for v in before.values()):
                 raise
-            self.model.set_precision(fallback_precision)
+            self.model.set_precision(fallback_precision)        # (both packings stay cached: modules key them by precision)
             try:
                 out = self.step(frames)
                 return out, hip.read_cluster_meta(out["meta"], out["status"])
             finally:
-                for name, v in before.items():
-                    getattr(m, name).precision = v
+                self.model.restore_precisions(before)
 
     @torch.no_grad()
     def step_batch(self, frames, n_clips):
@@ -171,7 +169,8 @@ class ClipPipeline(object):
             return res
         full = [g for g in groups if len(g) == batch] if use_graph and batch > 1 else []
         if full:
-            key = (batch, T, stride if windows else 0, tuple(frames.shape[1:]), lanes, bool(with_fg_logits))
+            key = (batch, T, stride if windows else 0, tuple(frames.shape[1:]), lanes, bool(with_fg_logits), int(self.model._model.backbone.plan_frames),
+                   tuple(sorted(self.model.precisions().items())))
             cache = self.__dict__.setdefault("_embed_graphs", {})
             if key not in cache:
                 ex = frames[torch.as_tensor(pass_frames(full[0]), device=dev)].contiguous()
@@ -225,6 +224,7 @@ class GraphedStep(object):
             fn = pipe.embed if n_clips is None else (lambda x: pipe.model.embed_frames_batch(x.contiguous(), n_clips))
         if embed_fn is not None:
             fn = embed_fn
+        self._fn, self._overlap = fn, bool(overlap)
         prev = pipe.model.overlap_decoders
         pipe.model.overlap_decoders = bool(overlap)       # True = capture the fork/join branch streams too (experimental)
         try:
@@ -262,6 +262,35 @@ class GraphedStep(object):
 
     def wait(self):
         torch.cuda.current_stream(self.static_in.device).wait_stream(self.stream)
+
+    def collect(self, fallback_precision="bf16x6"):
+        """The consumer's read-back of this lane's last replay of a clustering step, with the overflow policy of
+        ``ClipPipeline.step_checked``: -> (list of step dicts, list of StemsegClusterMeta).  When a head output of one of the clips is
+        non-finite (an activation left the split convolution mode's range) the lane's batch -- its frames are still in the graph's
+        static input -- is run ONCE more, eagerly, in ``fallback_precision`` on this lane's own stream and workspaces, and those
+        results are returned (fresh tensors, not the graph's static ones); the model's mode is restored.  A production lane therefore
+        never hands out NaN maps and never just raises (``fallback_precision=None`` restores raising)."""
+        outs = self.out if isinstance(self.out, (list, tuple)) else [self.out]
+        with torch.cuda.stream(self.stream):
+            try:
+                return list(outs), [hip.read_cluster_meta(o["meta"], o.get("status")) for o in outs]
+            except hip.NonFiniteError:
+                model = self.pipe.model
+                before = model.precisions()
+                if fallback_precision is None or all(v == fallback_precision for v in before.values()):
+                    raise
+                prev = model.overlap_decoders
+                model.set_precision(fallback_precision)
+                model.set_lane(self.lane)
+                model.overlap_decoders = self._overlap
+                try:
+                    redo = self._fn(self.static_in)
+                    redo = list(redo) if isinstance(redo, (list, tuple)) else [redo]
+                    return redo, [hip.read_cluster_meta(o["meta"], o.get("status")) for o in redo]
+                finally:
+                    model.restore_precisions(before)
+                    model.overlap_decoders = prev
+                    model.set_lane(0)
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU
@@ -314,7 +343,9 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     import numpy as np
     from .inference.online_chainer import stitch_from_tables
     dist = comm if comm is not None else TorchComm(group)           # (comm: tests drive N "virtual ranks" in one process)
-    distributed = dist.world > 1
+    # the two collectives run whenever there is a group to run them on -- also a group of ONE (a world-1 RCCL group exercises the
+    # same device-tensor all-gathers as world 8: tests/test_gpu_nccl.py); without a process group the buffers are used in place
+    distributed = bool(getattr(dist, "active", dist.world > 1))
     rank, world = dist.rank, dist.world
     ops, clusterer = chainer.ops, chainer.clusterer
     r_scale = float(chainer.resize_scale)
@@ -341,20 +372,32 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
     if blocks:
         seed0 = blocks[0][2]
         dev, (hl, wl) = seed0.device, tuple(blocks[0][0].shape[-2:])
-        shape_info = [hl, wl, blocks[0][0].shape[0]]
-    if distributed and world > 1 and n_clips < world:     # some ranks own no clip: they learn the map size from the others
+        ev0 = blocks[0][3] if Cfg else seed0               # the planes all-gather #1 carries
+        shape_info = [hl, wl, blocks[0][0].shape[0], int(ev0.shape[-2]), int(ev0.shape[-1]), int(seed0.shape[-2]), int(seed0.shape[-1])]
+    if distributed and n_clips < world:                   # some ranks own no clip: they learn the map size from the others
         dev = _default_device() if not blocks else dev
-        info = torch.tensor(shape_info if shape_info else [0, 0, 0], dtype=torch.int64, device=dev)
+        info = torch.tensor(shape_info if shape_info else [0] * 7, dtype=torch.int64, device=dev)
         infos = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(infos, info)
         shape_info = next(i for i in infos if int(i[0]) > 0).tolist()
     hl, wl = int(shape_info[0]), int(shape_info[1])       # the heads' resolution
     E_dims = int(shape_info[2])
+    he, we = int(shape_info[3]), int(shape_info[4])       # resolution of the exchanged evidence planes
+    # A model with a SEPARATE seediness head resizes its seediness itself (inference_model.py:156; InferenceModel._run_heads), and the
+    # chainer then resizes embeddings, bandwidths AND seediness (online_chainer.py:127-140): under --resize_embeddings such a model's
+    # seediness ends up at r^2 times the embeddings' resolution and the reference's clustering fails on the size mismatch -- the
+    # reference only ever combines --resize_embeddings with in-head seediness (youtube_vis.yaml).  Same here, said clearly, instead of
+    # a reshape error or a silently different result.
+    seed_hw = (int(shape_info[5]), int(shape_info[6]))
+    if seed_hw != (hl, wl):
+        raise ValueError("run_sequence_sharded: the seediness planes arrive at %s but the embeddings at %s: a separate seediness head resizes its "
+                         "output itself (inference_model.py:156) and the chainer would resize it again (online_chainer.py:127-140) -- the reference "
+                         "fails on this combination too; use resize_scale 1 or a model with in-head seediness" % (seed_hw, (hl, wl)))
     Cg = Cfg if Cfg else 1
-    seeds_local = torch.zeros((per_rank, Cg, T, hl, wl), dtype=torch.float32, device=dev)
+    seeds_local = torch.zeros((per_rank, Cg, T, he, we), dtype=torch.float32, device=dev)
     for slot, blk in enumerate(blocks):
-        seeds_local[slot] = (blk[3] if Cfg else blk[2]).reshape(Cg, T, hl, wl)
-    if distributed and world > 1:
+        seeds_local[slot] = (blk[3] if Cfg else blk[2]).reshape(Cg, T, he, we)
+    if distributed:
         seeds_all = [torch.empty_like(seeds_local) for _ in range(world)]
         t_ag1 = _Timer(seeds_local)
         dist.all_gather(seeds_all, seeds_local)        # data-path collective #1 (RCCL over xGMI on the box)
@@ -409,7 +452,7 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
         codes_local[slot, T * hw + ops.meta_bytes()] = ops.overflow_byte(blocks[slot])
 
     # ---- 4. all-gather #2: label codes + clustering records -------------------------------------------------------------
-    if distributed and world > 1:
+    if distributed:
         codes_all = torch.empty((world, per_rank, P * hw), dtype=torch.uint8, device=dev)
         t_ag2 = _Timer(codes_local)
         dist.all_gather_into_tensor(codes_all, codes_local)            # data-path collective #2
@@ -444,8 +487,6 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
             raise hip.NonFiniteError("clip %d (rank %d): a head output holds inf / NaN (an operand left the convolution mode's range) -- "
                                      "re-run the sequence with precision 'bf16x6'" % (ci, owner))
         m_ = ops.unpack_meta(row[:-1].tobytes())
-        if int(m_.K) < 0:                                   # (the opt-in one-launch clusterer reports a timed-out grid barrier as K = -1)
-            raise RuntimeError("clip %d (rank %d): the clusterer reported K = %d (STEMSEG_CLUSTER_PERSISTENT grid barrier timed out)" % (ci, owner, int(m_.K)))
         # (labels are i + label_start with i < K: with K <= max_instances every code is <= B - 2, so the out-of-range clamp of
         # labels_to_codes_kernel cannot be reached -- checked here rather than trusted)
         assert int(m_.K) <= clusterer.max_instances, "clip %d: K = %d exceeds max_instances = %d" % (ci, int(m_.K), clusterer.max_instances)
@@ -507,7 +548,8 @@ def run_sequence_sharded(n_frames, embed_clip_fn, chainer, dataset_name="davis",
         ag1_ms, ag2_ms = (t_ag1.elapsed() if t_ag1 else 0.0), (t_ag2.elapsed() if t_ag2 else 0.0)     # (events long complete: no extra sync)
         stats.update(allgather_ms=ag1_ms + ag2_ms, allgather_seediness_ms=ag1_ms, allgather_codes_ms=ag2_ms, host_chain_ms=host_ms,
                      allgather_bytes=(seeds_local.numel() * 4 + codes_local.numel()) * (world - 1) if world > 1 else 0,
-                     n_clips=n_clips, clips_this_rank=len(mine), world=world)
+                     n_clips=n_clips, clips_this_rank=len(mine), world=world, collectives_run=2 if distributed else 0,
+                     backend=getattr(dist, "backend", None), comm_calls=dict(getattr(dist, "calls", {})))
     return (track, counts, lifetimes), mask_idxes, subseq_labels, [], subseq_meta
 
 
@@ -519,16 +561,22 @@ class TorchComm(object):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         on = dist.is_available() and dist.is_initialized()
+        self.active = on                                              # a process group exists (possibly of one rank)
         self.rank = dist.get_rank(group) if on else 0
         self.world = dist.get_world_size(group) if on else 1
+        self.backend = dist.get_backend(group) if on else None
+        self.calls = {"all_gather": 0, "all_gather_into_tensor_nccl": 0, "all_gather_into_tensor_list": 0}
 
     def all_gather(self, outs, t):
+        self.calls["all_gather"] += 1
         self.dist.all_gather(outs, t.contiguous(), group=self.group)
 
     def all_gather_into_tensor(self, out, t):
-        if t.is_cuda and self.dist.get_backend(self.group) == "nccl":
+        if t.is_cuda and self.backend == "nccl":
+            self.calls["all_gather_into_tensor_nccl"] += 1
             self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         else:                                                          # (gloo: list form)
+            self.calls["all_gather_into_tensor_list"] += 1
             parts = [torch.empty_like(t) for _ in range(self.world)]
             self.dist.all_gather(parts, t.contiguous(), group=self.group)
             for r, p_ in enumerate(parts):
@@ -560,86 +608,6 @@ class _Timer(object):
             self.e1.synchronize()
             return self.e0.elapsed_time(self.e1)
         return self.ms
-
-
-@torch.no_grad()
-def run_sequence_replicated(n_frames, embed_clip_fn, chainer, dataset_name="davis", frame_overlap=-1, seediness_thresh=0.25,
-                         fg_mask_fn=None, group=None, stats=None, embed_many_fn=None, channel_split=None):
-    """Round-2 partitioning, kept for A/B runs and as the cross-check of the clip-parallel chain: only the EMBEDDING is sharded;
-    every rank receives all [E+Ev+1, T, h4, w4] head outputs and replicates fg mask + clustering + stitching for all clips.
-    embed_clip_fn(frame_indices) -> (emb [E,T,h,w], bw [Ev,T,h,w], seed [1,T,h,w]) on this rank's device; or
-    embed_many_fn(list of this rank's clips) -> list of stacked [E+Ev+1,T,h,w] blocks (e.g. ClipPipeline.embed_many: several clips
-    per encoder pass) together with channel_split = (E, Ev).
-    Returns OnlineChainer.process(...) output, identical on every rank.  ``stats`` (dict, optional) receives the exchange's
-    size and duration: ``allgather_bytes`` (payload received per rank), ``allgather_ms`` (device time of the collective on
-    this rank), ``n_clips``, ``clips_this_rank``."""
-    import time
-    import torch.distributed as dist
-    distributed = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if distributed else 0
-    world = dist.get_world_size(group) if distributed else 1
-    clips, _ = get_subsequence_frames(n_frames, cfg.INPUT.NUM_FRAMES, dataset_name, frame_overlap)
-    mine = shard_clips(len(clips), rank, world)
-    per_rank = (len(clips) + world - 1) // world
-    packed = None
-    E = Ev = None
-    if embed_many_fn is not None and mine:
-        E, Ev = channel_split
-        blocks = embed_many_fn([clips[ci] for ci in mine])
-        packed = torch.zeros((per_rank,) + tuple(blocks[0].shape), dtype=blocks[0].dtype, device=blocks[0].device)
-        for slot, blk in enumerate(blocks):
-            packed[slot] = blk
-    for slot, ci in enumerate(mine if embed_many_fn is None else []):
-        emb, bw, seed = embed_clip_fn(clips[ci])
-        if packed is None:
-            E, Ev = emb.shape[0], bw.shape[0]
-            packed = torch.zeros((per_rank, E + Ev + seed.shape[0]) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device)
-        packed[slot, :E], packed[slot, E:E + Ev], packed[slot, E + Ev:] = emb, bw, seed
-    ag_ms, ag_bytes = 0.0, 0
-    if distributed and world > 1:
-        if len(clips) < world:
-            # some ranks own no clip: they learn the block shape and the channel split from the others (tiny exchange)
-            dev = packed.device if packed is not None else _default_device()
-            info = torch.tensor((list(packed.shape) + [E, Ev]) if packed is not None else [0] * 7, dtype=torch.int64, device=dev)
-            infos = [torch.zeros_like(info) for _ in range(world)]
-            dist.all_gather(infos, info, group=group)
-            full = next(i for i in infos if int(i[0]) > 0).tolist()
-            E, Ev = int(full[5]), int(full[6])
-            if packed is None:
-                packed = torch.zeros(full[:5], dtype=torch.float32, device=dev)
-        gathered = [torch.empty_like(packed) for _ in range(world)]
-        on_gpu = packed.is_cuda
-        if on_gpu:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        else:
-            t0 = time.perf_counter()
-        dist.all_gather(gathered, packed.contiguous(), group=group)     # THE data-path collective (RCCL over xGMI on the box)
-        if on_gpu:
-            e1.record()
-            e1.synchronize()
-            ag_ms = e0.elapsed_time(e1)
-        else:
-            ag_ms = 1e3 * (time.perf_counter() - t0)
-        ag_bytes = packed.numel() * packed.element_size() * (world - 1)
-    else:
-        gathered = [packed]
-    if stats is not None:
-        stats.update(allgather_ms=ag_ms, allgather_bytes=ag_bytes, n_clips=len(clips), clips_this_rank=len(mine), world=world)
-    entries = []
-    for ci, frames in enumerate(clips):
-        owner, slot = clip_owner(ci, len(clips), world)
-        blk = gathered[owner][slot]
-        uniq = sorted(set(frames))
-        if len(uniq) != len(frames):
-            sel = torch.as_tensor([max(j for j, v in enumerate(frames) if v == t) for t in uniq], device=blk.device)
-            blk = blk[:, sel]
-        entries.append(EmbeddingMapEntry(uniq, blk[:E], blk[E:E + Ev], blk[E + Ev:]))
-    fg_fn = fg_mask_fn if fg_mask_fn is not None else fg_masks_from_seediness
-    fg = fg_fn(entries, seediness_thresh)
-    dicts = [{"frames": e.subseq_frames, "embeddings": e.embeddings, "bandwidths": e.bandwidths, "seediness": e.seediness}
-             for e in entries]
-    return chainer.process(fg, dicts)
 
 
 def _default_device():

@@ -89,10 +89,7 @@ def _worker(rank, world, port, tag, fn_name, q):
     try:
         ok, calls, clustered, mine, n_clips = _run(tag, fn_name)
         ok = ok and calls == mine                                         # each rank embedded only its own clips
-        if fn_name == "run_sequence_sharded":
-            ok = ok and clustered == [1] * len(mine)                      # ... and clustered only those, with label_start = 1
-        else:
-            ok = ok and len(clustered) == n_clips                         # (round-2 partitioning: the chain is replicated)
+        ok = ok and clustered == [1] * len(mine)                          # ... and clustered only those, with label_start = 1
         q.put((rank, bool(ok), len(calls), len(clustered)))
     finally:
         dist.destroy_process_group()
@@ -150,9 +147,29 @@ def test_virtual_ranks_in_one_process(world, tag):
     assert [r[1] for r in res] == [r[3] for r in res] and all(r[2] == [1] * len(r[3]) for r in res)
 
 
-def test_replicated_partitioning_still_matches_two_ranks_gloo():
-    """The round-2 form (only the embedding sharded, chain replicated) stays available as the cross-check."""
-    _spawn(2, "seq20_ov4", "run_sequence_replicated")
+def test_world_1_process_group_runs_both_collectives_gloo():
+    """A process group of ONE rank still runs the two exchanges (what tests/test_gpu_nccl.py does with RCCL on the GPU box)."""
+    res = _spawn(1, "seq14_ov6")
+    assert res[0][2] == 4 and res[0][3] == 4
+
+
+def test_sharded_path_refuses_pre_resized_seediness_with_a_clear_message():
+    """a model with a SEPARATE seediness head resizes its seediness itself under --resize_embeddings
+    (inference_model.py:156); the chainer would resize it again (online_chainer.py:127-140) and the reference fails on the size
+    mismatch.  The sharded driver says so instead of failing in a reshape (or resizing twice)."""
+    from stemseg_amd import config, pipeline
+    from stemseg_amd.inference.clusterers import SequentialClustering
+    from stemseg_amd.inference.online_chainer import OnlineChainer
+    from tests.oracle_ops import OracleChainerOps
+    emb, bw, sd, fg, clips, overlap, _ = _case("seq20_ov4")
+    config.load_preset("davis")
+    chainer = OnlineChainer(SequentialClustering(0.5, 0.3, 0.8, 2, [0.3, 0.3], "cpu"), 2.0, ops=OracleChainerOps())
+
+    def embed(fr):                                          # seediness already x2, as InferenceModel._run_heads hands it out
+        s2 = torch.from_numpy(sd[:, fr].copy()).repeat_interleave(2, -1).repeat_interleave(2, -2)
+        return torch.from_numpy(emb[:, fr].copy()), torch.from_numpy(bw[:, fr].copy()), s2
+    with pytest.raises(ValueError, match="separate seediness head"):
+        pipeline.run_sequence_sharded(fg.shape[0], embed, chainer, "davis", frame_overlap=overlap)
 
 
 def test_shard_clips_contiguous_blocks():

@@ -125,43 +125,6 @@ def test_conv3d_k1(hip, cfg, shape):
     assert report("conv3d_k1 cfg%d %s" % (cfg, shape), out.cpu().numpy(), ref.numpy()) <= 2e-4
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
-@pytest.mark.parametrize("kind", ["k3", "k2", "k1"])
-def test_conv_bf16x3_split_mfma(hip, kind, cfg):
-    """bf16x3 mode (x = hi + lo in bf16; a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix cores, fp32 accumulate):
-    every kernel class and tile shape vs the fp32 torch reference, same tolerance as the exact-fp32 kernels."""
-    rs = 31 + cfg
-    if kind == "k1":
-        if cfg == 3:
-            pytest.skip("1x1 has two tile shapes")
-        Cin, Cout, V = 256, 128, 4 * 30 * 54
-        x = _rand((Cin, V), rs)
-        w = _rand((Cout, Cin, 1, 1, 1), rs + 1, 1.0 / np.sqrt(Cin))
-        b = _rand((Cout,), rs + 2)
-        ref = (torch.from_numpy(w.reshape(Cout, Cin)) @ torch.from_numpy(x) + torch.from_numpy(b)[:, None]).numpy()
-        out = torch.full((Cout, V), float("nan"), device="cuda")
-        hip.conv3d(hip.flat_volume(dev(x)), hip.pack_conv_weight_any(dev(w), "bf16x3"), dev(b), hip.flat_volume(out), 1, cfg, None, dict(precision="bf16x3"))
-    else:
-        Cin, Cout, T, H, W = (64, 128, 3, 9, 40) if kind == "k3" else (64, 128, 2, 17, 70)
-        x = _rand((Cin, T, H, W), rs)
-        kt = 3 if kind == "k3" else 1
-        w = _rand((Cout, Cin, kt, 3, 3), rs + 1, 1.0 / np.sqrt(Cin * 9 * kt))
-        b = _rand((Cout,), rs + 2)
-        ref = F.conv3d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), padding=(kt // 2, 1, 1))[0].numpy()
-        if kind == "k3":
-            buf, g = hip.alloc_padded(Cin, T, H, W)
-            hip.copy_to_volume(dev(x), 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
-            vin = hip.padded_halo_view(buf, g, Cin, T, H, W)
-        else:
-            pitch = (W + 2 + 3) // 4 * 4
-            buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
-            buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
-            vin = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel())
-        out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
-        hip.conv3d(vin, hip.pack_conv_weight_any(dev(w), "bf16x3"), dev(b), hip.dense_volume(out), (kt, 3, 3), cfg, None, dict(precision="bf16x3"))
-    assert report("conv %s bf16x3 cfg%d" % (kind, cfg), out.cpu().numpy(), ref) <= 2e-4
-
-
 @pytest.mark.parametrize("shape", [(8, 64, 2, 9, 37), (64, 64, 3, 17, 40), (256, 256, 2, 6, 27), (128, 128, 8, 30, 54)])
 def test_conv2d_3x3_fused_epilogue(hip, shape):
     """(1,3,3) conv over every t-plane (= the encoder's frames) with bias + ReLU fused, zero-haloed 2-D input."""
@@ -208,35 +171,6 @@ def test_conv1x1_flat_decode_residual_relu(hip, shape):
         assert float(halo.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", [("k1", 256, 256, 2, 30, 54), ("k1", 40, 128, 1, 7, 33), ("k1", 1024, 256, 4, 30, 54), ("k2", 256, 256, 4, 30, 54), ("k2", 64, 128, 2, 9, 50)])
-def test_conv_224_wide_tiles(hip, case):
-    """The 7-segment (224-position) tiles the launcher picks when they divide a launch into fewer rounds of the chip -- forced
-    here with tile_cfg = 4: 1x1 (direct-to-LDS form, and the register-staged form when Cin % 16 != 0) with residual + ReLU, and the
-    flat 1x3x3 tile on zero-haloed planes of pitch 56; with and without split-K."""
-    kind, Cin, Cout, T, H, W = case
-    b = _rand((Cout,), 33)
-    if kind == "k1":
-        V = T * H * W
-        x, w, r = _rand((Cin, V), 31), _rand((Cout, Cin, 1, 1), 32, 1.0 / np.sqrt(Cin)), _rand((Cout, V), 34)
-        ref = F.relu(torch.from_numpy(w.reshape(Cout, Cin)) @ torch.from_numpy(x) + torch.from_numpy(b)[:, None] + torch.from_numpy(r)).numpy()
-        xd, rd, wd = dev(x), dev(r), hip.pack_conv_weight(dev(w))
-        for sk in (None, torch.empty(8 * Cout * V, device="cuda")):
-            out = torch.full((Cout, V), float("nan"), device="cuda")
-            hip.conv3d(hip.flat_volume(xd), wd, dev(b), hip.flat_volume(out), 1, 4, sk, dict(relu=1, residual=rd, res_strides=(V, 0, 0)))
-            assert report("conv1x1 224-tile %s splitk=%s" % (case, sk is not None), out.cpu().numpy(), ref) <= 2e-4
-    else:
-        x, w = _rand((Cin, T, H, W), 31), _rand((Cout, Cin, 3, 3), 32, 1.0 / np.sqrt(Cin * 9))
-        ref = F.relu(F.conv2d(torch.from_numpy(x).permute(1, 0, 2, 3), torch.from_numpy(w), torch.from_numpy(b), padding=1)).permute(1, 0, 2, 3).numpy()
-        pitch = (W + 2 + 3) // 4 * 4
-        buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
-        buf[:, :, 1:H + 1, 1:W + 1] = dev(x)
-        vin = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel())
-        for sk in (None, torch.empty(8 * Cout * T * H * W, device="cuda")):
-            out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
-            hip.conv3d(vin, hip.pack_conv_weight(dev(w)), dev(b), hip.dense_volume(out), (1, 3, 3), 4, sk, dict(relu=1))
-            assert report("conv2d 224-tile %s splitk=%s" % (case, sk is not None), out.cpu().numpy(), ref) <= 2e-4
-
-
 @pytest.mark.parametrize("btype", ["R-50-FPN", "R-101-FPN"])
 def test_encoder_vs_golden(hip, golden, btype):
     """HIP encoder (stem, bottlenecks with fused epilogues, FPN) vs the reference's outputs (golden) and the oracle."""
@@ -259,7 +193,7 @@ def test_encoder_vs_golden(hip, golden, btype):
         assert report("encoder %s 1/%d (rel to max %.3g)" % (btype, s, scale), got / scale, ref / scale) <= 1e-4
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_encoder_batch_of_8_odd_size_vs_oracle(hip, precision):
     """T = 8 frames, 96 x 160 (w32 = 5: ragged 32-column tiles everywhere), R-50, vs the CPU oracle."""
     from stemseg_amd.modeling.backbone import ResNetFPN
@@ -488,7 +422,7 @@ def test_seediness_decoder_vs_golden(hip, golden, T):
     assert np.array_equal(a, b), "decoder is not run-to-run deterministic"
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_decoder_full_size_480x864_vs_oracle(hip, precision):
     """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle, both MFMA modes."""
     T, h32, w32 = 8, 15, 27
@@ -536,8 +470,8 @@ def test_graphed_step_equals_eager(hip):
 
 def test_step_batch_shares_the_encoder_pass(hip):
     """ClipPipeline.step_batch: 3 clips through ONE encoder call (n_clips = 3 in the encoder descriptor, each clip's FPN maps
-    written into its own zero-haloed buffers) == the clips one by one.  Split-K partitions depend on the launch size, so floats
-    may differ in the last bits (<= 1e-5); labels are compared where the single-clip decision has margin."""
+    written into its own zero-haloed buffers) == the clips one by one, BIT FOR BIT: every launch of the encoder decides its tile and
+    split-K factor for the planning frame count, not for the frames that happen to share the pass."""
     from stemseg_amd import config
     from stemseg_amd.modeling.inference_model import InferenceModel
     from stemseg_amd.pipeline import ClipPipeline
@@ -558,13 +492,8 @@ def test_step_batch_shares_the_encoder_pass(hip):
         outs = pipe.step_batch(torch.cat(clips, 0), 3)
         assert len(outs) == 3
         for i, (o, r) in enumerate(zip(outs, single)):
-            assert report("batch clip %d emb" % i, o["emb"].cpu().numpy(), r["emb"].cpu().numpy()) <= 1e-5
-            # (the x40 gain on the seediness logits of this test amplifies the last-bit differences of the trunk)
-            assert report("batch clip %d seed" % i, o["seed"].cpu().numpy(), r["seed"].cpu().numpy()) <= 5e-4
-            if torch.equal(o["fg"], r["fg"]):
-                same = (o["labels"] == r["labels"]).float().mean().item()
-                print("[parity] batch clip %d: %.4f of labels identical" % (i, same))
-                assert same > 0.999
+            for k in ("emb", "bw", "seed", "fg", "labels"):
+                assert torch.equal(o[k], r[k]), "batch clip %d: %s differs from the clip stepped on its own" % (i, k)
         g = pipe.capture(torch.cat(clips, 0), n_clips=3)
         outs2 = g.run(torch.cat(clips, 0))
         for o, r in zip(outs2, outs):
@@ -639,7 +568,7 @@ def _semseg_head(ncls, fg, ws, inter=(128, 128, 64, 64)):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("name", ["sem_bin", "sem_kitti", "sem_ytvis"])
 def test_semseg_decoder_vs_golden(hip, golden, name, precision):
     """2 / 3+1 channels go through the fused heads kernel, 40+1 through the 1x1x1 MFMA conv (zero-padded to 64 rows)."""
@@ -1178,7 +1107,7 @@ def test_inference_model_vs_golden(hip, golden):
     config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_config0_vs_reference_cpu_path(hip, golden, precision):
     """BASELINE configs[0] -- one synthetic 8 x 256 x 448 clip, random-init ResNet-50 -- through the whole HIP path (uint8 frames
     -> pre-processing -> encoder -> decoders -> fg mask -> gather -> clustering -> chainer) against what the REFERENCE itself
@@ -1199,7 +1128,7 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         msd = model._model.state_dict()
         model._model.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])).reshape(msd[k].shape) for k in msd})
         model = model.cuda()
-        model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
+        model.set_precision(precision)
         exact = precision in ("f32", "bf16x6", "f16x3")        # the split modes with fp32-level error are held to the fp32 standard
         tg = TrackGenerator(model, "davis", seediness_thresh=thr, frame_overlap=4)
         embeddings, fg, _ = tg.do_inference([f for f in frames])
@@ -1219,11 +1148,8 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         agree = float((ref_lab[both] == got_lab[both]).mean())
         print("[parity] config0 vs reference: fg %d vs %d (%d pixels differ), %d instances vs %d, labels identical on %.4f of the common fg"
               % (got_fg.sum(), ref_fg.sum(), (got_fg != ref_fg).sum(), len(meta[0]["instance_labels"]), len(g["instance_labels"]), agree))
-        print("[bf16x3-labels] config0 %s: fg differs in %d pixels, label agreement %.5f, instance list %s"
+        print("[labels] config0 %s: fg differs in %d pixels, label agreement %.5f, instance list %s"
               % (precision, (got_fg != ref_fg).sum(), agree, "identical" if meta[0]["instance_labels"] == g["instance_labels"].tolist() else "DIFFERENT"))
-        # bf16x3 (measured): maps within 8e-5, 1 fg pixel flips, same 20 instances -- but 8.6 % of the points change instance.  With
-        # random-init weights the clusters of this fixture overlap, and a 1e-4 perturbation moves seeds / boundary points: the
-        # opt-in mode is NOT label-exact on such inputs (on the structured YT-VIS / KITTI fixtures it is, see below)
         if exact:
             # exact-or-in-band: a foreground pixel may differ from the reference only where the seediness sits within
             # 1e-4 of the threshold (two fp32 pipelines' maps agree to ~3e-5 here), and every label on the common foreground is identical
@@ -1238,7 +1164,7 @@ def test_config0_vs_reference_cpu_path(hip, golden, precision):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_ytvis_flow_vs_reference(hip, golden, precision):
     """BASELINE configs[2] flow (reduced size) vs the REFERENCE's own CPU result (tests/golden/model_ytvis.npz): YouTube-VIS preset
     -- 7-channel embedding head with in-head seediness, 40+1-channel semseg head (inter [256]*4, wide head on the MFMA conv),
@@ -1259,7 +1185,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 6.0
         model._model.load_state_dict(new)
         model = model.cuda()
-        model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
+        model.set_precision(precision)
         exact = precision in ("f32", "bf16x6", "f16x3")        # the split modes with fp32-level error are held to the fp32 standard
         frames = synth.synth_frames(12, 96, 128, seed=81)
         tg = TrackGenerator(model, "ytvis", resize_scale=4.0, frame_overlap=4)
@@ -1286,7 +1212,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         # (the fixture keeps the seediness sigmoid out of saturation: a plateau of exact 1.0 values, once resized x4, leaves the
         #  round's arg-max to last-bit differences between any two fp32 resamplers -- measured 3.6 % label differences with a x30
         #  gain, against the reference AND against the CPU oracle alike -- and a different, equally good seed moves the boundary)
-        print("[bf16x3-labels] ytvis %s: fg differs in %d pixels, label agreement %.5f" % (precision, (got_fg != ref_fg).sum(), agree))
+        print("[labels] ytvis %s: fg differs in %d pixels, label agreement %.5f" % (precision, (got_fg != ref_fg).sum(), agree))
         assert (got_fg != ref_fg).mean() < 1e-3 and agree >= (0.999 if exact else 0.99)
         for i in range(2):
             assert meta[i]["instance_labels"] == g["c%d_instance_labels" % i].tolist()
@@ -1306,7 +1232,7 @@ def test_ytvis_flow_vs_reference(hip, golden, precision):
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_kitti_flow_vs_reference(hip, golden, precision):
     """KITTI-MOTS preset ('xyt' embeddings: the time coordinate is an embedding dimension, no free dims; in-head seediness; 3+1
     channel semseg head through the fused heads kernel) at a reduced wide-aspect size, 14 frames as three overlapping clips, vs
@@ -1326,7 +1252,7 @@ def test_kitti_flow_vs_reference(hip, golden, precision):
         new["embedding_head.conv_seediness.weight"] = new["embedding_head.conv_seediness.weight"] * 6.0
         model._model.load_state_dict(new)
         model = model.cuda()
-        model.set_precision(precision)        # bf16x3: opt-in 3-term bf16 split -- same goldens, label agreement reported
+        model.set_precision(precision)
         exact = precision in ("f32", "bf16x6", "f16x3")        # the split modes with fp32-level error are held to the fp32 standard
         frames = synth.synth_frames(14, 60, 190, seed=91)
         tg = TrackGenerator(model, "kittimots", frame_overlap=4)
@@ -1347,7 +1273,7 @@ def test_kitti_flow_vs_reference(hip, golden, precision):
         agree = float((ref_lab[both] == got_lab[both]).mean())
         print("[parity] kitti flow vs reference: fg %d vs %d (%d pixels differ), labels identical on %.4f of the common fg, tracks %s"
               % (got_fg.sum(), ref_fg.sum(), (got_fg != ref_fg).sum(), agree, sorted(counts.items())[:8]))
-        print("[bf16x3-labels] kitti %s: fg differs in %d pixels, label agreement %.5f" % (precision, (got_fg != ref_fg).sum(), agree))
+        print("[labels] kitti %s: fg differs in %d pixels, label agreement %.5f" % (precision, (got_fg != ref_fg).sum(), agree))
         assert (got_fg != ref_fg).mean() < 1e-3 and agree >= (0.999 if exact else 0.99)
         assert not exact or sorted(counts.items()) == [tuple(r) for r in g["pt_counts"].tolist()] or (got_fg != ref_fg).any()
         for i in range(3):
@@ -1427,7 +1353,8 @@ def test_sequence_end_to_end_tracks_and_masks(hip):
 def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
     """ClipPipeline.embed_many (the sharded sequence driver's embedding: several clips per encoder pass, full batches as hipGraph
     replays alternating over two lanes, the remainder eagerly) returns, clip for clip, what embedding each clip on its own gives
-    (<= 1e-5: the batched encoder pass uses other launch shapes), in the caller's clip order, and identically when repeated."""
+    BIT FOR BIT -- the encoder plans every launch for a fixed frame count (ResNetFPN.plan_frames), so the K-partition of its split-K
+    launches does not depend on the batch -- in the caller's clip order, and identically when repeated."""
     from stemseg_amd import config
     from stemseg_amd.modeling.inference_model import InferenceModel
     from stemseg_amd.pipeline import ClipPipeline
@@ -1449,13 +1376,8 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
         three = pipe.embed_many(frames, clips, batch=3, lanes=1)                     # 3 windows per pass (20 frames) + 2 eagerly
         torch.cuda.synchronize()
         for i in range(len(clips)):
-            for other in (stacked, three):
-                sc = np.maximum(1.0, np.abs(ref[i].cpu().numpy()))
-                assert float(np.abs((other[i] - ref[i]).cpu().numpy() / sc).max()) <= 1e-5
-            g_, r_ = got[i].cpu().numpy(), ref[i].cpu().numpy()
-            scale = np.maximum(1.0, np.abs(r_))                      # (bandwidth channels are exp(.) * 10: compare relatively)
-            assert report("embed_many clip %d vs per-clip (rel)" % i, g_ / scale, r_ / scale) <= 1e-5
-            assert torch.equal(got[i], again[i]) and torch.equal(got[i], eager[i])
+            for name, other in (("windows x2 (graph)", got), ("again", again), ("eager", eager), ("stacked", stacked), ("windows x3", three)):
+                assert torch.equal(other[i], ref[i]), "clip %d: %s differs from the clip embedded on its own" % (i, name)
         # a sequence whose length leaves an OFF-STRIDE tail clip (22 frames: windows 0, 4, 8, 12 + the tail 14..21, what
         # get_subsequence_frames cuts when (F - T) % (T - overlap) != 0): the on-stride prefix still shares the trunk
         clips2 = [list(range(s0, s0 + 8)) for s0 in (0, 4, 8, 12)] + [list(range(14, 22))]
@@ -1463,8 +1385,7 @@ def test_embed_many_batches_and_lanes_match_per_clip_embedding(hip):
         got2 = pipe.embed_many(frames, clips2, batch=2, lanes=2)
         torch.cuda.synchronize()
         for i in range(len(clips2)):
-            sc = np.maximum(1.0, np.abs(ref2[i].cpu().numpy()))
-            assert float(np.abs((got2[i] - ref2[i]).cpu().numpy() / sc).max()) <= 1e-5, "tail-clip sequence, clip %d" % i
+            assert torch.equal(got2[i], ref2[i]), "tail-clip sequence, clip %d" % i
     finally:
         config.load_preset("defaults")
 
@@ -1523,19 +1444,17 @@ def test_clip_pipeline_step_on_semseg_presets(hip, preset):
             assert near[bad].all()
         # the batched form (two clips through one encoder pass) gives the same per clip
         outs = pipe.step_batch(torch.cat([frames, frames.flip(0)], 0), 2)
-        assert torch.equal(outs[0]["fg"], out["fg"]) and float((outs[0]["emb"] - out["emb"]).abs().max()) <= 1e-5
+        assert torch.equal(outs[0]["fg"], out["fg"]) and torch.equal(outs[0]["emb"], out["emb"]) and torch.equal(outs[0]["labels"], out["labels"])
     finally:
         config.load_preset("defaults")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("size", [(96, 160), (256, 448)])
 def test_clip_pipeline_end_to_end_vs_oracle(hip, precision, size):
     """One clip through ClipPipeline.step (the bench's unit of work) vs the oracle pipeline -- at a reduced size and at
     BASELINE configs[0] (one synthetic 8 x 256 x 448 clip, random-init ResNet-50: the reference's own CPU-runnable case):
     float outputs <= 1e-3; labels identical wherever the oracle's own decision has margin."""
-    if precision == "bf16x3" and size != (96, 160):
-        pytest.skip("configs[0] is checked in the exact-fp32 mode")
     from stemseg_amd import config
     from stemseg_amd.modeling.inference_model import InferenceModel
     from stemseg_amd.pipeline import ClipPipeline

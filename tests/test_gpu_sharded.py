@@ -101,8 +101,6 @@ def _run_gpu(tag, comm=None, fn_name="run_sequence_sharded"):
 def test_clip_parallel_chain_on_gpu_vs_golden(hip, tag):
     ok, crc, centers = _run_gpu(tag)
     assert ok
-    ok2, crc2, centers2 = _run_gpu(tag, fn_name="run_sequence_replicated") if tag != "long" else (True, crc, centers)
-    assert ok2 and crc2 == crc and centers2 == centers            # the replicated chain of round 2 agrees
 
 
 @pytest.mark.parametrize("world,tag", [(2, "seq20_ov4"), (3, "seq14_ov6"), (8, "long"), (8, "seq20_ov4")])
@@ -122,8 +120,8 @@ def test_sharded_semseg_presets_match_the_single_process_chain(hip, flow):
     (41+1 class logits, --resize_embeddings: everything x4, clustering at full resolution) and KITTI-MOTS (3+1 classes) -- on the
     reduced-size flows of tests/golden/model_{ytvis,kitti}.npz.  Fed with the head outputs of ``InferenceModel.forward`` the
     sharded driver must reproduce ``TrackGenerator.do_inference + do_clustering`` BIT FOR BIT at world 1 and on 2 / 3 virtual
-    ranks; fed by ``ClipPipeline.embed_many`` (its own encoder passes: another launch shape, last-bit differences in the maps)
-    the tracks must still agree on >= 99.9 % of the points."""
+    ranks -- and likewise when fed by ``ClipPipeline.embed_many`` (its own encoder passes, of other frame counts: the encoder plans
+    every launch for a fixed frame count, so the maps do not depend on them)."""
     from stemseg_amd import config, pipeline
     from stemseg_amd.inference.main import TrackGenerator
     from stemseg_amd.modeling.inference_model import InferenceModel, preprocess_frames
@@ -170,8 +168,7 @@ def test_sharded_semseg_presets_match_the_single_process_chain(hip, flow):
         (t2, c2, _), _, _, _, _ = pipeline.run_sequence_sharded(
             n, None, tg.chainer, name, frame_overlap=4, fg_logit_channels=Cfg, channel_split=(eh.embedding_size, eh.variance_channels),
             embed_many_fn=lambda my: pipe.embed_many(x, my, batch=2, lanes=1, use_graph=False, with_fg_logits=True))
-        same = [float((a.cpu() == b.cpu()).float().mean()) for a, b in zip(t0, t2) if a.numel() == b.numel() and a.numel()]
-        print("[sharded-semseg] %s: embed_many-fed tracks identical on %.5f of the points (%d of %d frames with equal fg)" % (flow, float(np.mean(same)), len(same), n))
-        assert len(same) >= n - 1 and np.mean(same) >= 0.999
+        assert len(t0) == len(t2) and all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(t0, t2)) and dict(c0) == dict(c2), \
+            "%s: the embed_many-fed sequence differs from the reference-API flow" % flow
     finally:
         config.load_preset("defaults")

@@ -66,13 +66,14 @@ def test_cabi_struct_sizes_and_argument_errors():
     e.n_clips, e.W = 4, 850                                           # frame size must be padded to multiples of 32
     assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0
     # packed weight sizes per precision (pure host arithmetic): chunks x k-groups x planes x [half][Cout] 16-B pieces (+ the f16x3 per-output-channel scale vector)
-    split2, split3 = l.stemseg_hip_packed_weight_bytes_split(128, 256, 27, 2), l.stemseg_hip_packed_weight_bytes_split(128, 256, 27, 3)
-    assert split3 == 64 * 7 * 3 * 2 * 128 * 16 and split2 * 3 == split3 * 2
-    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x3"]) == split2
+    split3 = 64 * 7 * 3 * 2 * 128 * 16
+    split2 = split3 // 3 * 2
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["bf16x6"]) == split3
+    assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 1) == 0                       # (code 1, the retired two-term bf16 split)
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) in (split2 + 8 * 128, split3 + 8 * 128)      # (two or three staged weight planes: SS_F16_WPLANES)
     assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) in (32 * 2 * 2 * 2 * 256 * 16 + 8 * 256, 32 * 2 * 3 * 2 * 256 * 16 + 8 * 256)
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f32"]) == 0 and l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 7) == 0
+    assert sorted(hip.PRECISIONS) == sorted(hip.PRECISION_INFO) and hip.PRECISION_INFO["f16x3"]["operand_significand_bits"] == 22
     # encoder plan offsets (debugging aid): distinct offsets, the first buffer at 0, the last value = the workspace size in floats
     e.n_clips, e.W = 4, 864
     offs = (ctypes.c_int64 * 25)()
@@ -80,47 +81,18 @@ def test_cabi_struct_sizes_and_argument_errors():
     present = [o for o in offs if o >= 0]
     assert len(set(present)) == len(present) == 21 and min(present) == 0 and offs[24] == max(present) and \
         offs[24] * 4 == l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e))            # (no FO buffers: the clips of this pass do not overlap)
-    # shared first-layer convolutions: workspace arithmetic and refusals (no compute)
-    sc = hip.SharedConvsDesc()
-    sc.struct_bytes = ctypes.sizeof(hip.SharedConvsDesc)
-    sc.in_channels, sc.T, sc.H4, sc.W4, sc.precision, sc.gn_eps = 256, 8, 120, 216, hip.PRECISIONS["f16x3"], 1e-5
-    for i, c in enumerate((512, 512, 256, 256)):
-        sc.cout[i], sc.gn_groups[i] = c, 64
-    full = l.stemseg_hip_shared_convs_workspace_bytes(ctypes.byref(sc))
-    assert full > 4 * (512 * 8 * 15 * 27 + 512 * 8 * 30 * 54 + 256 * 8 * 60 * 108 + 256 * 8 * 120 * 216)      # at least the four conv outputs
-    sc.cout[3], sc.gn_groups[3] = 0, 0                                # a branch that is not shared takes no workspace
-    assert 0 < l.stemseg_hip_shared_convs_workspace_bytes(ctypes.byref(sc)) < full - 4 * 256 * 8 * 120 * 216
-    sc.gn_groups[0] = 65                                              # more groups than the statistics table holds
-    assert l.stemseg_hip_shared_convs_workspace_bytes(ctypes.byref(sc)) == 0 and b"gn_groups" in l.stemseg_hip_last_error()
-    sc.gn_groups[0], sc.struct_bytes = 64, sc.struct_bytes - 4
-    assert l.stemseg_hip_shared_convs_workspace_bytes(ctypes.byref(sc)) == 0 and b"descriptor size mismatch" in l.stemseg_hip_last_error()
+    # planning frames: the split-K scratch grows with T / plan_frames (a pass of more frames keeps the plan's K-partition), never shrinks
+    base = l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e))
+    e.plan_frames = 32
+    assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == base
+    e.plan_frames = 8
+    assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == base + 3 * (32 << 20) * 4
+    e.plan_frames = -1
+    assert l.stemseg_hip_encoder_workspace_bytes(ctypes.byref(e)) == 0 and b"plan_frames" in l.stemseg_hip_last_error()
+    e.plan_frames = 0
     # mask materialisation: the crop must fit the up-sampled mask (davis.py:91-96 raises the same way)
     rc = l.stemseg_hip_resample_instance_masks(ctypes.c_void_p(16), 24, 32, ctypes.c_float(4.0), 97, 128, 70, 100, ctypes.c_void_p(16), None)
     assert rc != 0 and b"should be <= padded dims" in l.stemseg_hip_last_error()
-
-
-def test_shared_first_convs_branch_selection():
-    """Which branches two decoders can share (SharedFirstConvs.shared_branches): GroupNorm in both, the same channels per group on that
-    branch, <= 64 groups together -- DAVIS / KITTI pairs share all four, YouTube-VIS (semseg INTER_CHANNELS 256 x 4) the first two."""
-    from stemseg_amd import config
-    from stemseg_amd.modeling.decoder_base import SharedFirstConvs
-    from stemseg_amd.modeling.model_builder import build_model
-    try:
-        for preset, want in (("davis", [True] * 4), ("kittimots", [True] * 4), ("ytvis", [True, True, False, False])):
-            config.load_preset(preset)
-            config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
-            with torch.no_grad():
-                m = build_model(restore_pretrained_backbone_wts=False)
-            twin = m.seediness_head if m.seediness_head is not None else m.semseg_head
-            sf = SharedFirstConvs([m.embedding_head, twin])
-            assert sf.shared_branches() == want, preset
-            twin.precision = "bf16x6"                                 # decoders in different convolution modes share nothing
-            assert sf.shared_branches() == [False] * 4
-            twin.precision = m.embedding_head.precision
-            if preset == "davis":
-                assert SharedFirstConvs([m.embedding_head, twin, twin]).shared_branches() == [False] * 4      # 96 groups > 64
-    finally:
-        config.load_preset("defaults")
 
 
 # ------------------------------------------------------------------------------------------------ small host functions
