@@ -233,6 +233,11 @@ typedef struct StemsegDecoderWeights {
 size_t stemseg_hip_decoder_workspace_bytes(const StemsegDecoderDesc* desc);
 /* zero the halos; call once per (workspace, desc) before the first forward */
 int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
+/* Debug check (SYNCHRONISES the stream): every slice of the workspace is followed by a 64-word guard block that init_workspace filled
+ * with a canary; *n_bad_host = guard words that no longer hold it (an out-of-slice write by some kernel), *first_bad_host = float
+ * offset of the first such word in the workspace (-1: none).  Costs one tiny launch + one 16-byte read-back. */
+int stemseg_hip_decoder_check_workspace(const StemsegDecoderDesc* desc, const void* workspace, size_t ws_bytes, int32_t* n_bad_host,
+                                        int64_t* first_bad_host, void* stream);
 /* feats[0..3] = 32x,16x,8x,4x feature stacks in desc->input_layout; out = [n_out][T][H4][W4] dense */
 int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* weights,
                                 const float* const feats[4], float* out,
@@ -293,6 +298,9 @@ int stemseg_hip_encoder_plan_offsets(const StemsegEncoderDesc* desc, int64_t* ou
 int stemseg_hip_stem_conv(const float* frames, const float* w_tap_major, const float* bias, float* out, int32_t T, int32_t H, int32_t W,
                           void* stream);
 int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc, void* workspace, size_t ws_bytes, void* stream);
+/* the encoder's twin of stemseg_hip_decoder_check_workspace */
+int stemseg_hip_encoder_check_workspace(const StemsegEncoderDesc* desc, const void* workspace, size_t ws_bytes, int32_t* n_bad_host,
+                                        int64_t* first_bad_host, void* stream);
 /* frames: dense [T][3][H][W] (BGR, mean-subtracted).  out[4 * c + k], c < n_clips, k = 0..3: the four FPN maps (4x, 8x, 16x,
  * 32x) of clip c as volumes [256][clip frames][H/s][W/s] -- dense, or the interior view of the decoders' zero-haloed
  * inputs (then no copy is needed). */

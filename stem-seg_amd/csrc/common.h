@@ -79,6 +79,20 @@ static inline StemsegVolume padded_interior_view(float* base, int C, int T, int 
     return make_volume(base + g.interior, g.cs, g.ts, g.pitch, C, T, H, W, g.total - g.interior);
 }
 
+// ---- workspace canaries (with 288 GB nothing is aliased, so nothing but a guard would notice an out-of-slice
+// write): every slice of the encoder / decoder workspaces is followed by a guard block of WS_GUARD_FLOATS words holding WS_CANARY (a
+// quiet-NaN bit pattern: a stray write of data will not reproduce it, a stray READ poisons whatever consumed it);
+// *_init_workspace writes them, stemseg_hip_{encoder,decoder}_check_workspace counts the words that no longer hold it.
+constexpr int WS_GUARD_FLOATS = 64;
+constexpr uint32_t WS_CANARY = 0x7fc5ca7au;
+struct GuardList {
+    int n = 0;
+    int64_t off[64];              // float offset of every guard block inside the workspace
+};
+int launch_canary_fill(float* ws, const GuardList& g, hipStream_t s);
+// synchronises `s`; *n_bad_host = clobbered guard words, *first_bad_host = float offset of the first one (-1: none)
+int canary_check(const float* ws, const GuardList& g, int32_t* n_bad_host, int64_t* first_bad_host, hipStream_t s);
+
 // ---- optional in-library profiler: hipEvent pairs around tagged launches (off by default) -------
 void* profile_begin(int tag, double work, hipStream_t s);   // returns NULL when profiling is off
 void profile_end(void* handle, hipStream_t s);

@@ -1288,6 +1288,10 @@ struct SplitTiles {
     // flat (ragged-width) form of the big 2-D tile: 128 co x 512 flat positions of the whole [T][H + 2][pitch] run (across the
     // frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
     template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
+    // four-wave halves of the two eight-wave tiles that own a CU (tile_cfg 6; tools/conv_sweep.py): two of them share a CU, so one's
+    // staging / barrier phases run under the other's MFMA stream -- at twice the weight-slab traffic per MFMA
+    using Y1WideN = ConvCfg<1, 1, 1, 32, 4, 2, 2, 2, 4, false, BFV>;                            // 256 co x 128 voxels
+    template <int PMAX> using Y2FlatH = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, false, BFV, false, PMAX>;   // 128 co x 256 flat positions
 };
 
 // sustained per-CU rate while the chip is full, for the row planner's cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
@@ -1509,9 +1513,13 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
         // piece: the 13-21 % fewer workgroups only pay at pitch <= 56 (layer-3 3x3: 256 -> 224 workgroups, 207 -> 191 us).
         const bool flat_ok = p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0;
         if (flat_ok && k2 && !p.gn_part && p.in_ts == (int64_t)p.in_H * p.in_ys && p.in_H == p.H + 2 &&
-            (tile_cfg == 5 || (auto_cfg && num_workgroups<Y2Big>(d) >= (scratch ? 96 : 384)))) {
+            (tile_cfg == 5 || tile_cfg == 6 || (auto_cfg && num_workgroups<Y2Big>(d) >= (scratch ? 96 : 384)))) {
             const double e2d = (double)p.H * p.W / ((double)Y2Big::ROWS * ceil_div(p.H, Y2Big::ROWS) * 32.0 * ceil_div(p.W, 32));
             const double efl = (double)d.T * p.H * p.W / (512.0 * ceil_div((int64_t)d.T * p.in_ts, 512));
+            if (tile_cfg == 6 && p.in_ys <= 56) {
+                p.flat_t = 1;
+                return launch_cfg<typename F::template Y2FlatH<56>>(p, s, scratch, scratch_floats, 0, pc);
+            }
             if (tile_cfg == 5 || (efl > 1.04 * e2d && p.in_ys <= 56)) {
                 p.flat_t = 1;
                 if (p.in_ys <= 56) return launch_cfg<typename F::template Y2Flat<56>>(p, s, scratch, scratch_floats, 0, pc);
@@ -1538,6 +1546,7 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     }
     if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats, 0, pc);
     if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats, 0, pc);
+    if (tile_cfg == 6 && p.Cout % 256 == 0) return launch_cfg<typename F::Y1WideN>(p, s, scratch, scratch_floats, 0, pc);
     // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
     // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
     if (auto_cfg && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(d) >= 128)

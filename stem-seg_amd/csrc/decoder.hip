@@ -54,7 +54,47 @@ void profile_end(void* handle, hipStream_t s) {
     if (i < g_prof.size()) (void)hipEventRecord(g_prof[i].b, s);
 }
 
+// ---- workspace canaries (common.h) ----------------------------------------------------------------------
+__global__ void canary_fill_kernel(float* ws, const GuardList g) {
+    reinterpret_cast<uint32_t*>(ws + g.off[blockIdx.x])[threadIdx.x] = WS_CANARY;
+}
+__global__ void canary_check_kernel(const float* ws, const GuardList g, unsigned long long* res) {      // res[0] = bad words, res[1] = min bad offset
+    const int64_t o = g.off[blockIdx.x] + threadIdx.x;
+    if (reinterpret_cast<const uint32_t*>(ws)[o] != WS_CANARY) {
+        atomicAdd(&res[0], 1ull);
+        atomicMin(&res[1], (unsigned long long)o);
+    }
+}
+int launch_canary_fill(float* ws, const GuardList& g, hipStream_t s) {
+    if (g.n == 0) return STEMSEG_OK;
+    hipLaunchKernelGGL(canary_fill_kernel, dim3(g.n), dim3(WS_GUARD_FLOATS), 0, s, ws, g);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+int canary_check(const float* ws, const GuardList& g, int32_t* n_bad_host, int64_t* first_bad_host, hipStream_t s) {
+    SS_CHECK_ARG(n_bad_host && first_bad_host, "check_workspace: null result pointer");
+    unsigned long long* res = nullptr;
+    unsigned long long host[2] = {0ull, ~0ull};
+    SS_HIP(hipMalloc(&res, sizeof(host)));
+    hipError_t e = hipMemcpyAsync(res, host, sizeof(host), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && g.n > 0) {
+        hipLaunchKernelGGL(canary_check_kernel, dim3(g.n), dim3(WS_GUARD_FLOATS), 0, s, ws, g, res);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(res);
+    if (e != hipSuccess) {
+        set_error("check_workspace failed: %s", hipGetErrorString(e));
+        return STEMSEG_E_HIP;
+    }
+    *n_bad_host = (int32_t)std::min<unsigned long long>(host[0], 0x7fffffffull);
+    *first_bad_host = host[0] ? (int64_t)host[1] : -1;
+    return STEMSEG_OK;
+}
+
 struct DecoderPlan {
+    GuardList guards;
     int cin, c32, c16, c8, c4, T, G;
     int h[4], w[4];                 // 32x, 16x, 8x, 4x
     int Ta1, Ta2, Ta3, Tb1, Tb2, Tc1, T16, T8;
@@ -90,7 +130,14 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
                  "decoder: pool / t_scale tables inconsistent for T=%d (32x->%d*%d vs 16x %d; ->%d vs 8x %d; ->%d vs %d)", p.T, p.Ta3,
                  d->t_scale[0], p.Tb2, p.T8, p.Tc1, p.T8 * d->t_scale[2], p.T);
     int64_t off = 0;
-    auto take = [&](int64_t floats) { int64_t o = off; off += round_up(floats, 64); return o; };
+    p.guards.n = 0;
+    auto take = [&](int64_t floats) {            // a slice + its guard block
+        int64_t o = off;
+        off += round_up(floats, 64);
+        p.guards.off[p.guards.n++] = off;
+        off += WS_GUARD_FLOATS;
+        return o;
+    };
     for (int i = 0; i < 4; ++i) p.pin[i] = (d->input_layout == 2) ? -1 : take(PaddedGeom(p.cin, p.T, p.h[i], p.w[i]).total);
     // one dense conv-output scratch per branch: the four branches run concurrently on their own streams
     p.D[0] = take((int64_t)p.c32 * p.T * p.h[0] * p.w[0]);
@@ -242,7 +289,16 @@ extern "C" int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc
         return STEMSEG_E_WORKSPACE;
     }
     SS_HIP(hipMemsetAsync(workspace, 0, (size_t)p.total * sizeof(float), as_stream(stream)));
-    return STEMSEG_OK;
+    return launch_canary_fill(reinterpret_cast<float*>(workspace), p.guards, as_stream(stream));
+}
+
+extern "C" int stemseg_hip_decoder_check_workspace(const StemsegDecoderDesc* desc, const void* workspace, size_t ws_bytes, int32_t* n_bad_host,
+                                                   int64_t* first_bad_host, void* stream) {
+    DecoderPlan p;
+    int rc = make_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(workspace && ws_bytes >= (size_t)p.total * sizeof(float), "decoder_check_workspace: bad workspace");
+    return canary_check(reinterpret_cast<const float*>(workspace), p.guards, n_bad_host, first_bad_host, as_stream(stream));
 }
 
 extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* wts, const float* const feats[4],

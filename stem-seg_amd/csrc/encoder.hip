@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(float* __restrict__
 static int grid1d(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 256 * 16)); }
 
 struct EncoderPlan {
+    GuardList guards;          // one guard block behind every slice below (common.h: workspace canaries)
     int T, H, W, nblk[4], total_blocks;
     int h[4], w[4];            // 4x, 8x, 16x, 32x
     int64_t V[4];
@@ -352,7 +353,14 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     }
     SS_CHECK_ARG(p.total_blocks <= STEMSEG_MAX_ENCODER_BLOCKS, "encoder: more than %d bottleneck blocks", STEMSEG_MAX_ENCODER_BLOCKS);
     int64_t off = 0;
-    auto take = [&](int64_t floats) { int64_t o = off; off += round_up(floats, 64); return o; };
+    p.guards.n = 0;
+    auto take = [&](int64_t floats) {            // a slice + its guard block
+        int64_t o = off;
+        off += round_up(floats, 64);
+        p.guards.off[p.guards.n++] = off;
+        off += WS_GUARD_FLOATS;
+        return o;
+    };
     p.S0 = take(64 * 4 * p.V[0]);
     p.X1 = take(64 * p.V[0]);
     p.A = take(256 * p.V[0]);
@@ -418,7 +426,16 @@ extern "C" int stemseg_hip_encoder_init_workspace(const StemsegEncoderDesc* desc
     }
     // only the zero-haloed buffers need it, but one memset keeps the rule simple
     SS_HIP(hipMemsetAsync(workspace, 0, (size_t)p.total * sizeof(float), as_stream(stream)));
-    return STEMSEG_OK;
+    return launch_canary_fill(reinterpret_cast<float*>(workspace), p.guards, as_stream(stream));
+}
+
+extern "C" int stemseg_hip_encoder_check_workspace(const StemsegEncoderDesc* desc, const void* workspace, size_t ws_bytes, int32_t* n_bad_host,
+                                                   int64_t* first_bad_host, void* stream) {
+    EncoderPlan p;
+    int rc = make_encoder_plan(desc, p);
+    if (rc) return rc;
+    SS_CHECK_ARG(workspace && ws_bytes >= (size_t)p.total * sizeof(float), "encoder_check_workspace: bad workspace");
+    return canary_check(reinterpret_cast<const float*>(workspace), p.guards, n_bad_host, first_bad_host, as_stream(stream));
 }
 
 #ifdef SS_EXPERIMENTS

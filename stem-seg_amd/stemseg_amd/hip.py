@@ -98,6 +98,7 @@ SIGNATURES = {
     "stemseg_hip_stem_conv": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "stemseg_hip_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderDesc)]),
     "stemseg_hip_encoder_init_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, _P]),
+    "stemseg_hip_encoder_check_workspace": (C.c_int, [C.POINTER(EncoderDesc), _P, C.c_size_t, C.POINTER(_I32), C.POINTER(_I64), _P]),
     "stemseg_hip_encoder_forward": (C.c_int, [C.POINTER(EncoderDesc), C.POINTER(EncoderWeights), _P, C.POINTER(Volume), _P, C.c_size_t, _P]),
     "stemseg_hip_groupnorm_stats": (C.c_int, [_P, _I32, _I64, _I32, _F, _P, _P, _P]),
     "stemseg_hip_gn_relu_pool": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, C.POINTER(Volume), _P]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "stemseg_hip_nonfinite_flags": (C.c_int, [_P, _I64, _P, _I32, _P]),
     "stemseg_hip_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDesc)]),
     "stemseg_hip_decoder_init_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, _P]),
+    "stemseg_hip_decoder_check_workspace": (C.c_int, [C.POINTER(DecoderDesc), _P, C.c_size_t, C.POINTER(_I32), C.POINTER(_I64), _P]),
     "stemseg_hip_decoder_forward": (C.c_int, [C.POINTER(DecoderDesc), C.POINTER(DecoderWeights), C.POINTER(_P), _P, _P, C.c_size_t, _P]),
     "stemseg_hip_decoder_join": (C.c_int, [_I32, _P]),
     "stemseg_hip_seediness_accumulate": (C.c_int, [_P, _P, _I64, _I32, _P]),

@@ -100,7 +100,7 @@ class ResNetFPN(nn.Module):
         self.body = _Body(self.stage_blocks)
         self.fpn = _FPN(out_channels)
         self.out_channels, self.is_3d = out_channels, False
-        self._packed, self._ws = {}, {}           # precision -> (parameter signature, packed weights); workspaces by shape / lane
+        self._packed, self._ws, self._ws_desc = {}, {}, {}     # precision -> (parameter signature, packed weights); workspaces (+ their descriptors) by shape / lane
         self.precision = hip.DEFAULT_PRECISION    # hip.PRECISIONS: "f16x3" | "bf16x6" | "f32"
         self.lane = 0             # selects one of several independent workspaces (one per in-flight step / stream)
         # Every convolution of a pass decides its tile shape and split-K factor as if the pass held this many frames
@@ -215,8 +215,22 @@ class ResNetFPN(nn.Module):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=frames.device)
             hip.check(hip.lib().stemseg_hip_encoder_init_workspace(C.byref(d), hip.ptr(ws), nbytes, hip.stream()))
             self._ws[key] = ws
+            self._ws_desc[key] = d
         vols = (hip.Volume * len(out_volumes))(*out_volumes)
         hip.check(hip.lib().stemseg_hip_encoder_forward(C.byref(d), C.byref(w), hip.ptr(frames), vols, hip.ptr(ws), ws.numel(), hip.stream()))
+
+    def check_workspaces(self):
+        """Debug check (synchronises): clobbered guard words over all cached workspaces -- 0 unless some kernel wrote outside its
+        slice (stemseg_hip_encoder_check_workspace).  -> (n_bad, [(workspace key, first bad float offset)])"""
+        bad, where = 0, []
+        for key, ws in self._ws.items():
+            n, first = C.c_int32(0), C.c_int64(-1)
+            with torch.cuda.device(ws.device):
+                hip.check(hip.lib().stemseg_hip_encoder_check_workspace(C.byref(self._ws_desc[key]), hip.ptr(ws), ws.numel(), C.byref(n), C.byref(first), hip.stream()))
+            if n.value:
+                bad += n.value
+                where.append((key, first.value))
+        return bad, where
 
     @torch.no_grad()
     def forward_channel_major(self, frames):

@@ -63,7 +63,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.conv_8 = nn.Conv3d(c16 + c8, c8, 1, bias=False)
         self.conv_4 = nn.Conv3d(c8 + c4, c4, 1, bias=False)
         self._cache = {}          # precision -> packed weights (valid while the parameter versions match)
-        self._workspaces = {}     # (T, H4, W4, layout) -> (tensor, desc)
+        self._workspaces, self._ws_desc = {}, {}     # (T, H4, W4, layout, device, lane) -> workspace tensor / the descriptor it was sized for
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
         self.detached = False     # True: the call does not join; ``join()`` must follow (twin-decoder overlap)
@@ -121,6 +121,18 @@ class SqueezeExpandTrunk(nn.Module):
     def _grid(self, c, T, H4, W4, dev):
         return None, None, None
 
+    def check_workspaces(self):
+        """Debug check (synchronises): clobbered guard words over all cached workspaces (stemseg_hip_decoder_check_workspace)."""
+        bad, where = 0, []
+        for key, ws in self._workspaces.items():
+            n, first = C.c_int32(0), C.c_int64(-1)
+            with torch.cuda.device(ws.device):
+                hip.check(hip.lib().stemseg_hip_decoder_check_workspace(C.byref(self._ws_desc[key]), hip.ptr(ws), ws.numel(), C.byref(n), C.byref(first), hip.stream()))
+            if n.value:
+                bad += n.value
+                where.append((key, first.value))
+        return bad, where
+
     def join(self):
         """Make the current stream wait for a detached forward of this decoder."""
         hip.check(hip.lib().stemseg_hip_decoder_join(int(self.concurrency), hip.stream()))
@@ -159,6 +171,7 @@ class SqueezeExpandTrunk(nn.Module):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             hip.check(hip.lib().stemseg_hip_decoder_init_workspace(C.byref(d), hip.ptr(ws), nbytes, hip.stream()))
             self._workspaces[key] = ws
+            self._ws_desc[key] = d
         w = hip.DecoderWeights()
         for i in range(7):
             w.conv_w[i], w.conv_b[i] = c["conv_w"][i].data_ptr(), c["conv_b"][i].data_ptr()

@@ -121,6 +121,19 @@ class InferenceModel(nn.Module):
             if mod is not None:
                 mod.precision = precision
 
+    def check_workspaces(self):
+        """Debug check (synchronises the device): guard words behind every slice of every cached encoder / decoder workspace that no
+        longer hold their canary -- 0 unless a kernel wrote outside its slice.  -> (n_bad, details)"""
+        m = self._model
+        bad, where = 0, []
+        for n_ in ("backbone", "embedding_head", "seediness_head", "semseg_head"):
+            mod = getattr(m, n_)
+            if mod is not None:
+                b, w = mod.check_workspaces()
+                bad += b
+                where += [(n_,) + x for x in w]
+        return bad, where
+
     def precisions(self):
         """{module name: its MFMA mode} -- to put back with ``restore_precisions`` after a fallback re-run."""
         m = self._model

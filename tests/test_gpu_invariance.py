@@ -308,3 +308,57 @@ def test_graph_lane_reruns_an_overflowing_batch_in_bf16x6_instead_of_raising(hip
         assert all(torch.equal(o["emb"], p_["emb"]) and torch.equal(o["labels"], p_["labels"]) for o, p_ in zip(outs3, before))
     finally:
         config.load_preset("defaults")
+
+
+# ------------------------------------------------------------------------------------------------ workspace canaries
+@pytest.mark.parametrize("preset", ["davis", "ytvis"])
+def test_no_kernel_writes_outside_its_workspace_slice(hip, preset):
+    """SURVEY.md section 5 (race / sanitizer row): every slice of the encoder / decoder workspaces is followed by a guard block holding
+    a canary.  After single steps, batched steps, graph replays on two lanes and windowed encoder passes -- ragged sizes included --
+    not one guard word has changed; and the check does notice a stray write."""
+    from stemseg_amd import config
+    from stemseg_amd.modeling.inference_model import InferenceModel
+    from stemseg_amd.pipeline import ClipPipeline
+    config.load_preset(preset)
+    config.cfg.MODEL.BACKBONE.TYPE = "R-50-FPN"
+    try:
+        yt = preset == "ytvis"
+        model = InferenceModel(resize_scale=4.0) if yt else InferenceModel()
+        msd = model._model.state_dict()
+        new = {k: torch.from_numpy(np.asarray(synth.synth_param(k, v.shape, 61))).reshape(v.shape) for k, v in msd.items()}
+        model._model.load_state_dict(new)
+        pipe = ClipPipeline(model)
+        for (Hh, Ww) in ((96, 160), (64, 96), (128, 224)):
+            frames = (torch.from_numpy(synth.synth_frames(20, Hh, Ww, seed=61).astype(np.float32)).permute(0, 3, 1, 2) - 110.0).cuda().contiguous()
+            for prec in ("f16x3", "bf16x6", "f32"):
+                model.set_precision(prec)
+                pipe.step(frames[:8].contiguous())
+                pipe.step_batch(frames[:16].contiguous(), 2)
+            model.set_precision("f16x3")
+            clips = [list(range(s, s + 8)) for s in (0, 4, 8, 12)]
+            pipe.embed_many(frames, clips, batch=2, lanes=2, with_fg_logits=yt)
+            pipe.embed_many(frames, clips, batch=3, lanes=1, use_graph=False, with_fg_logits=yt)
+            g = pipe.capture(frames[:16].contiguous(), n_clips=2, lane=1)
+            g.run_async(frames[4:20].contiguous())
+            g.collect()
+            torch.cuda.synchronize()
+        bad, where = model.check_workspaces()
+        assert bad == 0, "guard words clobbered: %s" % (where,)
+        n_ws = len(model._model.backbone._ws) + sum(len(getattr(model._model, n)._workspaces) for n in ("embedding_head", "seediness_head", "semseg_head")
+                                                    if getattr(model._model, n) is not None)
+        assert n_ws >= 6
+        # the check sees a stray write: poke the guard behind the FIRST slice of one encoder workspace (the S0 buffer; X1 follows it)
+        bb = model._model.backbone
+        key = next(iter(bb._ws))
+        offs = (hip.C.c_int64 * 25)()
+        hip.check(hip.lib().stemseg_hip_encoder_plan_offsets(hip.C.byref(bb._ws_desc[key]), offs))
+        ws_f = bb._ws[key].view(torch.float32)
+        guard = int(offs[1]) - 64
+        saved = ws_f[guard + 5].clone()
+        ws_f[guard + 5] = 1.0
+        bad, where = model.check_workspaces()
+        assert bad == 1 and where[0][0] == "backbone" and where[0][2] == guard + 5
+        ws_f[guard + 5] = saved
+        assert model.check_workspaces()[0] == 0
+    finally:
+        config.load_preset("defaults")

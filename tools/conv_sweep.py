@@ -12,7 +12,7 @@ from stemseg_amd import hip  # noqa: E402
 hip.require_gpu()
 T = int(os.environ.get("SWEEP_T", "8"))       # frames per encoder pass (bench default: 4 clips x 8)
 REPS = int(os.environ.get("REPS", "20"))
-PREC = os.environ.get("PREC", "f32")          # f32 | bf16x3 | bf16x6
+PREC = os.environ.get("PREC", "f32")          # f32 | bf16x6 | f16x3
 ONLY = os.environ.get("ONLY", "")             # "dec": decoder shapes only; "enc": encoder shapes only
 
 
@@ -42,7 +42,7 @@ def k1(name, cin, cout, h, w, residual):
         epi.update(residual=res, res_strides=(V, 0, 0))
     fl = 2.0 * cin * cout * V
     row = []
-    for cfg in ((0, 1, 2, 3) if PREC in ("bf16x6", "f16x3") and cout % 256 == 0 else (0, 1, 2)):           # 0 = the launcher's own choice
+    for cfg in ((0, 1, 2, 3, 6) if PREC in ("bf16x6", "f16x3") and cout % 256 == 0 else (0, 1, 2)):           # 0 = the launcher's own choice; 6 = 256 co x 128 voxels, four waves
         for sc in (None, scratch):
             us = timeit(lambda: hip.conv3d(hip.flat_volume(x), wt, b, hip.flat_volume(out), 1, cfg, sc, epi))
             row.append("cfg%d%s %7.1f us %5.1f TF" % (cfg, "+sk" if sc is not None else "   ", us, fl / us / 1e6))
@@ -61,7 +61,7 @@ def k2(name, cin, cout, h, w):
     scratch = torch.empty(32 << 20, device="cuda")
     fl = 2.0 * cin * 9 * cout * T * h * w
     row = []
-    for cfg in ((0, 1, 2, 3, 5) if PREC == "f16x3" and cout % 128 == 0 and pitch <= 224 else (0, 1, 2, 3)):     # 5 = the flat split-staged tile
+    for cfg in ((0, 1, 2, 3, 5, 6) if PREC == "f16x3" and cout % 128 == 0 and pitch <= 56 else (0, 1, 2, 3, 5) if PREC == "f16x3" and cout % 128 == 0 and pitch <= 224 else (0, 1, 2, 3)):     # 5 = the flat split-staged tile, 6 = its four-wave half
         for sc in (None, scratch):
             us = timeit(lambda: hip.conv3d(vin, wt, b, hip.dense_volume(out), (1, 3, 3), cfg, sc, dict(relu=1, precision=PREC)))
             row.append("cfg%d%s %7.1f us %5.1f TF" % (cfg, "+sk" if sc is not None else "   ", us, fl / us / 1e6))

@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Reproducer attempt for the round-3/4 lane differences: TWO SMALL hipGraphs replayed
+concurrently on two streams -- a victim that is one launch of the encoder's stem kernel, and an aggressor that is a short run of the
+library's MFMA convolutions -- with the victim's output compared bitwise with its lone replay after every round.
+
+The failures of rounds 3 / 4 were only ever seen with whole captured pipelines replaying concurrently, and every one of them started
+in the VALU stem kernel; the two stand-alone probes of round 4 (tools/stem_corun_probe.py, tools/microbench/valu_corun_probe.hip)
+launched EAGERLY and stayed clean.  This probe closes that gap: captured victim x captured aggressor, plus the three mixed /
+eager combinations as controls, for both stem forms.
+
+The VALU stem is not in the product library.  Build the experiment library and point the probe at it:
+
+    STEMSEG_BUILD_DEFINES=-DSS_EXPERIMENTS STEMSEG_BUILD_TAG=exp python stem-seg_amd/build.py
+    STEMSEG_HIP_LIB=$PWD/stem-seg_amd/stemseg_amd/lib/libstemseg_hip_exp.so STEMSEG_STEM=valu python tools/graph_corun_probe.py --rounds 300
+    STEMSEG_HIP_LIB=$PWD/stem-seg_amd/stemseg_amd/lib/libstemseg_hip_exp.so python tools/graph_corun_probe.py --rounds 300      # MFMA stem
+
+Prints one line per (victim mode, aggressor mode, aggressor kind): rounds with a differing victim output, and for the first few the
+word offsets decoded to (channel, frame, row, column run) -- the round-4 signature was 5-13 wrong words inside ONE 16-column run.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "stem-seg_amd"))
+from stemseg_amd import hip  # noqa: E402
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32)).cuda()
+
+
+def make_victim(T, H, W):
+    frames = (torch.from_numpy(np.random.RandomState(1).randint(0, 256, (T, 3, H, W)).astype(np.float32)) - 110.0).cuda().contiguous()
+    wt = rnd((64, 3, 7, 7), 2, 1.0 / np.sqrt(147.0)).reshape(64, 147).t().contiguous()      # tap-major, as stemseg_hip_stem_conv takes it
+    b = rnd((64,), 3)
+    out = torch.empty(64, T, H // 2, W // 2, dtype=torch.float32, device="cuda")
+
+    def run():                                                 # exactly ONE kernel: the stem
+        hip.check(hip.lib().stemseg_hip_stem_conv(hip.ptr(frames), hip.ptr(wt), hip.ptr(b), hip.ptr(out), T, H, W, hip.stream()))
+        return out
+    return run
+
+
+def make_aggressor(kind, prec):
+    """A run of library convolutions (MFMA streams with LDS staging and barriers), ~1-2 ms per replay."""
+    ops = []
+    if kind in ("k3", "mix"):
+        Cin, Cout, T, H, W = 256, 128, 8, 120, 216               # the decoders' block_4x convolution
+        buf, g = hip.alloc_padded(Cin, T, H, W)
+        hip.copy_to_volume(rnd((Cin, T, H, W), 5), 0, hip.padded_interior_view(buf, g, Cin, T, H, W))
+        pw = hip.pack_conv_weight_any(rnd((Cout, Cin, 3, 3, 3), 6, 1.0 / np.sqrt(Cin * 27.0)), prec)
+        out = torch.empty(Cout, T, H, W, device="cuda")
+        ops.append(lambda: hip.conv3d(hip.padded_halo_view(buf, g, Cin, T, H, W), pw, None, hip.dense_volume(out), 3, 0, None, dict(precision=prec)))
+        outs = [out]
+    else:
+        outs = []
+    if kind in ("k1", "mix"):
+        Cin, Cout, V = 256, 1024, 32 * 30 * 54                   # a layer-3 expansion of the encoder
+        x = rnd((Cin, V), 7)
+        pw1 = hip.pack_conv_weight_any(rnd((Cout, Cin, 1, 1, 1), 8, 1.0 / np.sqrt(Cin)), prec)
+        o1 = torch.empty(Cout, V, device="cuda")
+        for _ in range(4):
+            ops.append(lambda: hip.conv3d(hip.flat_volume(x), pw1, None, hip.flat_volume(o1), 1, 0, None, dict(precision=prec, relu=1)))
+        outs.append(o1)
+
+    def run():
+        for f in ops:
+            f()
+        return outs
+    return run
+
+
+class Replayable(object):
+    """fn() either captured into a hipGraph (replayed on a stream) or launched eagerly on that stream."""
+
+    def __init__(self, fn, captured):
+        self.fn, self.captured = fn, captured
+        self.stream = torch.cuda.Stream()
+        with torch.cuda.stream(self.stream):
+            self.out = fn()
+        torch.cuda.synchronize()
+        if captured:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+                self.out = fn()
+            torch.cuda.synchronize()
+
+    def go(self, times=1):
+        with torch.cuda.stream(self.stream):
+            for _ in range(times):
+                if self.captured:
+                    self.graph.replay()
+                else:
+                    self.out = self.fn()
+        return self.out
+
+
+def decode(idx, T, Ho, Wo):
+    ch, r = divmod(int(idx), T * Ho * Wo)
+    t, r = divmod(r, Ho * Wo)
+    y, x = divmod(r, Wo)
+    return "c%d t%d y%d x%d" % (ch, t, y, x)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=300)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--precision", default="f16x3")
+    args = ap.parse_args()
+    hip.require_gpu()
+    T, H, W = args.frames, 480, 864
+    Ho, Wo = H // 2, W // 2
+    stem = "VALU (experiment build)" if os.environ.get("STEMSEG_STEM", "").startswith("v") else "MFMA (product)"
+    print("graph_corun_probe: stem kernel %s, library %s, %d rounds per combination, aggressors in %s" % (stem, hip.LIB_PATH, args.rounds, args.precision), flush=True)
+    total_bad = 0
+    for agg_kind in ("k3", "k1", "mix"):
+        for v_cap in (True, False):
+            for a_cap in (True, False):
+                vic = Replayable(make_victim(T, H, W), v_cap)
+                agg = Replayable(make_aggressor(agg_kind, args.precision), a_cap)
+                ref = vic.go().clone()
+                torch.cuda.synchronize()
+                agg_ref = [o.clone() for o in agg.go()]
+                torch.cuda.synchronize()
+                bad, bad_agg, notes = 0, 0, []
+                for r in range(args.rounds):
+                    agg.go(2)                                  # the aggressor brackets the victim in time
+                    out = vic.go()
+                    agg.go(2)
+                    torch.cuda.synchronize()
+                    if not torch.equal(out, ref):
+                        bad += 1
+                        if len(notes) < 3:
+                            idx = torch.nonzero((out != ref).reshape(-1)).reshape(-1)
+                            d = (out.reshape(-1)[idx] - ref.reshape(-1)[idx])[:4].tolist()
+                            notes.append("round %d: %d words, first at %s, last at %s, off by %s" % (r, idx.numel(), decode(idx[0], T, Ho, Wo), decode(idx[-1], T, Ho, Wo),
+                                                                                                      [round(float(v), 4) for v in d]))
+                    if any(not torch.equal(a, b) for a, b in zip(agg.out, agg_ref)):
+                        bad_agg += 1
+                total_bad += bad + bad_agg
+                print("victim %-8s x aggressor %-8s (%-3s): %3d of %d rounds with a differing stem output, %d with a differing aggressor output"
+                      % ("graph" if v_cap else "eager", "graph" if a_cap else "eager", agg_kind, bad, args.rounds, bad_agg), flush=True)
+                for n_ in notes:
+                    print("    " + n_, flush=True)
+                del vic, agg
+    print("total differing rounds: %d" % total_bad)
+
+
+if __name__ == "__main__":
+    main()

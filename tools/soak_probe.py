@@ -48,7 +48,7 @@ def decoder_segments(mod, T, H4, W4, layout):
     def take(name, floats):
         nonlocal off
         segs.append((name, off))
-        off += ru(floats, 64)
+        off += ru(floats, 64) + 64              # (+ the slice's guard block: csrc/common.h, workspace canaries)
     if layout != 2:
         for i in range(4):
             take("pin%d" % i, padded_total(cin, T, h[i], w[i]))
