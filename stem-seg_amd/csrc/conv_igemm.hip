@@ -1292,6 +1292,13 @@ struct SplitTiles {
     // staging / barrier phases run under the other's MFMA stream -- at twice the weight-slab traffic per MFMA
     using Y1WideN = ConvCfg<1, 1, 1, 32, 4, 2, 2, 2, 4, false, BFV>;                            // 256 co x 128 voxels
     template <int PMAX> using Y2FlatH = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, false, BFV, false, PMAX>;   // 128 co x 256 flat positions
+    using Y3BigH = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, BFV>;                             // 128 co x (8 rows x 32 cols)
+    using Y2BigH = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, false, BFV>;                             // 128 co x (8 rows x 32 cols)
+    // 64-channel chunks for the 1x1 tiles (tile_cfg 7 / 8): the same packed weights (a 64-channel chunk is two consecutive 32-channel
+    // chunks of the [chunk][k-group] order; Cin % 64 == 0), half the chunk boundaries -- each one is a round trip to memory that a
+    // 0.4 us MFMA stream of a short-K tile cannot hide
+    using Y1Small64 = ConvCfg<1, 1, 1, 64, 2, 2, 2, 2, 4, false, BFV>;                         // 128 co x 128 voxels
+    using Y1Wide64 = ConvCfg<1, 1, 1, 64, 4, 2, 2, 4, 8, false, BFV>;                          // 256 co x 256 voxels
 };
 
 // sustained per-CU rate while the chip is full, for the row planner's cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
@@ -1529,6 +1536,7 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
         }
     }
     if (k3) {
+        if constexpr (BFV == 3) { if (tile_cfg == 6) return launch_cfg<typename F::Y3BigH>(p, s, scratch, scratch_floats, 0, pc); }
         if (cfg == 0) cfg = num_workgroups<Y3Big>(d) >= 384 ? 1 : (num_workgroups<Y3Med>(d) >= (scratch ? 32 : 256) ? 2 : 3);
         if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats, 0, pc);
         if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats, 0, pc);
@@ -1536,6 +1544,7 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     }
     if (k2) {
         if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats, 0, pc);
+        if constexpr (BFV == 3) { if (tile_cfg == 6) return launch_cfg<typename F::Y2BigH>(p, s, scratch, scratch_floats, 0, pc); }
         if (cfg == 0) {
             const int64_t need = scratch ? 96 : 384;
             cfg = num_workgroups<Y2Big>(d) >= need ? 1 : (num_workgroups<Y2Med>(d) >= need ? 2 : 3);
@@ -1546,7 +1555,11 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     }
     if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats, 0, pc);
     if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats, 0, pc);
-    if (tile_cfg == 6 && p.Cout % 256 == 0) return launch_cfg<typename F::Y1WideN>(p, s, scratch, scratch_floats, 0, pc);
+    if constexpr (BFV == 3) {
+        if (tile_cfg == 6 && p.Cout % 256 == 0) return launch_cfg<typename F::Y1WideN>(p, s, scratch, scratch_floats, 0, pc);
+        if (tile_cfg == 7 && p.Cin % 64 == 0) return launch_cfg<typename F::Y1Small64>(p, s, scratch, scratch_floats, 0, pc);
+        if (tile_cfg == 8 && p.Cin % 64 == 0 && p.Cout % 256 == 0) return launch_cfg<typename F::Y1Wide64>(p, s, scratch, scratch_floats, 0, pc);
+    }
     // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
     // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
     if (auto_cfg && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(d) >= 128)
@@ -1785,6 +1798,7 @@ extern "C" int stemseg_hip_conv3d(const StemsegVolume* in, const float* packed_w
         e.relu = epilogue->relu; e.res = epilogue->residual; e.res_cs = epilogue->res_c_stride; e.res_ts = epilogue->res_t_stride;
         e.res_ys = epilogue->res_y_stride; e.dec_H = epilogue->decode_H; e.dec_W = epilogue->decode_W;
         e.precision = epilogue->precision;
+        e.frames = epilogue->frames; e.plan_frames = epilogue->plan_frames; e.plan_scratch_floats = epilogue->plan_scratch_floats;
     }
     return launch_conv3d(*in, packed_w, bias, *out, kt, kh, kw, tile_cfg, as_stream(stream), splitk_scratch, splitk_scratch_floats,
                          epilogue ? &e : nullptr);

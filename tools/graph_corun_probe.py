@@ -34,8 +34,8 @@ def rnd(shape, seed, scale=1.0):
     return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32)).cuda()
 
 
-def make_victim(T, H, W):
-    frames = (torch.from_numpy(np.random.RandomState(1).randint(0, 256, (T, 3, H, W)).astype(np.float32)) - 110.0).cuda().contiguous()
+def make_victim(T, H, W, seed=1):
+    frames = (torch.from_numpy(np.random.RandomState(seed).randint(0, 256, (T, 3, H, W)).astype(np.float32)) - 110.0).cuda().contiguous()
     wt = rnd((64, 3, 7, 7), 2, 1.0 / np.sqrt(147.0)).reshape(64, 147).t().contiguous()      # tap-major, as stemseg_hip_stem_conv takes it
     b = rnd((64,), 3)
     out = torch.empty(64, T, H // 2, W // 2, dtype=torch.float32, device="cuda")
@@ -59,14 +59,36 @@ def make_aggressor(kind, prec):
         outs = [out]
     else:
         outs = []
-    if kind in ("k1", "mix"):
+    if kind in ("k1", "mix", "k1_f32", "k1_bf16x6"):
+        p1 = {"k1_f32": "f32", "k1_bf16x6": "bf16x6"}.get(kind, prec)
         Cin, Cout, V = 256, 1024, 32 * 30 * 54                   # a layer-3 expansion of the encoder
         x = rnd((Cin, V), 7)
-        pw1 = hip.pack_conv_weight_any(rnd((Cout, Cin, 1, 1, 1), 8, 1.0 / np.sqrt(Cin)), prec)
+        pw1 = hip.pack_conv_weight_any(rnd((Cout, Cin, 1, 1, 1), 8, 1.0 / np.sqrt(Cin)), p1)
         o1 = torch.empty(Cout, V, device="cuda")
         for _ in range(4):
-            ops.append(lambda: hip.conv3d(hip.flat_volume(x), pw1, None, hip.flat_volume(o1), 1, 0, None, dict(precision=prec, relu=1)))
+            ops.append(lambda: hip.conv3d(hip.flat_volume(x), pw1, None, hip.flat_volume(o1), 1, 0, None, dict(precision=p1, relu=1)))
         outs.append(o1)
+    if kind == "k2":                                             # a layer-3 3x3 convolution (eight-wave flat tile, 61 KB of LDS: fits beside a stem workgroup)
+        Cin, Cout, T, H, W = 256, 256, 32, 30, 54
+        pitch = (W + 2 + 3) // 4 * 4
+        buf = torch.zeros(Cin, T, H + 2, pitch, device="cuda")
+        buf[:, :, 1:H + 1, 1:W + 1] = rnd((Cin, T, H, W), 9)
+        vin = hip.Volume(buf.data_ptr(), T * (H + 2) * pitch, (H + 2) * pitch, pitch, Cin, T, H + 2, W + 2, buf.numel())
+        pw2 = hip.pack_conv_weight_any(rnd((Cout, Cin, 1, 3, 3), 10, 1.0 / np.sqrt(Cin * 9.0)), prec)
+        o2 = torch.empty(Cout, T, H, W, device="cuda")
+        for _ in range(3):
+            ops.append(lambda: hip.conv3d(vin, pw2, None, hip.dense_volume(o2), (1, 3, 3), 0, None, dict(precision=prec, relu=1)))
+        outs.append(o2)
+    if kind == "stream":                                         # no matrix cores, no LDS: a streaming kernel (trilinear x2)
+        xs = rnd((128, 8, 60, 108), 11)
+        o3 = torch.empty(128, 16, 120, 216, device="cuda")
+        for _ in range(6):
+            ops.append(lambda: hip.upsample_trilinear(xs, 2, 2, 2, hip.dense_volume(o3)))
+        outs.append(o3)
+    if kind == "stem":                                           # a second instance of the victim's own kernel
+        v2 = make_victim(16, 480, 864, seed=21)
+        ops.append(v2)
+        outs.append(v2())
 
     def run():
         for f in ops:
@@ -112,6 +134,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=300)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--aggressors", default="k3,k1,mix", help="comma list of k3 | k1 | mix | k1_f32 | k1_bf16x6 | k2 | stream | stem")
+    ap.add_argument("--modes", default="gg,ge,eg,ee", help="(victim, aggressor) launch modes: g = captured graph, e = eager")
     args = ap.parse_args()
     hip.require_gpu()
     T, H, W = args.frames, 480, 864
@@ -119,9 +143,10 @@ def main():
     stem = "VALU (experiment build)" if os.environ.get("STEMSEG_STEM", "").startswith("v") else "MFMA (product)"
     print("graph_corun_probe: stem kernel %s, library %s, %d rounds per combination, aggressors in %s" % (stem, hip.LIB_PATH, args.rounds, args.precision), flush=True)
     total_bad = 0
-    for agg_kind in ("k3", "k1", "mix"):
-        for v_cap in (True, False):
-            for a_cap in (True, False):
+    for agg_kind in args.aggressors.split(","):
+        for mode in args.modes.split(","):
+            v_cap, a_cap = mode[0] == "g", mode[1] == "g"
+            if True:
                 vic = Replayable(make_victim(T, H, W), v_cap)
                 agg = Replayable(make_aggressor(agg_kind, args.precision), a_cap)
                 ref = vic.go().clone()
@@ -129,6 +154,7 @@ def main():
                 agg_ref = [o.clone() for o in agg.go()]
                 torch.cuda.synchronize()
                 bad, bad_agg, notes = 0, 0, []
+                hist_q, hist_pix, hist_reg = [0, 0, 0, 0], [0, 0], {}
                 for r in range(args.rounds):
                     agg.go(2)                                  # the aggressor brackets the victim in time
                     out = vic.go()
@@ -136,8 +162,21 @@ def main():
                     torch.cuda.synchronize()
                     if not torch.equal(out, ref):
                         bad += 1
+                        idx = torch.nonzero((out != ref).reshape(-1)).reshape(-1)
+                        if bad <= 20:
+                            # VALU stem: thread (py, px) of a 256-thread workgroup owns output columns px and px + 32 of row py of an 8 x 64 tile and
+                            # all 64 channels (two passes of 32: register k = channel % 32, acc0 / acc1 = the two columns); lane = (py & 1) * 32 + px
+                            ii = idx.cpu().numpy()
+                            ch, rem = np.divmod(ii, T * Ho * Wo)
+                            yy, xx = np.divmod(rem % (Ho * Wo), Wo)
+                            lane = (yy % 2) * 32 + (xx % 32)
+                            for q_ in range(4):
+                                hist_q[q_] += int(((lane >> 4) == q_).sum())
+                            hist_pix[0] += int(((xx % 64) < 32).sum())
+                            hist_pix[1] += int(((xx % 64) >= 32).sum())
+                            for k_ in (ch % 32).tolist()[:2000]:
+                                hist_reg[k_] = hist_reg.get(k_, 0) + 1
                         if len(notes) < 3:
-                            idx = torch.nonzero((out != ref).reshape(-1)).reshape(-1)
                             d = (out.reshape(-1)[idx] - ref.reshape(-1)[idx])[:4].tolist()
                             notes.append("round %d: %d words, first at %s, last at %s, off by %s" % (r, idx.numel(), decode(idx[0], T, Ho, Wo), decode(idx[-1], T, Ho, Wo),
                                                                                                       [round(float(v), 4) for v in d]))
@@ -148,6 +187,9 @@ def main():
                       % ("graph" if v_cap else "eager", "graph" if a_cap else "eager", agg_kind, bad, args.rounds, bad_agg), flush=True)
                 for n_ in notes:
                     print("    " + n_, flush=True)
+                if bad:
+                    print("    wrong words by lane quarter (lanes 0-15, 16-31, 32-47, 48-63): %s; by pixel of the thread (acc0, acc1): %s; registers hit (channel %% 32): %d of 32"
+                          % (hist_q, hist_pix, len(hist_reg)), flush=True)
                 del vic, agg
     print("total differing rounds: %d" % total_bad)
 
