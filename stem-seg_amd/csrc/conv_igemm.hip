@@ -1288,17 +1288,11 @@ struct SplitTiles {
     // flat (ragged-width) form of the big 2-D tile: 128 co x 512 flat positions of the whole [T][H + 2][pitch] run (across the
     // frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
     template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
-    // four-wave halves of the two eight-wave tiles that own a CU (tile_cfg 6; tools/conv_sweep.py): two of them share a CU, so one's
-    // staging / barrier phases run under the other's MFMA stream -- at twice the weight-slab traffic per MFMA
-    using Y1WideN = ConvCfg<1, 1, 1, 32, 4, 2, 2, 2, 4, false, BFV>;                            // 256 co x 128 voxels
-    template <int PMAX> using Y2FlatH = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 8, false, BFV, false, PMAX>;   // 128 co x 256 flat positions
-    using Y3BigH = ConvCfg<3, 3, 3, 4, 4, 2, 1, 4, 1, false, BFV>;                             // 128 co x (8 rows x 32 cols)
-    using Y2BigH = ConvCfg<1, 3, 3, 8, 4, 2, 1, 4, 1, false, BFV>;                             // 128 co x (8 rows x 32 cols)
-    // 64-channel chunks for the 1x1 tiles (tile_cfg 7 / 8): the same packed weights (a 64-channel chunk is two consecutive 32-channel
-    // chunks of the [chunk][k-group] order; Cin % 64 == 0), half the chunk boundaries -- each one is a round trip to memory that a
-    // 0.4 us MFMA stream of a short-K tile cannot hide
-    using Y1Small64 = ConvCfg<1, 1, 1, 64, 2, 2, 2, 2, 4, false, BFV>;                         // 128 co x 128 voxels
-    using Y1Wide64 = ConvCfg<1, 1, 1, 64, 4, 2, 2, 4, 8, false, BFV>;                          // 256 co x 256 voxels
+    // Measured in round 5 and not kept (profiles/r05b_conv_sweep_f16x3_T32.txt, tile_cfg 6 / 7 / 8 of that build): four-wave halves of the
+    // eight-wave tiles, two per CU so that one's staging phases run under the other's MFMA stream -- block_4x 1 076 vs 1 006 us, layer-3 3x3
+    // 214 vs 203, 1024 -> 256 110 vs 107, 256 -> 1024 + residual 170 vs 154; and 64-channel chunks for the 1x1 tiles (half the chunk
+    // boundaries) -- 1024 -> 256 106 vs 107 (256-co tile), 134 vs 125 (128-co tile), 256 -> 1024 190 vs 154.  Neither barrier overlap
+    // nor chunk length is what these kernels wait for.
 };
 
 // sustained per-CU rate while the chip is full, for the row planner's cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
@@ -1520,13 +1514,9 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
         // piece: the 13-21 % fewer workgroups only pay at pitch <= 56 (layer-3 3x3: 256 -> 224 workgroups, 207 -> 191 us).
         const bool flat_ok = p.vec4 && p.dec_W == 0 && p.in_ys % 4 == 0 && p.W + 2 <= p.in_ys && p.in_ys <= 224 && p.Cout % 128 == 0;
         if (flat_ok && k2 && !p.gn_part && p.in_ts == (int64_t)p.in_H * p.in_ys && p.in_H == p.H + 2 &&
-            (tile_cfg == 5 || tile_cfg == 6 || (auto_cfg && num_workgroups<Y2Big>(d) >= (scratch ? 96 : 384)))) {
+            (tile_cfg == 5 || (auto_cfg && num_workgroups<Y2Big>(d) >= (scratch ? 96 : 384)))) {
             const double e2d = (double)p.H * p.W / ((double)Y2Big::ROWS * ceil_div(p.H, Y2Big::ROWS) * 32.0 * ceil_div(p.W, 32));
             const double efl = (double)d.T * p.H * p.W / (512.0 * ceil_div((int64_t)d.T * p.in_ts, 512));
-            if (tile_cfg == 6 && p.in_ys <= 56) {
-                p.flat_t = 1;
-                return launch_cfg<typename F::template Y2FlatH<56>>(p, s, scratch, scratch_floats, 0, pc);
-            }
             if (tile_cfg == 5 || (efl > 1.04 * e2d && p.in_ys <= 56)) {
                 p.flat_t = 1;
                 if (p.in_ys <= 56) return launch_cfg<typename F::template Y2Flat<56>>(p, s, scratch, scratch_floats, 0, pc);
@@ -1536,7 +1526,6 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
         }
     }
     if (k3) {
-        if constexpr (BFV == 3) { if (tile_cfg == 6) return launch_cfg<typename F::Y3BigH>(p, s, scratch, scratch_floats, 0, pc); }
         if (cfg == 0) cfg = num_workgroups<Y3Big>(d) >= 384 ? 1 : (num_workgroups<Y3Med>(d) >= (scratch ? 32 : 256) ? 2 : 3);
         if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats, 0, pc);
         if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats, 0, pc);
@@ -1544,7 +1533,6 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     }
     if (k2) {
         if (p.Cout <= 64) return launch_cfg<Y2M64>(p, s, scratch, scratch_floats, 0, pc);
-        if constexpr (BFV == 3) { if (tile_cfg == 6) return launch_cfg<typename F::Y2BigH>(p, s, scratch, scratch_floats, 0, pc); }
         if (cfg == 0) {
             const int64_t need = scratch ? 96 : 384;
             cfg = num_workgroups<Y2Big>(d) >= need ? 1 : (num_workgroups<Y2Med>(d) >= need ? 2 : 3);
@@ -1555,11 +1543,6 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     }
     if (p.Cout <= 64) return launch_cfg<Y1M64>(p, s, scratch, scratch_floats, 0, pc);
     if (tile_cfg == 3 && p.Cout % 256 == 0) return launch_cfg<Y1Wide>(p, s, scratch, scratch_floats, 0, pc);
-    if constexpr (BFV == 3) {
-        if (tile_cfg == 6 && p.Cout % 256 == 0) return launch_cfg<typename F::Y1WideN>(p, s, scratch, scratch_floats, 0, pc);
-        if (tile_cfg == 7 && p.Cin % 64 == 0) return launch_cfg<typename F::Y1Small64>(p, s, scratch, scratch_floats, 0, pc);
-        if (tile_cfg == 8 && p.Cin % 64 == 0 && p.Cout % 256 == 0) return launch_cfg<typename F::Y1Wide64>(p, s, scratch, scratch_floats, 0, pc);
-    }
     // reductions / square 1x1 convs onto >= 256 channels: the 256-channel tile splits every input element once per 256 outputs
     // (measured, tools/conv_sweep.py: 1024 -> 256 173 -> 155 us, 256 -> 256 at 4x 806 -> 728 us; short-K expansions lose with it)
     if (auto_cfg && p.Cout % 256 == 0 && p.Cin >= p.Cout && !p.res && num_workgroups<Y1Wide>(d) >= 128)

@@ -42,10 +42,7 @@ def k1(name, cin, cout, h, w, residual):
         epi.update(residual=res, res_strides=(V, 0, 0))
     fl = 2.0 * cin * cout * V
     row = []
-    # 6 = 256 co x 128 voxels on four waves; 7 / 8 = the 128 x 128 / 256 x 256 tiles with 64-channel chunks
-    f16 = PREC == "f16x3"
-    for cfg in ((0, 1, 2, 3, 6) + ((7, 8) if cin % 64 == 0 else ()) if f16 and cout % 256 == 0 else (0, 1, 2) + ((7,) if f16 and cin % 64 == 0 and cout > 64 else ())
-                if PREC != "bf16x6" or cout % 256 else (0, 1, 2, 3)):           # 0 = the launcher's own choice
+    for cfg in ((0, 1, 2, 3) if PREC in ("bf16x6", "f16x3") and cout % 256 == 0 else (0, 1, 2)):           # 0 = the launcher's own choice
         for sc in (None, scratch):
             us = timeit(lambda: hip.conv3d(hip.flat_volume(x), wt, b, hip.flat_volume(out), 1, cfg, sc, epi))
             row.append("cfg%d%s %7.1f us %5.1f TF" % (cfg, "+sk" if sc is not None else "   ", us, fl / us / 1e6))
@@ -64,8 +61,7 @@ def k2(name, cin, cout, h, w):
     scratch = torch.empty(32 << 20, device="cuda")
     fl = 2.0 * cin * 9 * cout * T * h * w
     row = []
-    # 5 = the flat split-staged tile; 6 = the four-wave half of the big tile (flat at pitch <= 56, 8 rows x 32 columns elsewhere)
-    for cfg in ((0, 1, 2, 3, 5, 6) if PREC == "f16x3" and cout % 128 == 0 and pitch <= 224 else (0, 1, 2, 3, 6) if PREC == "f16x3" and cout > 64 else (0, 1, 2, 3)):
+    for cfg in ((0, 1, 2, 3, 5) if PREC == "f16x3" and cout % 128 == 0 and pitch <= 224 else (0, 1, 2, 3)):     # 5 = the flat split-staged tile
         for sc in (None, scratch):
             us = timeit(lambda: hip.conv3d(vin, wt, b, hip.dense_volume(out), (1, 3, 3), cfg, sc, dict(relu=1, precision=PREC)))
             row.append("cfg%d%s %7.1f us %5.1f TF" % (cfg, "+sk" if sc is not None else "   ", us, fl / us / 1e6))
@@ -81,7 +77,7 @@ def k3(name, cin, cout, t, h, w):
     scratch = torch.empty(64 << 20, device="cuda")
     fl = 2.0 * cin * 27 * cout * t * h * w
     row = []
-    for cfg in ((0, 1, 2, 3, 6) if PREC == "f16x3" else (0, 1, 2, 3)):      # 6 = the four-wave half of the big tile (two workgroups per CU)
+    for cfg in (0, 1, 2, 3):
         for sc in (None, scratch):
             us = timeit(lambda: hip.conv3d(hip.padded_halo_view(buf, g, cin, t, h, w), wt, b, hip.dense_volume(out), 3, cfg, sc, dict(precision=PREC)))
             row.append("cfg%d%s %7.1f us %5.1f TF" % (cfg, "+sk" if sc is not None else "   ", us, fl / us / 1e6))
