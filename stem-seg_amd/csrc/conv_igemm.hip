@@ -1292,7 +1292,9 @@ struct SplitTiles {
     // eight-wave tiles, two per CU so that one's staging phases run under the other's MFMA stream -- block_4x 1 076 vs 1 006 us, layer-3 3x3
     // 214 vs 203, 1024 -> 256 110 vs 107, 256 -> 1024 + residual 170 vs 154; and 64-channel chunks for the 1x1 tiles (half the chunk
     // boundaries) -- 1024 -> 256 106 vs 107 (256-co tile), 134 vs 125 (128-co tile), 256 -> 1024 190 vs 154.  Neither barrier overlap
-    // nor chunk length is what these kernels wait for.
+    // nor chunk length is what these kernels wait for.  Likewise the input tile fetched TWO chunks ahead through a second register set
+    // (profiles/r05h_sweep{,_ina}.txt): the 128 x 128 tile drops from three to two waves per SIMD (174 VGPRs) and loses 18 % (256 -> 1024
+    // 182 vs 154 us), the eight-wave 256 x 256 tile is unchanged (111 vs 108): the step 96.4 vs 98.6 clips/s.  Removed.
 };
 
 // sustained per-CU rate while the chip is full, for the row planner's cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32

@@ -4,7 +4,7 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_step_$c
-  (cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc_step_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision --lanes 1 --no-graph --no-overlap) > gpurun_out/pmc_step_$c.log 2>&1
+  (cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc_step_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision --no-sequence-leg --lanes 1 --no-graph --no-overlap) > gpurun_out/pmc_step_$c.log 2>&1
   echo "pmc $c exit $?"
 done
 python - <<'PY'
