@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 7
+#define STEMSEG_HIP_ABI_VERSION 8
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -214,6 +214,12 @@ typedef struct StemsegDecoderDesc {
                                     inputs / workspace.  Lets a twin decoder be enqueued in between (both fill the chip). */
     int32_t precision;           /* STEMSEG_PRECISION_F32 | _BF16X6 | _F16X3 for every convolution of the decoder
                                     (weights in StemsegDecoderWeights must be packed for the same mode)                    */
+    int32_t n_clips;             /* clip batch: the decoder runs n_clips clips (0 / 1: one) in ONE launch per stage -- the clip is a grid
+                                    dimension of every kernel.  Every launch decision is taken on one clip's shape, so a clip's
+                                    output is bit-identical whatever the batch.  The workspace holds n_clips clip plans.          */
+    int64_t feat_clip_stride[4]; /* n_clips > 1: floats between consecutive clips' input feature buffers, per level (feats[i] is
+                                    clip 0's)                                                                                     */
+    int64_t out_clip_stride;     /* n_clips > 1: floats between consecutive clips' outputs (0: n_out * T * H4 * W4, i.e. dense)   */
 } StemsegDecoderDesc;
 
 typedef struct StemsegDecoderWeights {

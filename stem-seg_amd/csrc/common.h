@@ -113,6 +113,11 @@ struct ConvEpilogue {            // fused into the conv epilogue (or the split-K
     double* gn_part = nullptr;   // [Cout / gn_cpg][gn_cap][2] partial (sum, sum of squares) table
     int gn_cpg = 0, gn_cap = 0;
     int* gn_used = nullptr;      // host counter: slots filled by this conv's launches
+    // clip batch (decoder stages; blockIdx.y of the launch): nb clips whose input / output volumes and gn_part tables lie in_bs / out_bs
+    // floats and gn_bs doubles apart.  Tile shape and split-K factor are decided on one clip, so a clip's result is the same in any batch;
+    // the split-K scratch must hold nb times a single clip's slabs.
+    int nb = 1;
+    int64_t in_bs = 0, out_bs = 0, gn_bs = 0;
 };
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0,
@@ -125,13 +130,20 @@ constexpr int GN_SLOT_CAP = 32768;      // slots per group (x 16 B x groups = 33
 static inline int64_t gn_scratch_doubles(int Cout, int groups) { return (int64_t)groups * GN_SLOT_CAP * 2 > (int64_t)groups * 128 ? (int64_t)groups * GN_SLOT_CAP * 2 : (int64_t)groups * 128; }
 int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
                      int tile_cfg, hipStream_t s, float* splitk_scratch, int64_t splitk_scratch_floats, const ConvEpilogue* epi, int groups,
-                     float eps, float* stats, double* gn_scratch);
+                     float eps, float* stats, double* gn_scratch, int64_t stats_bs = 0);     // (stats_bs: floats between the clips' stats of a clip batch, epi->nb)
 int launch_gn_identity_stats(float* stats, int groups, hipStream_t s);
-int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s);
+// Clip batches (the decoders run all clips of a step in one launch per stage): `nb` clips whose buffers lie at fixed strides (floats;
+// doubles for the partial-sum tables) from clip 0's; the clip is the launch's last grid dimension.
+struct ClipBatch {
+    int nb = 1;
+    int64_t in_bs = 0, out_bs = 0, stats_bs = 0;
+};
+int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s,
+                             int nb = 1, int64_t part_bs = 0, int64_t stats_bs = 0);
 int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
-                        const float* beta, int pool, const StemsegVolume& out, hipStream_t s);
+                        const float* beta, int pool, const StemsegVolume& out, hipStream_t s, const ClipBatch& cb = ClipBatch());
 int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy, int sx, const StemsegVolume& out,
-                    hipStream_t s);
+                    hipStream_t s, const ClipBatch& cb = ClipBatch());
 int launch_copy_to_volume(const float* in, int layout, const StemsegVolume& out, hipStream_t s);
 int launch_copy_strided(const float* in, int64_t in_c_stride, int64_t in_t_stride, const StemsegVolume& out, hipStream_t s);
 struct HeadSpec {
@@ -140,6 +152,6 @@ struct HeadSpec {
     int grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
 };
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
-                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s);
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb = ClipBatch());
 
 }  // namespace stemseg

@@ -65,6 +65,18 @@
                                   // 1: +0.4 %, 3: -0.5 %, 4: -1.0 %)
 #endif
 
+#ifndef SS_PROBE
+#define SS_PROBE 0                 // timing probes of the split-staged chunk loop (experiment builds; results are WRONG for any value but 0):
+                                  // 1 no global loads of the next chunk, 2 loads waited for but neither split nor written to LDS, 3 no MFMAs
+                                  // (fragments still read), 4 no LDS fragment reads (MFMAs on stale registers), 5 no barriers
+#endif
+
+#if SS_PROBE == 5
+#define SS_CHUNK_SYNC() do { } while (0)
+#else
+#define SS_CHUNK_SYNC() __syncthreads()
+#endif
+
 namespace stemseg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -104,6 +116,10 @@ struct ConvKParams {
     double* gn_part;             // [Cout / gn_cpg][gn_cap][2] or NULL
     int gn_cpg, gn_cap, gn_slot0;
     int* gn_used_host;           // host-side slot counter of the current conv (never dereferenced on the device)
+    // clip batch (decoder stages): blockIdx.y = clip; the clips' volumes / partial tables lie at fixed strides from clip 0's.  Every
+    // launch decision is taken on ONE clip's shape, so a clip's result does not depend on how many share the launch.
+    int nb;
+    int64_t in_bs, out_bs, gn_bs;   // floats, floats, doubles
 };
 
 // FLAT (PMAX > 0): the N tile is a run of NSEG * 32 consecutive positions of the zero-haloed PLANE (row pitch <= PMAX floats)
@@ -185,6 +201,25 @@ struct ConvCfg {
                                      : ((GL && LDS_FLOATS * 4 * 4 <= 140 * 1024 && MI * NI <= 4) ? MIN_WG4 : ((GL && LDS_FLOATS * 4 * 3 <= 160 * 1024) ? 3 : 2));
 };
 
+// f16x3 split of the same position of a channel pair (x0: channel 2p, x1: channel 2p + 1) into the two words the staged planes hold:
+// hw = (hi(x0), hi(x1)), lw = (lo(x0), lo(x1)) with hi = fp16(x / 4), lo = fp16((x / 4 - hi) * 2^11) -- the arithmetic of split3's f16
+// branch, bit for bit (x / 4 and the remainder are exact in fp32, so each term is rounded once), as six mixed-precision FMAs that write
+// the fp16 halves in place: per value 3 VALU instructions instead of 6.5 (multiply, two conversions, subtract, scale-and-convert, pack).
+// The staging of a 1x1 tile is ~150 VALU instructions per 24 MFMAs, two thirds of them this split.
+__device__ __forceinline__ void split_pair_f16(const float x0, const float x1, unsigned int& hw, unsigned int& lw) {
+    const float qs = STEMSEG_F16X3_ACT_SCALE, ks = 2048.0f;           // (neither is an inline constant: one SGPR each)
+    unsigned int h, l;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "s"(qs));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "s"(qs));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "s"(qs), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "s"(qs), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(r0), "s"(ks));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(r1), "s"(ks));
+    hw = h;
+    lw = l;
+}
+
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(const ConvKParams p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
@@ -251,7 +286,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         b_ptr6[ni] = C::FLAT ? reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + s * 32 + l31 + 3   // (the staged run starts at F0 - pitch - 4)
                              : reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
     }
-    const float* in_tile = p.in + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
+    const float* in_tile = p.in + (int64_t)blockIdx.y * p.in_bs + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
 
     // ---- staging helpers ------------------------------------------------------------------------------
@@ -442,6 +477,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     // channel further.)
     typedef float f32x4 __attribute__((ext_vector_type(4)));          // (a native vector: struct copies of float4 stay memcpys)
     auto fetch_in6_fast = [&](int c0, int k, f32x4& v0, f32x4& v1) __attribute__((always_inline)) {
+#if SS_PROBE == 1
+        return;
+#endif
         const char* base = reinterpret_cast<const char*>(in_tile) + (int64_t)c0 * p.in_cs * 4;
         const unsigned int cs4 = (unsigned int)(p.in_cs * 4);          // (a chunk of channels spans < 4 GB: in6_voff already relies on it)
         v0 = *reinterpret_cast<const f32x4*>(base + (c0 < in6_clim[k] ? in6_voff[k] : 0u));
@@ -450,6 +488,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     auto store_in6 = [&](int q, const float4& v0, const float4& v1) { // split both channels, interleave, 16-B stores into the tile
         unsigned int h0, m0, l0, h1, m1, l1;
         uint4 ph, pm, pl;
+        if constexpr (C::F16) {                                       // (three mixed-precision FMAs per value, no packing: see split_pair_f16)
+            split_pair_f16(v0.x, v1.x, ph.x, pm.x); split_pair_f16(v0.y, v1.y, ph.y, pm.y);
+            split_pair_f16(v0.z, v1.z, ph.z, pm.z); split_pair_f16(v0.w, v1.w, ph.w, pm.w);
+            unsigned int* d16 = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
+            *reinterpret_cast<uint4*>(d16) = ph;
+            *reinterpret_cast<uint4*>(d16 + C::IN_PLANE_STRIDE) = pm;
+            return;
+        }
         split3(v0.x, h0, m0, l0); split3(v1.x, h1, m1, l1); ph.x = h0 | (h1 << 16); pm.x = m0 | (m1 << 16); pl.x = l0 | (l1 << 16);
         split3(v0.y, h0, m0, l0); split3(v1.y, h1, m1, l1); ph.y = h0 | (h1 << 16); pm.y = m0 | (m1 << 16); pl.y = l0 | (l1 << 16);
         split3(v0.z, h0, m0, l0); split3(v1.z, h1, m1, l1); ph.z = h0 | (h1 << 16); pm.z = m0 | (m1 << 16); pl.z = l0 | (l1 << 16);
@@ -526,6 +572,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             for (int ni = 0; ni < C::NI; ++ni) { bdy6[ni][0] = b_ptr6[ni]; bdy6[ni][1] = b_ptr6[ni] + pitch; bdy6[ni][2] = b_ptr6[ni] + 2 * pitch; }
         }
         auto ld_b = [&](const int grp, h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
+#if SS_PROBE == 4
+            if (grp >= 0) { _Pragma("unroll") for (int pl = 0; pl < NPX; ++pl) _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni) asm volatile("" : "+v"(b[pl][ni])); return; }
+#endif
             const int cg = grp / C::NTG, tg = grp % C::NTG;
 #pragma unroll
             for (int ni = 0; ni < C::NI; ++ni)
@@ -551,12 +600,20 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 }
         };
         auto ld_a = [&](const int grp, const int mi, h16x8 (&a)[NPA]) __attribute__((always_inline)) {
+#if SS_PROBE == 4
+            if (grp >= 0) { _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(a[pl])); return; }
+#endif
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
                 a[pl] = *reinterpret_cast<const h16x8*>(a_base + (((grp * NPL + pl) * 2) * C::MT + mi * 32) * 16);
         };
         // smallest products first (planes: 0 hi, 1 mid / lo, 2 lo); consecutive MFMAs alternate between the NI accumulators of this mi
         auto mm = [&](const int mi, h16x8 (&a)[NPA], const h16x8 (&b)[NPX][C::NI]) __attribute__((always_inline)) {
+#if SS_PROBE == 3
+            _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) asm volatile("" ::"v"(a[pl]));
+            _Pragma("unroll") for (int pl = 0; pl < NPX; ++pl) _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni) asm volatile("" ::"v"(b[pl][ni]));
+            return;
+#endif
             if constexpr (C::F16) {
                 // two staged planes: the weights' hi * 2^-11 operand (it meets the input tile's lo * 2^11 plane) is made here, four packed
                 // multiplies in the shadow of the MFMAs (exact: a power of two on a normal number; the same rounding as the packed
@@ -669,15 +726,26 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         f32x4 rw6b[W_PT6];                                            // (lookahead tiles: phase B's own register set)
         auto fetch_w6_k = [&](int c0, auto q0c, auto q1c, f32x4 (&r)[W_PT6], const int k) __attribute__((always_inline)) {      // piece k of [q0, q1)
             constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+#if SS_PROBE == 1
+            return;
+#endif
             if ((k + 1) * C::NTHREADS <= q1 - q0 || q0 + tid + k * C::NTHREADS < q1) r[k] = *reinterpret_cast<const f32x4*>(w6_src(c0, q0 + k * C::NTHREADS));
         };
         auto store_w6 = [&](auto q0c, auto q1c, const f32x4 (&r)[W_PT6]) __attribute__((always_inline)) {
             constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+#if SS_PROBE == 2
+            _Pragma("unroll") for (int k = 0; k < W_PT6; ++k) asm volatile("" ::"v"(r[k]));
+            return;
+#endif
     #pragma unroll
             for (int k = 0; k < W_PT6; ++k) { const int q = q0 + tid + k * C::NTHREADS; if ((k + 1) * C::NTHREADS <= q1 - q0 || (k * C::NTHREADS < q1 - q0 && q < q1)) *reinterpret_cast<f32x4*>(w_lds + q * 4) = r[k]; }
         };
         // the next chunk's input tile, written between barriers (the one tile is what the MFMA stream reads)
         auto store_in6_all = [&](int c0) __attribute__((always_inline)) {
+#if SS_PROBE == 2
+            _Pragma("unroll") for (int k = 0; k < 2 * IN_PT6; ++k) asm volatile("" ::"v"(rin[k]));
+            return;
+#endif
             if (p.vec4) {
 #pragma unroll
                 for (int k = 0; k < IN_PT6; ++k) {
@@ -727,11 +795,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
                     }
                 });
-                __syncthreads();
+                SS_CHUNK_SYNC();
                 if constexpr (more) {
                     store_w6(Q0{}, QE{}, rw6);
                     store_in6_all(cn);
-                    __syncthreads();
+                    SS_CHUNK_SYNC();
                 }
             };
             int c0 = c_begin;
@@ -752,17 +820,17 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSA : 1>{}, INc{}, std::integral_constant<int, NPB>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6b, k); });
                 });
-                __syncthreads();
+                SS_CHUNK_SYNC();
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPA>{}, [](const int) {},
                                           [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cnn, Q0{}, QA{}, rw6, k); });
                 });
-                __syncthreads();
+                SS_CHUNK_SYNC();
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6b);
                     store_in6_all(cn);
-                    __syncthreads();
+                    SS_CHUNK_SYNC();
                 }
             };
             int c0 = c_begin;
@@ -780,7 +848,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, INc{}, std::integral_constant<int, NPA>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QA{}, rw6, k); });
                 });
-                __syncthreads();                                   // phase A's slots are idle
+                SS_CHUNK_SYNC();                                   // phase A's slots are idle
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more) {
@@ -788,11 +856,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
                     }
                 });
-                __syncthreads();                                   // everyone is done with phase B's slots and this chunk's input tile
+                SS_CHUNK_SYNC();                                   // everyone is done with phase B's slots and this chunk's input tile
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6);
                     store_in6_all(cn);
-                    __syncthreads();
+                    SS_CHUNK_SYNC();
                 }
             };
             int c0 = c_begin;
@@ -937,7 +1005,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 const int gg = co0 / p.gn_cpg + tid;
                 if (gg * p.gn_cpg < p.Cout) {
                     const int slot = p.gn_slot0 + (t * p.tiles_y + ty) * p.tiles_x + tx;
-                    double* o = p.gn_part + ((size_t)gg * p.gn_cap + slot) * 2;
+                    double* o = p.gn_part + (int64_t)blockIdx.y * p.gn_bs + ((size_t)gg * p.gn_cap + slot) * 2;
                     o[0] = a; o[1] = b;
                 }
             }
@@ -998,7 +1066,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                             const float4 rv = rres[mg][j];         // (acc + bias) + residual, as before
                             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                             if (p.relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); v.z = relu_keep_nan(v.z); v.w = relu_keep_nan(v.w); }
-                            *reinterpret_cast<float4*>(p.out + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)co * p.out_cs + off) = v;
+                            *reinterpret_cast<float4*>(p.out + (int64_t)blockIdx.y * p.out_bs + (int64_t)blockIdx.z * p.out_split_stride + (int64_t)co * p.out_cs + off) = v;
                         }
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);            // reads done before the next tile overwrites the buffer
@@ -1034,7 +1102,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 off = (int64_t)te * p.out_ts + (int64_t)y * p.out_ys + x;
                 roff = (int64_t)te * p.res_ts + (int64_t)y * p.res_ys + x;
             }
-            float* o = p.out + (int64_t)blockIdx.z * p.out_split_stride + off;
+            float* o = p.out + (int64_t)blockIdx.y * p.out_bs + (int64_t)blockIdx.z * p.out_split_stride + off;
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi) {
 #pragma unroll
@@ -1064,6 +1132,7 @@ struct SplitReduceParams {
     unsigned per_c;                // threads needed per channel: V / (4 or 1)
     double* gn_part;               // GroupNorm partial sums of the reduced output (see ConvKParams), or NULL
     int gn_cpg, gn_cap, gn_slot0;
+    int64_t part_bs, out_bs, gn_bs; // clip batch (blockIdx.z = clip): strides of the partial slabs, the output and the partial-sum table
 };
 // grid = (blocks per channel, channels).  One thread per output float4 (VEC: W % 4 == 0 and 16-B aligned output / residual
 // rows) or per output float; 32-bit index math.  Partial slabs are dense [C][T][H][W], so their reads are coalesced 16-B
@@ -1076,6 +1145,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReducePar
     const unsigned c = blockIdx.y;
     const unsigned j = blockIdx.x * 256u + threadIdx.x;        // item within the channel
     const bool active = j < p.per_c;
+    const float* const partial = p.partial + (int64_t)blockIdx.z * p.part_bs;
+    float* const outp = p.out + (int64_t)blockIdx.z * p.out_bs;
     float s1 = 0.f, s2 = 0.f;
     if (active) {
         const unsigned r2 = j / wq, x = (j - r2 * wq) * VW;    // r2 = t * H + y
@@ -1083,9 +1154,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReducePar
         const int64_t i = (int64_t)c * p.V + (int64_t)r2 * p.W + x;
         const int64_t o = (int64_t)c * p.out_cs + (int64_t)t * p.out_ts + (int64_t)y * p.out_ys + x;
         if constexpr (VEC) {
-            float4 acc = *reinterpret_cast<const float4*>(p.partial + i);
+            float4 acc = *reinterpret_cast<const float4*>(partial + i);
             for (int z = 1; z < p.ksplit; ++z) {
-                const float4 v = *reinterpret_cast<const float4*>(p.partial + (int64_t)z * p.slab + i);
+                const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)z * p.slab + i);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             if (p.bias) { const float b = p.bias[c]; acc.x += b; acc.y += b; acc.z += b; acc.w += b; }
@@ -1094,16 +1165,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReducePar
                 acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
             }
             if (p.relu) { acc.x = relu_keep_nan(acc.x); acc.y = relu_keep_nan(acc.y); acc.z = relu_keep_nan(acc.z); acc.w = relu_keep_nan(acc.w); }
-            *reinterpret_cast<float4*>(p.out + o) = acc;
+            *reinterpret_cast<float4*>(outp + o) = acc;
             s1 = (acc.x + acc.y) + (acc.z + acc.w);
             s2 = (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
         } else {
-            float acc = p.partial[i];
-            for (int z = 1; z < p.ksplit; ++z) acc += p.partial[(int64_t)z * p.slab + i];
+            float acc = partial[i];
+            for (int z = 1; z < p.ksplit; ++z) acc += partial[(int64_t)z * p.slab + i];
             if (p.bias) acc += p.bias[c];
             if (p.res) acc += p.res[(int64_t)c * p.res_cs + (int64_t)t * p.res_ts + (int64_t)y * p.res_ys + x];
             if (p.relu) acc = relu_keep_nan(acc);
-            p.out[o] = acc;
+            outp[o] = acc;
             s1 = acc;
             s2 = acc * acc;
         }
@@ -1117,7 +1188,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitReducePar
         __syncthreads();
         if (threadIdx.x == 0) {
             const int g = (int)c / p.gn_cpg, slot = p.gn_slot0 + ((int)c % p.gn_cpg) * (int)gridDim.x + (int)blockIdx.x;
-            double* o = p.gn_part + ((size_t)g * p.gn_cap + slot) * 2;
+            double* o = p.gn_part + (int64_t)blockIdx.z * p.gn_bs + ((size_t)g * p.gn_cap + slot) * 2;
             o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
             o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         }
@@ -1295,6 +1366,15 @@ struct SplitTiles {
     // nor chunk length is what these kernels wait for.  Likewise the input tile fetched TWO chunks ahead through a second register set
     // (profiles/r05h_sweep{,_ina}.txt): the 128 x 128 tile drops from three to two waves per SIMD (174 VGPRs) and loses 18 % (256 -> 1024
     // 182 vs 154 us), the eight-wave 256 x 256 tile is unchanged (111 vs 108): the step 96.4 vs 98.6 clips/s.  Removed.
+    // And PING-PONG forms of the eight-wave tiles (two LDS buffers; waves 0-3 run the MFMA stream of chunk i while waves 4-7 -- their SIMD
+    // partners -- split their share of chunk i + 1 into the other buffer, roles swapped at every barrier; B fragments a k-group ahead):
+    // bit-identical results, and the same times -- 3x3 tiles within +-1 % (fpn_layer1 2 790 vs 2 796 us, layer-3 3x3 246 vs 239), the 256-co
+    // 1x1 tile 5-9 % ahead on the long-K reductions (1024 -> 256 112 vs 119 us) = 0.7 % of the step; the 3x3x3 tile does not fit twice into
+    // 160 KB (profiles/r05i_pingpong_tiles.txt).  Why no schedule moves these kernels (profiles/r05i_dvfs_zero_inputs.txt): the SAME launches
+    // on all-zero activations -- same instructions, less switching -- run 20-25 % faster (block_4x 995 -> 832 us = 441 TF-eq, fpn_layer1
+    // 2 790 -> 2 247): on real data the chip sits at its POWER limit (1.9-2.0 GHz effective under these MFMA streams, GRBM_GUI_ACTIVE / time),
+    // and cycles saved by a better schedule come back as a lower clock.  What is left to win is work not done: MFMAs on tap padding (10 tap
+    // slots for 9 taps in the 1x3x3 class), junk positions of ragged maps, re-split inputs.
 };
 
 // sustained per-CU rate while the chip is full, for the row planner's cost model (measured: ~0.75 of the 157.3 / 256 TFLOP/s fp32
@@ -1348,16 +1428,16 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         dd.T = (int)d_T;
         const int64_t wgs = cfg_workgroups<C>(dd, flat_t);
         const int64_t slab_plan = (int64_t)d.Cout * d_T * d.H * d.W;
-        const int64_t plan_scratch = plan ? plan->scratch_floats : scratch_floats;
+        const int64_t plan_scratch = plan ? plan->scratch_floats : scratch_floats / p.nb;      // (a clip batch decides on one clip's share)
         const int64_t wg_target = (C::X6 && C::NWAVES >= 8) ? 320 : 640;
         while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= wg_target && slab_plan * ksplit * 2 <= plan_scratch) ksplit *= 2;
     }
-    if (force_ksplit > 0) ksplit = (scratch && (int64_t)force_ksplit * slab <= scratch_floats) ? std::min(force_ksplit, nchunks) : 1;
+    if (force_ksplit > 0) ksplit = (scratch && (int64_t)p.nb * force_ksplit * slab <= scratch_floats) ? std::min(force_ksplit, nchunks) : 1;
     p.chunks_per_split = (int)ceil_div(nchunks, ksplit);
     ksplit = (int)ceil_div(nchunks, p.chunks_per_split);
     // (a planned launch never shrinks its K-partition to fit: that would be a batch-dependent summation order again)
-    SS_CHECK_ARG(ksplit == 1 || (int64_t)ksplit * slab <= scratch_floats, "conv3d: split-K scratch too small (%lld floats needed, %lld given)",
-                 (long long)((int64_t)ksplit * slab), (long long)scratch_floats);
+    SS_CHECK_ARG(ksplit == 1 || (int64_t)p.nb * ksplit * slab <= scratch_floats, "conv3d: split-K scratch too small (%lld floats needed, %lld given)",
+                 (long long)((int64_t)p.nb * ksplit * slab), (long long)scratch_floats);
     SplitReduceParams rp;
     // 16-B reduce: the true output (and residual) rows are aligned (vec_epi as computed by the caller) and W % 4 == 0
     const bool rp_vec = out_vec && p.dec_W == 0 && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) && (slab % 4 == 0);
@@ -1367,6 +1447,8 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         rp.slab = slab; rp.C = p.Cout; rp.V = (int64_t)p.T_all * p.H * p.W; rp.ksplit = ksplit; rp.relu = p.relu;
         rp.H = p.dec_W > 0 ? p.dec_H : p.H; rp.W = p.dec_W > 0 ? p.dec_W : p.W;
         rp.gn_part = nullptr; rp.gn_cpg = rp.gn_cap = rp.gn_slot0 = 0;
+        rp.part_bs = (int64_t)ksplit * slab; rp.out_bs = p.out_bs; rp.gn_bs = p.gn_bs;
+        p.out_bs = (int64_t)ksplit * slab;                  // (each clip's slabs behind the previous clip's)
         // partial slabs are dense in the launch's own tile coordinates; the whole epilogue moves to the reduce kernel
         p.out = scratch; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.dec_H = p.dec_W = 0;
         p.out_cs = (int64_t)p.T_all * p.H * p.W; p.out_ts = (int64_t)p.H * p.W; p.out_ys = p.W;
@@ -1385,8 +1467,8 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         else p.gn_slot0 = slot0;
         *p.gn_used_host = slot0 + (int)slots;
     }
-    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), 1, (unsigned)ksplit);
-    const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T_all * p.H * p.W;
+    dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), (unsigned)p.nb, (unsigned)ksplit);
+    const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T_all * p.H * p.W * p.nb;
     constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
     const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : (tile_rows == 16 ? 9 : tile_rows));   // 9/8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
@@ -1394,8 +1476,8 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     if (ksplit > 1) {
         SS_CHECK_ARG(red_items < (1ll << 32) - 256 && p.Cout <= 65535, "conv3d: split-K output too large (%lld elements)", (long long)slab);
         rp.per_c = (unsigned)red_items;
-        if (rp_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(red_bx, (unsigned)p.Cout), dim3(256), 0, s, rp);
-        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(red_bx, (unsigned)p.Cout), dim3(256), 0, s, rp);
+        if (rp_vec) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(red_bx, (unsigned)p.Cout, (unsigned)p.nb), dim3(256), 0, s, rp);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(red_bx, (unsigned)p.Cout, (unsigned)p.nb), dim3(256), 0, s, rp);
     }
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
@@ -1458,14 +1540,14 @@ static int launch_rows(const ConvKParams& p0, hipStream_t s, float* scratch, int
         if (rc) return rc;
     }
     const ConvKParams qB = rows(rA, p0.H);
-    SS_CHECK_ARG((int64_t)plan.k * qB.Cout * qB.T * qB.H * qB.W <= scratch_floats, "conv3d: split-K scratch too small for the planned row cut");
+    SS_CHECK_ARG((int64_t)p0.nb * plan.k * qB.Cout * qB.T * qB.H * qB.W <= scratch_floats, "conv3d: split-K scratch too small for the planned row cut");
     return launch_cfg<C>(qB, s, scratch, scratch_floats, plan.k);
 }
 
 // big launches (>= 512 workgroups of the 8-row tile): 8-row tile vs 4-row tile, each with its best row cut
 template <class Big, class Med>
 static int launch_planned(const ConvKParams& p, const ConvKParams& d, const PlanCtx* pc, hipStream_t s, float* scratch, int64_t scratch_floats, int occ_big, int occ_med) {
-    const int64_t plan_scratch = pc ? pc->scratch_floats : scratch_floats;
+    const int64_t plan_scratch = pc ? pc->scratch_floats : scratch_floats / p.nb;
     const RowPlan a = plan_rows<Big>(d, scratch != nullptr, plan_scratch, CU_FLOPS_F32, occ_big, 1.0);
     const RowPlan b = plan_rows<Med>(d, scratch != nullptr, plan_scratch, CU_FLOPS_F32, occ_med, 0.92);
     if (b.cost < 0.97 * a.cost) return launch_rows<Med>(p, s, scratch, scratch_floats, b, pc);
@@ -1593,6 +1675,9 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.gn_part = epi ? epi->gn_part : nullptr;
     p.gn_cpg = epi ? epi->gn_cpg : 0; p.gn_cap = epi ? epi->gn_cap : 0; p.gn_slot0 = 0;
     p.gn_used_host = epi ? epi->gn_used : nullptr;
+    p.nb = (epi && epi->nb > 1) ? epi->nb : 1;
+    p.in_bs = p.nb > 1 ? epi->in_bs : 0; p.out_bs = p.nb > 1 ? epi->out_bs : 0; p.gn_bs = p.nb > 1 ? epi->gn_bs : 0;
+    SS_CHECK_ARG(p.nb == 1 || (!p.res && p.nb <= 65535 && p.in_bs % 4 == 0 && p.out_bs % 4 == 0), "conv3d: a clip batch takes no residual and 16-byte aligned clip strides");
     SS_CHECK_ARG(!p.gn_part || ((p.gn_cpg == 4 || p.gn_cpg == 8) && p.gn_used_host && p.Cout % p.gn_cpg == 0 && !(epi->relu || epi->res)),
                  "conv3d: fused GroupNorm statistics need groups of 4 or 8 channels and a plain (bias-only) epilogue");
     auto al16 = [](const void* ptr, int64_t cs, int64_t ts, int64_t ys, int T, int H) {
@@ -1685,7 +1770,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
 
 int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out, int kt, int kh, int kw,
                      int tile_cfg, hipStream_t s, float* splitk_scratch, int64_t splitk_scratch_floats, const ConvEpilogue* epi, int groups,
-                     float eps, float* stats, double* gn_scratch) {
+                     float eps, float* stats, double* gn_scratch, int64_t stats_bs) {
     SS_CHECK_ARG(stats && gn_scratch && groups > 0 && out.C % groups == 0, "conv3d_gn: bad GroupNorm arguments");
     const int cpg = out.C / groups;
     const int64_t S = (int64_t)out.T * out.H * out.W;
@@ -1694,15 +1779,18 @@ int launch_conv3d_gn(const StemsegVolume& in, const float* packed_w, const float
     const int64_t slot_bound = ceil_div(out.W, 32) * ceil_div(out.H, 2) * out.T + (int64_t)cpg * ceil_div(S, 256);
     if ((cpg != 4 && cpg != 8) || slot_bound > GN_SLOT_CAP || (epi && (epi->relu || epi->res || epi->dec_W > 0))) {
         SS_CHECK_ARG(dense, "conv3d_gn: the separate statistics pass needs a dense output");
-        const int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, epi);
-        return rc ? rc : launch_gn_stats(out.ptr, out.C, S, groups, eps, stats, gn_scratch, s);
+        int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, epi);
+        const int nb = (epi && epi->nb > 1) ? epi->nb : 1;
+        for (int b = 0; b < nb && !rc; ++b)
+            rc = launch_gn_stats(out.ptr + (nb > 1 ? b * epi->out_bs : 0), out.C, S, groups, eps, stats + (int64_t)b * stats_bs, gn_scratch + (nb > 1 ? b * epi->gn_bs : 0), s);
+        return rc;
     }
     ConvEpilogue e = epi ? *epi : ConvEpilogue();
     int used = 0;
     e.gn_part = gn_scratch; e.gn_cpg = cpg; e.gn_cap = GN_SLOT_CAP; e.gn_used = &used;
     const int rc = launch_conv3d(in, packed_w, bias, out, kt, kh, kw, tile_cfg, s, splitk_scratch, splitk_scratch_floats, &e);
     if (rc) return rc;
-    return launch_gn_finalize_slots(gn_scratch, groups, GN_SLOT_CAP, used, (double)cpg * (double)S, eps, stats, s);
+    return launch_gn_finalize_slots(gn_scratch, groups, GN_SLOT_CAP, used, (double)cpg * (double)S, eps, stats, s, e.nb, e.gn_bs, stats_bs);
 }
 
 }  // namespace stemseg

@@ -94,7 +94,11 @@ int canary_check(const float* ws, const GuardList& g, int32_t* n_bad_host, int64
 }
 
 struct DecoderPlan {
-    GuardList guards;
+    GuardList guards;              // guard blocks of ONE clip's plan (offsets from that clip's base)
+    GuardList tail_guards;         // guard blocks of the shared split-K scratch behind the clip plans (offsets from the workspace base)
+    int nb;                        // clips per call (>= 1); clip c's plan starts at c * clip_floats
+    int64_t clip_floats;
+    int64_t out_bs;                // floats between the clips' outputs
     int cin, c32, c16, c8, c4, T, G;
     int h[4], w[4];                 // 32x, 16x, 8x, 4x
     int Ta1, Ta2, Ta3, Tb1, Tb2, Tc1, T16, T8;
@@ -120,7 +124,16 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     SS_CHECK_ARG(d->input_layout >= 0 && d->input_layout <= 2, "decoder: input_layout");
     p.cin = d->in_channels; p.c32 = d->inter[0]; p.c16 = d->inter[1]; p.c8 = d->inter[2]; p.c4 = d->inter[3];
     p.T = d->T; p.G = d->gn_groups;
+    SS_CHECK_ARG(d->n_clips >= 0 && d->n_clips <= 4096, "decoder: n_clips=%d", d->n_clips);
+    p.nb = d->n_clips > 1 ? d->n_clips : 1;
     for (int i = 0; i < 4; ++i) { p.h[i] = d->H4 >> (3 - i); p.w[i] = d->W4 >> (3 - i); }
+    const int64_t out_dense = (int64_t)d->n_out * d->T * d->H4 * d->W4;
+    p.out_bs = (p.nb > 1 && d->out_clip_stride > 0) ? d->out_clip_stride : out_dense;
+    SS_CHECK_ARG(p.out_bs >= out_dense && p.out_bs % 4 == 0, "decoder: out_clip_stride %lld (>= %lld, a multiple of 4)", (long long)p.out_bs, (long long)out_dense);
+    if (p.nb > 1 && d->input_layout == 2)
+        for (int i = 0; i < 4; ++i)
+            SS_CHECK_ARG(d->feat_clip_stride[i] >= PaddedGeom(d->in_channels, d->T, p.h[i], p.w[i]).total && d->feat_clip_stride[i] % 4 == 0,
+                         "decoder: feat_clip_stride[%d]=%lld (>= one zero-haloed buffer, a multiple of 4)", i, (long long)d->feat_clip_stride[i]);
     p.Ta1 = pooled(p.T, d->pool[0]); p.Ta2 = pooled(p.Ta1, d->pool[1]); p.Ta3 = pooled(p.Ta2, d->pool[2]);
     p.Tb1 = pooled(p.T, d->pool[0]); p.Tb2 = pooled(p.Tb1, d->pool[1]);
     p.Tc1 = pooled(p.T, d->pool[0]);
@@ -150,7 +163,6 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     p.Sfloats[1] = 4 * (int64_t)p.c16 * p.T * p.h[1] * p.w[1];
     p.Sfloats[2] = 4 * (int64_t)p.c8 * p.T * p.h[2] * p.w[2];
     p.Sfloats[3] = 2 * (int64_t)p.c4 * p.T * p.h[3] * p.w[3];
-    for (int i = 0; i < 4; ++i) p.S[i] = p.Sfloats[i] ? take(p.Sfloats[i]) : 0;
     p.P32b = take(PaddedGeom(p.c32, p.Ta1, p.h[0], p.w[0]).total);
     p.P32c = take(PaddedGeom(p.c32, p.Ta2, p.h[0], p.w[0]).total);
     p.X32 = take((int64_t)p.c32 * p.Ta3 * p.h[0] * p.w[0]);
@@ -164,6 +176,18 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     for (int i = 0; i < 4; ++i) {
         p.stats[i] = take(2 * 64);
         p.gn_scratch[i] = take(2 * gn_scratch_doubles(64 * 8, p.G > 0 ? p.G : 1));   // doubles (2 floats each): the decoder's OWN group count x GN_SLOT_CAP x 2
+    }
+    p.clip_floats = round_up(off, 256);
+    // the split-K scratch of the four branches, shared by the clips of a call (a batched launch keeps clip c's slabs behind clip c - 1's):
+    // nb times one clip's worth, behind the clip plans
+    off = p.clip_floats * p.nb;
+    p.tail_guards.n = 0;
+    for (int i = 0; i < 4; ++i) {
+        p.Sfloats[i] *= p.nb;
+        p.S[i] = off;
+        off += round_up(p.Sfloats[i], 64);
+        p.tail_guards.off[p.tail_guards.n++] = off;
+        off += WS_GUARD_FLOATS;
     }
     p.total = off;
     return STEMSEG_OK;
@@ -205,23 +229,27 @@ static inline StemsegVolume flat_volume(float* base, int C, int64_t V) {
     return make_volume(base, V, 0, 0, C, 1, 1, (int)V, (int64_t)C * V);
 }
 
+// one conv -> GroupNorm -> ReLU (-> pool) stage for the nb clips of the call: the input volumes lie in_bs floats apart, everything inside
+// the workspace (D, stats, scratch, dst) ws_bs floats
 static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b, const float* gw, const float* gb, int Cout, int T, int H,
                    int W, int pool, const StemsegVolume& dst, float* D, float* stats, double* scratch, int G, float eps, hipStream_t s,
-                   float* splitk, int64_t splitk_floats, int precision) {
+                   float* splitk, int64_t splitk_floats, int precision, int nb, int64_t in_bs, int64_t ws_bs) {
     StemsegVolume d = dense_volume(D, Cout, T, H, W);
     ConvEpilogue e;
     e.precision = precision;
+    e.nb = nb; e.in_bs = in_bs; e.out_bs = ws_bs; e.gn_bs = ws_bs / 2;
+    ClipBatch cb;
+    cb.nb = nb; cb.in_bs = ws_bs; cb.out_bs = ws_bs; cb.stats_bs = ws_bs;
     if (G == 0) {      // NORMALIZATION_LAYER 'none' (model_builder.py:29-33): conv -> ReLU -> pool; gw / gb are ones / zeros from the caller
         int rc0 = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e);
+        for (int c = 0; c < nb && !rc0; ++c) rc0 = launch_gn_identity_stats(stats + c * ws_bs, 1, s);
         if (rc0) return rc0;
-        rc0 = launch_gn_identity_stats(stats, 1, s);
-        if (rc0) return rc0;
-        return launch_gn_relu_pool(D, Cout, T, H, W, 1, stats, gw, gb, pool, dst, s);
+        return launch_gn_relu_pool(D, Cout, T, H, W, 1, stats, gw, gb, pool, dst, s, cb);
     }
     // the conv's epilogue (or its split-K reduce) leaves the GroupNorm partial sums: its output is not read again for them
-    int rc = launch_conv3d_gn(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e, G, eps, stats, scratch);
+    int rc = launch_conv3d_gn(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e, G, eps, stats, scratch, ws_bs);
     if (rc) return rc;
-    return launch_gn_relu_pool(D, Cout, T, H, W, G, stats, gw, gb, pool, dst, s);
+    return launch_gn_relu_pool(D, Cout, T, H, W, G, stats, gw, gb, pool, dst, s, cb);
 }
 
 }  // namespace stemseg
@@ -289,7 +317,11 @@ extern "C" int stemseg_hip_decoder_init_workspace(const StemsegDecoderDesc* desc
         return STEMSEG_E_WORKSPACE;
     }
     SS_HIP(hipMemsetAsync(workspace, 0, (size_t)p.total * sizeof(float), as_stream(stream)));
-    return launch_canary_fill(reinterpret_cast<float*>(workspace), p.guards, as_stream(stream));
+    for (int c = 0; c < p.nb; ++c) {
+        rc = launch_canary_fill(reinterpret_cast<float*>(workspace) + c * p.clip_floats, p.guards, as_stream(stream));
+        if (rc) return rc;
+    }
+    return launch_canary_fill(reinterpret_cast<float*>(workspace), p.tail_guards, as_stream(stream));
 }
 
 extern "C" int stemseg_hip_decoder_check_workspace(const StemsegDecoderDesc* desc, const void* workspace, size_t ws_bytes, int32_t* n_bad_host,
@@ -297,8 +329,21 @@ extern "C" int stemseg_hip_decoder_check_workspace(const StemsegDecoderDesc* des
     DecoderPlan p;
     int rc = make_plan(desc, p);
     if (rc) return rc;
-    SS_CHECK_ARG(workspace && ws_bytes >= (size_t)p.total * sizeof(float), "decoder_check_workspace: bad workspace");
-    return canary_check(reinterpret_cast<const float*>(workspace), p.guards, n_bad_host, first_bad_host, as_stream(stream));
+    SS_CHECK_ARG(workspace && ws_bytes >= (size_t)p.total * sizeof(float) && n_bad_host && first_bad_host, "decoder_check_workspace: bad workspace");
+    int32_t bad = 0;
+    int64_t first = -1;
+    for (int c = 0; c <= p.nb; ++c) {                      // every clip's plan, then the shared tail
+        int32_t n = 0;
+        int64_t f = -1;
+        const int64_t base = c < p.nb ? c * p.clip_floats : 0;
+        rc = canary_check(reinterpret_cast<const float*>(workspace) + base, c < p.nb ? p.guards : p.tail_guards, &n, &f, as_stream(stream));
+        if (rc) return rc;
+        if (n && first < 0) first = base + f;
+        bad += n;
+    }
+    *n_bad_host = bad;
+    *first_bad_host = first;
+    return STEMSEG_OK;
 }
 
 extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const StemsegDecoderWeights* wts, const float* const feats[4],
@@ -318,10 +363,17 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
 
     hipStream_t s = as_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
+    // clip batch: clip c's plan at ws + c * WS, its inputs at feats[i] + c * pin_bs[i], its output at out + c * p.out_bs; every launch
+    // below covers all nb clips (the clip is a grid dimension of every kernel)
+    const int nb = p.nb;
+    const int64_t WS = p.clip_floats;
+    ClipBatch wsb;                                          // a stage that reads and writes inside the workspace
+    wsb.nb = nb; wsb.in_bs = WS; wsb.out_bs = WS; wsb.stats_bs = WS;
     SS_CHECK_ARG(desc->precision == STEMSEG_PRECISION_F32 || desc->precision == STEMSEG_PRECISION_BF16X6 || desc->precision == STEMSEG_PRECISION_F16X3,
                  "decoder: precision must be 0 (f32), 2 (bf16x6) or 3 (f16x3)");
     ConvEpilogue fuse_epi;
     fuse_epi.precision = desc->precision;
+    fuse_epi.nb = nb; fuse_epi.in_bs = WS; fuse_epi.out_bs = WS;
     const float eps = desc->gn_eps;
     const int G = p.G, T = p.T;
     float* D[4]; float* stats[4]; double* scratch[4];
@@ -341,12 +393,19 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
 
     // 0. inputs into the zero-haloed layout (skipped when the caller already provides it)
     float* pin[4];
+    int64_t pin_bs[4];
     for (int i = 0; i < 4; ++i) {
-        if (desc->input_layout == 2) pin[i] = const_cast<float*>(feats[i]);
+        if (desc->input_layout == 2) { pin[i] = const_cast<float*>(feats[i]); pin_bs[i] = nb > 1 ? desc->feat_clip_stride[i] : 0; }
         else {
             pin[i] = ws + p.pin[i];
-            rc = launch_copy_to_volume(feats[i], desc->input_layout, padded_interior_view(pin[i], p.cin, T, p.h[i], p.w[i]), s);
-            if (rc) return rc;
+            pin_bs[i] = WS;
+            const int64_t dense = (int64_t)p.cin * T * p.h[i] * p.w[i];
+            const int64_t fs = (nb > 1 && desc->feat_clip_stride[i] > 0) ? desc->feat_clip_stride[i] : dense;
+            SS_CHECK_ARG(fs >= dense, "decoder: feat_clip_stride[%d] smaller than one dense feature map", i);
+            for (int c = 0; c < nb; ++c) {
+                rc = launch_copy_to_volume(feats[i] + c * fs, desc->input_layout, padded_interior_view(pin[i] + c * WS, p.cin, T, p.h[i], p.w[i]), s);
+                if (rc) return rc;
+            }
         }
     }
     if (bs) {
@@ -355,46 +414,46 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     }
     // 1. block_32x on s32: three conv/GN/ReLU(/pool) stages (embedding_decoder.py:20-35), then upsample into cat16[0:c32]
     rc = conv_gn(padded_halo_view(pin[0], p.cin, T, p.h[0], p.w[0]), wts->conv_w[0], wts->conv_b[0], wts->gn_w[0], wts->gn_b[0], p.c32, T,
-                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
+                 p.h[0], p.w[0], desc->pool[0], padded_interior_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision, nb, pin_bs[0], WS);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32b, p.c32, p.Ta1, p.h[0], p.w[0]), wts->conv_w[1], wts->conv_b[1], wts->gn_w[1], wts->gn_b[1], p.c32,
-                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
+                 p.Ta1, p.h[0], p.w[0], desc->pool[1], padded_interior_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision, nb, WS, WS);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), wts->conv_w[2], wts->conv_b[2], wts->gn_w[2], wts->gn_b[2], p.c32,
-                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision);
+                 p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision, nb, WS, WS);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2,
-                         slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s32);
+                         slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s32, wsb);
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[0], s32));
     // 2. block_16x on s16 into cat16[c32:], join 32x, 1x1x1 fuse, upsample into cat8[0:c16]  (:112-117)
     rc = conv_gn(padded_halo_view(pin[1], p.cin, T, p.h[1], p.w[1]), wts->conv_w[3], wts->conv_b[3], wts->gn_w[3], wts->gn_b[3], p.c16, T,
-                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision);
+                 p.h[1], p.w[1], desc->pool[0], padded_interior_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision, nb, pin_bs[1], WS);
     if (rc) return rc;
     rc = conv_gn(padded_halo_view(ws + p.P16b, p.c16, p.Tb1, p.h[1], p.w[1]), wts->conv_w[4], wts->conv_b[4], wts->gn_w[4], wts->gn_b[4], p.c16,
-                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision);
+                 p.Tb1, p.h[1], p.w[1], desc->pool[1], slice_volume(ws + p.cat16, p.c32, p.c16, p.T16, p.h[1], p.w[1]), D[1], stats[1], scratch[1], G, eps, s16, ws + p.S[1], p.Sfloats[1], desc->precision, nb, WS, WS);
     if (rc) return rc;
     const int64_t V16 = (int64_t)p.T16 * p.h[1] * p.w[1], V8 = (int64_t)p.T8 * p.h[2] * p.w[2], V4 = (int64_t)T * p.h[3] * p.w[3];
     if (bs) SS_HIP(hipStreamWaitEvent(s16, bs->done[0], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16, ws + p.S[1], p.Sfloats[1], &fuse_epi);
     if (rc) return rc;
     rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
-                         slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16);
+                         slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16, wsb);
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[1], s16));
     // 3. block_8x on s8 into cat8[c16:], join 16x, fuse, upsample into cat4[0:c8]  (:119-123)
     rc = conv_gn(padded_halo_view(pin[2], p.cin, T, p.h[2], p.w[2]), wts->conv_w[5], wts->conv_b[5], wts->gn_w[5], wts->gn_b[5], p.c8, T, p.h[2],
-                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision);
+                 p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision, nb, pin_bs[2], WS);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(s8, bs->done[1], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, ws + p.S[2], p.Sfloats[2], &fuse_epi);
     if (rc) return rc;
-    rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8);
+    rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8, wsb);
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision, nb, pin_bs[3], WS);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
     rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
@@ -403,13 +462,17 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (desc->n_out > STEMSEG_MAX_HEAD_OUT) {
         // wide linear head (semseg_decoder.py:116: conv_out, class logits, no activation): the 1x1x1 MFMA conv; head_w is
         // then a PACKED conv weight with Cout = n_out (zero-padded to a multiple of 32 by the caller), head_b may be NULL
-        rc = launch_conv3d(flat_volume(ws + p.X4, p.c4, V4), wts->head_w, wts->head_b, flat_volume(out, desc->n_out, V4), 1, 1, 1, 0, sm, nullptr, 0, &fuse_epi);
+        ConvEpilogue head_epi = fuse_epi;
+        head_epi.out_bs = p.out_bs;
+        rc = launch_conv3d(flat_volume(ws + p.X4, p.c4, V4), wts->head_w, wts->head_b, flat_volume(out, desc->n_out, V4), 1, 1, 1, 0, sm, nullptr, 0, &head_epi);
         if (rc) return rc;
     } else {
         HeadSpec hs;
         hs.n_out = desc->n_out;
         for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
-        rc = launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm);
+        ClipBatch hb;
+        hb.nb = nb; hb.in_bs = WS; hb.out_bs = p.out_bs;
+        rc = launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm, hb);
         if (rc) return rc;
     }
     if (detached) SS_HIP(hipEventRecord(bs->done[3], sm));

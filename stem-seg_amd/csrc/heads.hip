@@ -22,6 +22,7 @@ struct HeadsParams {
     float* out;
     int Cin, T, H, W;
     int64_t V;
+    int64_t x_bs, out_bs;          // clip batch (grid.y = clip)
     int act[HEADS_MAX_OUT];
     int axis[HEADS_MAX_OUT];
 };
@@ -38,8 +39,9 @@ __device__ __forceinline__ float head_act(float z, int act, float grid) {
 
 // one thread = 4 consecutive voxels (float4 loads along W), NOUT accumulators each
 template <int NOUT>
-__global__ __launch_bounds__(256) void heads_kernel(const HeadsParams p) {
+__global__ __launch_bounds__(256) void heads_kernel(HeadsParams p) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [NOUT][Cin]
+    p.x += (int64_t)blockIdx.y * p.x_bs; p.out += (int64_t)blockIdx.y * p.out_bs;
     for (int i = threadIdx.x; i < NOUT * p.Cin; i += blockDim.x) w_lds[i] = p.w[i];
     __syncthreads();
     const int64_t nq = p.V / 4;
@@ -86,23 +88,25 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsParams p) {
 }
 
 template <int NOUT>
-static int launch_heads_n(const HeadsParams& p, hipStream_t s) {
+static int launch_heads_n(const HeadsParams& p, int nb, hipStream_t s) {
     const int64_t nq = p.V / 4;
     const int blocks = (int)std::min<int64_t>(ceil_div(nq, 256), 256 * 8);
-    hipLaunchKernelGGL(heads_kernel<NOUT>, dim3(blocks), dim3(256), (size_t)NOUT * p.Cin * sizeof(float), s, p);
+    hipLaunchKernelGGL(heads_kernel<NOUT>, dim3(blocks, (unsigned)nb), dim3(256), (size_t)NOUT * p.Cin * sizeof(float), s, p);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
 
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
-                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s) {
-    SS_CHECK_ARG(x && w && out, "heads: null pointer");
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb) {
+    SS_CHECK_ARG(x && w && out && cb.nb >= 1 && cb.nb <= 65535 && cb.in_bs % 4 == 0 && cb.out_bs % 4 == 0, "heads: null pointer");
     SS_CHECK_ARG(hs.n_out >= 1 && hs.n_out <= STEMSEG_MAX_HEAD_OUT, "heads: n_out=%d unsupported (1..%d)", hs.n_out, STEMSEG_MAX_HEAD_OUT);
     SS_CHECK_ARG(Cin % 4 == 0 && W % 4 == 0, "heads: Cin %% 4 == 0 and W %% 4 == 0 required (Cin=%d, W=%d)", Cin, W);
     SS_CHECK_ARG((reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0), "heads: 16-byte alignment");
     HeadsParams p;
     p.x = x; p.w = w; p.bias = bias; p.gt = gt; p.gy = gy; p.gx = gx; p.out = out;
     p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.V = (int64_t)T * H * W;
+    p.x_bs = cb.in_bs; p.out_bs = cb.out_bs;
+    const int nb = cb.nb;
     for (int o = 0; o < HEADS_MAX_OUT; ++o) { p.act[o] = 0; p.axis[o] = 0; }
     for (int o = 0; o < hs.n_out; ++o) {
         p.act[o] = hs.act[o];
@@ -112,19 +116,19 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
         if (!needs_grid) p.axis[o] = 0;
         SS_CHECK_ARG(!needs_grid || (gt && gy && gx), "heads: grid vectors required for channel %d", o);
     }
-    void* ev = profile_begin(44, 4.0 * (double)p.V * (Cin + hs.n_out), s);
+    void* ev = profile_begin(44, 4.0 * (double)p.V * (Cin + hs.n_out) * nb, s);
     int rc;
     switch (hs.n_out) {
-        case 1: rc = launch_heads_n<1>(p, s); break;
-        case 2: rc = launch_heads_n<2>(p, s); break;
-        case 3: rc = launch_heads_n<3>(p, s); break;
-        case 4: rc = launch_heads_n<4>(p, s); break;
-        case 5: rc = launch_heads_n<5>(p, s); break;
-        case 6: rc = launch_heads_n<6>(p, s); break;
-        case 7: rc = launch_heads_n<7>(p, s); break;
-        case 8: rc = launch_heads_n<8>(p, s); break;
-        case 9: rc = launch_heads_n<9>(p, s); break;          // xytff + seediness (embedding_utils.py:4-25): 5 + 3 + 1
-        default: rc = launch_heads_n<10>(p, s); break;
+        case 1: rc = launch_heads_n<1>(p, nb, s); break;
+        case 2: rc = launch_heads_n<2>(p, nb, s); break;
+        case 3: rc = launch_heads_n<3>(p, nb, s); break;
+        case 4: rc = launch_heads_n<4>(p, nb, s); break;
+        case 5: rc = launch_heads_n<5>(p, nb, s); break;
+        case 6: rc = launch_heads_n<6>(p, nb, s); break;
+        case 7: rc = launch_heads_n<7>(p, nb, s); break;
+        case 8: rc = launch_heads_n<8>(p, nb, s); break;
+        case 9: rc = launch_heads_n<9>(p, nb, s); break;          // xytff + seediness (embedding_utils.py:4-25): 5 + 3 + 1
+        default: rc = launch_heads_n<10>(p, nb, s); break;
     }
     profile_end(ev, s);
     return rc;

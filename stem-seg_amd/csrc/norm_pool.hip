@@ -84,8 +84,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
 // one workgroup per group: fixed-order combine of the `used` per-tile partials the conv epilogue / split-K reduce left in
 // part[g][slot] (thread k takes slots k, k + 256, ...; then a fixed tree) -> mean, rstd.  Deterministic, no atomics.
 __global__ __launch_bounds__(256) void gn_finalize_slots_kernel(const double* __restrict__ part, int cap, int used, double group_elems,
-                                                                float eps, float* __restrict__ stats) {
+                                                                float eps, float* __restrict__ stats, int64_t part_bs, int64_t stats_bs) {
     const int g = blockIdx.x;
+    part += (int64_t)blockIdx.y * part_bs;                     // (grid.y: clip of a clip batch)
+    stats += (int64_t)blockIdx.y * stats_bs;
     const double* pg = part + (size_t)g * cap * 2;
     double s = 0.0, ss = 0.0;
     for (int k = threadIdx.x; k < used; k += 256) { s += pg[2 * k]; ss += pg[2 * k + 1]; }
@@ -112,6 +114,7 @@ struct GnApplyParams {
     const float* beta;
     float* out;
     int64_t out_cs, out_ts, out_ys;
+    int64_t x_bs, out_bs, stats_bs;   // clip batch (the launch's last grid dimension = clip)
     int C, T, H, W, To, cpg;
     int pool_max;                  // pooled forms: 0 = AvgPool3d (sum / 27, count_include_pad), 1 = MaxPool3d (values are >= 0 after the ReLU, so the
                                    // -inf padding of nn.MaxPool3d and a zero start give the same maximum)
@@ -119,7 +122,8 @@ struct GnApplyParams {
 
 // Scalar form, any destination layout: one thread per output element, x fastest.
 template <bool POOL>
-__global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p) {
+__global__ __launch_bounds__(256) void gn_relu_pool_kernel(GnApplyParams p) {
+    p.x += (int64_t)blockIdx.y * p.x_bs; p.out += (int64_t)blockIdx.y * p.out_bs; p.stats += (int64_t)blockIdx.y * p.stats_bs;
     const int64_t HW = (int64_t)p.H * p.W;
     const int64_t per_c = (int64_t)p.To * HW;
     const int64_t total = per_c * p.C;
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(256) void gn_relu_pool_kernel(const GnApplyParams p
 // Streaming form of the un-pooled apply for dense destinations (block_4x -> its slice of the concat buffer: 106 MB in,
 // 106 MB out per decoder at 480p): grid.y = channel, 16-B loads and stores along the contiguous [T][H][W] run of the
 // channel, 32-bit indices, the (scale, shift) pair is uniform per workgroup.
-__global__ __launch_bounds__(256) void gn_relu_stream_kernel(const GnApplyParams p, unsigned n4) {
+__global__ __launch_bounds__(256) void gn_relu_stream_kernel(GnApplyParams p, unsigned n4) {
+    p.x += (int64_t)blockIdx.z * p.x_bs; p.out += (int64_t)blockIdx.z * p.out_bs; p.stats += (int64_t)blockIdx.z * p.stats_bs;
     const int c = blockIdx.y, g = c / p.cpg;
     const float a = p.stats[2 * g + 1] * p.gamma[c];
     const float b = p.beta[c] - p.stats[2 * g] * a;
@@ -182,9 +187,10 @@ __global__ __launch_bounds__(256) void gn_relu_stream_kernel(const GnApplyParams
 // Pooled apply, 4 outputs along x per thread: the 3 x 3 x 3 window of 4 neighbouring outputs is 9 rows of 6 inputs, each
 // normalised / rectified ONCE (the scalar form does it 27 times per output), then three-term row sums slide along x.
 // grid.y = (channel, pooled t); the destination may be dense or zero-haloed (scalar stores: its rows start at +1).
-__global__ __launch_bounds__(256) void gn_relu_pool4_kernel(const GnApplyParams p, unsigned wq, unsigned n_items) {
+__global__ __launch_bounds__(256) void gn_relu_pool4_kernel(GnApplyParams p, unsigned wq, unsigned n_items) {
     const unsigned item = blockIdx.x * 256u + threadIdx.x;
     if (item >= n_items) return;
+    p.x += (int64_t)blockIdx.z * p.x_bs; p.out += (int64_t)blockIdx.z * p.out_bs; p.stats += (int64_t)blockIdx.z * p.stats_bs;
     const int c = blockIdx.y / p.To, to = blockIdx.y - c * p.To;
     const int y = (int)(item / wq), x0 = (int)(item - (unsigned)y * wq) * 4;
     const int g = c / p.cpg;
@@ -243,18 +249,19 @@ int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, flo
     return STEMSEG_OK;
 }
 
-int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s) {
-    SS_CHECK_ARG(part && stats && groups > 0 && used > 0 && used <= cap, "gn_finalize_slots: bad arguments (used %d of %d)", used, cap);
-    void* ev = profile_begin(41, 16.0 * groups * used, s);
-    hipLaunchKernelGGL(gn_finalize_slots_kernel, dim3(groups), dim3(256), 0, s, part, cap, used, group_elems, eps, stats);
+int launch_gn_finalize_slots(const double* part, int groups, int cap, int used, double group_elems, float eps, float* stats, hipStream_t s, int nb,
+                             int64_t part_bs, int64_t stats_bs) {
+    SS_CHECK_ARG(part && stats && groups > 0 && used > 0 && used <= cap && nb >= 1 && nb <= 65535, "gn_finalize_slots: bad arguments (used %d of %d)", used, cap);
+    void* ev = profile_begin(41, 16.0 * groups * used * nb, s);
+    hipLaunchKernelGGL(gn_finalize_slots_kernel, dim3(groups, nb), dim3(256), 0, s, part, cap, used, group_elems, eps, stats, part_bs, stats_bs);
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
 
 int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, const float* stats, const float* gamma,
-                        const float* beta, int pool, const StemsegVolume& out, hipStream_t s) {
-    SS_CHECK_ARG(x && stats && gamma && beta && out.ptr, "gn_relu_pool: null pointer");
+                        const float* beta, int pool, const StemsegVolume& out, hipStream_t s, const ClipBatch& cb) {
+    SS_CHECK_ARG(x && stats && gamma && beta && out.ptr && cb.nb >= 1 && cb.nb <= 65535, "gn_relu_pool: null pointer");
     const int To = pool ? (T + 1) / 2 : T;   // floor((T + 2 - 3)/2) + 1
     SS_CHECK_ARG(out.C == C && out.T == To && out.H == H && out.W == W,
                  "gn_relu_pool: output volume (%d,%d,%d,%d) != expected (%d,%d,%d,%d)", out.C, out.T, out.H, out.W, C, To, H, W);
@@ -262,24 +269,26 @@ int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, 
     p.x = x; p.stats = stats; p.gamma = gamma; p.beta = beta;
     p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
     p.C = C; p.T = T; p.H = H; p.W = W; p.To = To; p.cpg = C / groups;
+    p.x_bs = cb.in_bs; p.out_bs = cb.out_bs; p.stats_bs = cb.stats_bs;
+    const unsigned nb = (unsigned)cb.nb;
     p.pool_max = pool == 2 ? 1 : 0;
     SS_CHECK_ARG(pool >= 0 && pool <= 2, "gn_relu_pool: pool code %d (0 none, 1 average, 2 max)", pool);
     const int64_t total = (int64_t)C * To * H * W;
     const int64_t S = (int64_t)T * H * W;
     const bool small = S < (1ll << 31) && total < (1ll << 40);      // 32-bit offsets inside a channel
-    void* ev = profile_begin(pool ? 43 : 42, 4.0 * ((double)C * S + (double)total), s);
+    void* ev = profile_begin(pool ? 43 : 42, 4.0 * ((double)C * S + (double)total) * nb, s);
     if (pool && small && C * To <= 65535) {
         const unsigned wq = (unsigned)ceil_div(W, 4), items = wq * (unsigned)H;
-        hipLaunchKernelGGL(gn_relu_pool4_kernel, dim3((unsigned)ceil_div(items, 256), (unsigned)(C * To)), dim3(256), 0, s, p, wq, items);
+        hipLaunchKernelGGL(gn_relu_pool4_kernel, dim3((unsigned)ceil_div(items, 256), (unsigned)(C * To), nb), dim3(256), 0, s, p, wq, items);
     } else if (!pool && C <= 65535 && S % 4 == 0 && S / 4 < (1ll << 31) && out.t_stride == (int64_t)H * W && out.y_stride == W &&
                out.c_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out.ptr) % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0)) {
         const unsigned n4 = (unsigned)(S / 4);
         const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n4, 256 * 4), 4096));   // ~4 float4 per thread
-        hipLaunchKernelGGL(gn_relu_stream_kernel, dim3(bx, (unsigned)C), dim3(256), 0, s, p, n4);
+        hipLaunchKernelGGL(gn_relu_stream_kernel, dim3(bx, (unsigned)C, nb), dim3(256), 0, s, p, n4);
     } else {
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
-        if (pool) hipLaunchKernelGGL(gn_relu_pool_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(gn_relu_pool_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+        if (pool) hipLaunchKernelGGL(gn_relu_pool_kernel<true>, dim3(blocks, nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gn_relu_pool_kernel<false>, dim3(blocks, nb), dim3(256), 0, s, p);
     }
     profile_end(ev, s);
     SS_LAUNCH_CHECK();

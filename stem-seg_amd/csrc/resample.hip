@@ -13,6 +13,7 @@ struct UpParams {
     const float* in;
     float* out;
     int64_t out_cs, out_ts, out_ys;
+    int64_t in_bs, out_bs;   // clip batch (the launch's last grid dimension = clip)
     int C, T, H, W, To, Ho, Wo;
     float rt, ry, rx;   // 1/scale
 };
@@ -26,7 +27,8 @@ __device__ __forceinline__ void src_index(int dst, float rscale, int n, int& i0,
     w1 = __fsub_rn(src, (float)i0);
 }
 
-__global__ __launch_bounds__(256) void upsample_trilinear_kernel(const UpParams p) {
+__global__ __launch_bounds__(256) void upsample_trilinear_kernel(UpParams p) {
+    p.in += (int64_t)blockIdx.y * p.in_bs; p.out += (int64_t)blockIdx.y * p.out_bs;
     const int64_t HWo = (int64_t)p.Ho * p.Wo;
     const int64_t per_c = (int64_t)p.To * HWo;
     const int64_t total = per_c * p.C;
@@ -68,10 +70,11 @@ __global__ __launch_bounds__(256) void upsample_trilinear_kernel(const UpParams 
 // clamped neighbour enters with weight exactly 0 or duplicates the edge value, as in ATen).  grid.y = (channel, t_out):
 // 32-bit index math, one division per thread.
 template <int SX>
-__global__ __launch_bounds__(256) void upsample_vec4_kernel(const UpParams p, unsigned wq, unsigned n_items) {
+__global__ __launch_bounds__(256) void upsample_vec4_kernel(UpParams p, unsigned wq, unsigned n_items) {
     static_assert(SX == 2 || SX == 4, "x scale 2 or 4");
     const unsigned item = blockIdx.x * 256u + threadIdx.x;
     if (item >= n_items) return;
+    p.in += (int64_t)blockIdx.z * p.in_bs; p.out += (int64_t)blockIdx.z * p.out_bs;
     const int c = blockIdx.y / p.To, to = blockIdx.y - c * p.To;
     const int yo = (int)(item / wq), j = (int)(item - (unsigned)yo * wq);
     int t0, t1, y0, y1;
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256) void copy_to_volume_kernel(const CopyParams p)
 }
 
 int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy, int sx, const StemsegVolume& out,
-                    hipStream_t s) {
-    SS_CHECK_ARG(in && out.ptr, "upsample: null pointer");
+                    hipStream_t s, const ClipBatch& cb) {
+    SS_CHECK_ARG(in && out.ptr && cb.nb >= 1 && cb.nb <= 65535 && cb.out_bs % 4 == 0, "upsample: null pointer");
     SS_CHECK_ARG(st >= 1 && sy >= 1 && sx >= 1, "upsample: scale factors must be >= 1");
     SS_CHECK_ARG(out.C == C && out.T == T * st && out.H == H * sy && out.W == W * sx,
                  "upsample: output volume (%d,%d,%d,%d) != (%d,%d,%d,%d)", out.C, out.T, out.H, out.W, C, T * st, H * sy, W * sx);
@@ -143,19 +146,20 @@ int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy,
     p.in = in; p.out = out.ptr; p.out_cs = out.c_stride; p.out_ts = out.t_stride; p.out_ys = out.y_stride;
     p.C = C; p.T = T; p.H = H; p.W = W; p.To = T * st; p.Ho = H * sy; p.Wo = W * sx;
     p.rt = 1.0f / (float)st; p.ry = 1.0f / (float)sy; p.rx = 1.0f / (float)sx;
+    p.in_bs = cb.in_bs; p.out_bs = cb.out_bs;
     const int64_t total = (int64_t)C * p.To * p.Ho * p.Wo;
-    void* ev = profile_begin(40, 4.0 * ((double)C * T * H * W + (double)total), s);
+    void* ev = profile_begin(40, 4.0 * ((double)C * T * H * W + (double)total) * cb.nb, s);
     const bool vec = (sx == 2 || sx == 4) && p.Wo % 4 == 0 && (int64_t)C * p.To <= 65535 && (int64_t)T * H * W < (1ll << 31) &&
                      (int64_t)p.Ho * p.Wo < (1ll << 32) && (reinterpret_cast<uintptr_t>(out.ptr) % 16 == 0) && out.c_stride % 4 == 0 &&
                      out.t_stride % 4 == 0 && out.y_stride % 4 == 0;
     if (vec) {
         const unsigned wq = (unsigned)(p.Wo / 4), items = wq * (unsigned)p.Ho;
-        const dim3 grid((unsigned)ceil_div(items, 256), (unsigned)(C * p.To));
+        const dim3 grid((unsigned)ceil_div(items, 256), (unsigned)(C * p.To), (unsigned)cb.nb);
         if (sx == 2) hipLaunchKernelGGL(upsample_vec4_kernel<2>, grid, dim3(256), 0, s, p, wq, items);
         else hipLaunchKernelGGL(upsample_vec4_kernel<4>, grid, dim3(256), 0, s, p, wq, items);
     } else {
         const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 256 * 16);
-        hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(upsample_trilinear_kernel, dim3(blocks, (unsigned)cb.nb), dim3(256), 0, s, p);
     }
     profile_end(ev, s);
     SS_LAUNCH_CHECK();

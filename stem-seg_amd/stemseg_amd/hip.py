@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class Volume(C.Structure):
@@ -28,7 +28,8 @@ class DecoderDesc(C.Structure):
                 ("T", C.c_int32), ("H4", C.c_int32), ("W4", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
                 ("pool", C.c_int32 * 3), ("t_scale", C.c_int32 * 3), ("n_out", C.c_int32),
                 ("act", C.c_int32 * (2 * MAX_EMB_DIMS)), ("grid_axis", C.c_int32 * (2 * MAX_EMB_DIMS)),
-                ("input_layout", C.c_int32), ("concurrency", C.c_int32), ("detached", C.c_int32), ("precision", C.c_int32)]
+                ("input_layout", C.c_int32), ("concurrency", C.c_int32), ("detached", C.c_int32), ("precision", C.c_int32),
+                ("n_clips", C.c_int32), ("feat_clip_stride", C.c_int64 * 4), ("out_clip_stride", C.c_int64)]
 
 
 class DecoderWeights(C.Structure):
@@ -227,6 +228,15 @@ def flat_volume(t):
 def alloc_padded(Cn, T, H, W, device="cuda"):
     g = padded_geometry(Cn, T, H, W)
     return torch.zeros(g["total"], dtype=torch.float32, device=device), g
+
+
+def alloc_padded_batch(n, Cn, T, H, W, device="cuda"):
+    """``n`` zero-haloed buffers of one geometry in ONE allocation, a fixed stride apart (a multiple of 64 floats): the inputs of a
+    clip-batched decoder call (StemsegDecoderDesc.feat_clip_stride).  -> (list of n buffer views, geometry, stride in floats)"""
+    g = padded_geometry(Cn, T, H, W)
+    stride = (g["total"] + 63) // 64 * 64
+    whole = torch.zeros(n * stride, dtype=torch.float32, device=device)
+    return [whole[c * stride:c * stride + g["total"]] for c in range(n)], g, stride
 
 
 def padded_halo_view(buf, g, Cn, T, H, W):

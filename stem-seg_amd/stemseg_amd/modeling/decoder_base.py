@@ -138,12 +138,20 @@ class SqueezeExpandTrunk(nn.Module):
         hip.check(hip.lib().stemseg_hip_decoder_join(int(self.concurrency), hip.stream()))
 
     @torch.no_grad()
-    def run_hip(self, feats, input_layout=None, act_override=None):
+    def run_hip(self, feats, input_layout=None, act_override=None, clip_batch=None):
         """feats: 4 device tensors (32x,16x,8x,4x) for ONE sample: dense [C,T,h,w] (layout 0), dense [T,C,h,w]
         (layout 1) or zero-haloed flat buffers (layout 2, then T/H4/W4 must be given via ``feats_shape``).
-        Returns [n_out, T, H4, W4]."""
+        Returns [n_out, T, H4, W4].
+        ``clip_batch = (n, strides)``: layout 2 only -- ``feats`` are clip 0's buffers and clip c's lie ``strides[level] * c`` floats
+        further (hip.alloc_padded_batch); all n clips go through ONE launch per decoder stage (StemsegDecoderDesc.n_clips) and the
+        result is [n, n_out, T, H4, W4].  A clip's output is bit-identical to its single-clip call."""
         hip.require_gpu()
         layout = self.input_layout if input_layout is None else input_layout
+        nb = 1
+        if clip_batch is not None:
+            nb, bstrides = int(clip_batch[0]), [int(v) for v in clip_batch[1]]
+            if layout != 2 or nb < 1 or len(bstrides) != 4:
+                raise ValueError("clip_batch needs zero-haloed inputs (layout 2) and one stride per level")
         if layout == 2:
             bufs, (T, H4, W4) = feats
         else:
@@ -162,7 +170,11 @@ class SqueezeExpandTrunk(nn.Module):
         d.concurrency = int(self.concurrency)
         d.detached = int(bool(self.detached) and self.concurrency >= 1)
         d.precision = hip.PRECISIONS[self.precision]
-        key = (T, H4, W4, layout, dev.index, self.lane)
+        if nb > 1:
+            d.n_clips = nb
+            for i in range(4):
+                d.feat_clip_stride[i] = bstrides[i]
+        key = (T, H4, W4, layout, dev.index, self.lane, nb)
         ws = self._workspaces.get(key)
         if ws is None:
             nbytes = hip.lib().stemseg_hip_decoder_workspace_bytes(C.byref(d))
@@ -182,7 +194,7 @@ class SqueezeExpandTrunk(nn.Module):
         gt, gy, gx = self._grid(c, T, H4, W4, dev)
         if gt is not None:
             w.grid_t, w.grid_y, w.grid_x = gt.data_ptr(), gy.data_ptr(), gx.data_ptr()
-        out = torch.empty(d.n_out, T, H4, W4, dtype=torch.float32, device=dev)
+        out = torch.empty((nb, d.n_out, T, H4, W4) if clip_batch is not None else (d.n_out, T, H4, W4), dtype=torch.float32, device=dev)
         fp = (C.c_void_p * 4)(*[b.data_ptr() for b in bufs])
         hip.check(hip.lib().stemseg_hip_decoder_forward(C.byref(d), C.byref(w), fp, hip.ptr(out), hip.ptr(ws), ws.numel(), hip.stream()))
         return out

@@ -93,6 +93,6 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
         return torch.stack([self.run_hip([f[n] for f in x], 0, act) for n in range(x[0].shape[0])], 0)
 
     @torch.no_grad()
-    def forward_single(self, feats, input_layout):
-        """One sample, encoder-native layouts (1: [T,C,h,w]; 2: (zero-haloed buffers, (T,H4,W4)))."""
-        return self.run_hip(feats, input_layout, self._acts())
+    def forward_single(self, feats, input_layout, clip_batch=None):
+        """One sample, encoder-native layouts (1: [T,C,h,w]; 2: (zero-haloed buffers, (T,H4,W4))); ``clip_batch``: see run_hip."""
+        return self.run_hip(feats, input_layout, self._acts(), clip_batch=clip_batch)

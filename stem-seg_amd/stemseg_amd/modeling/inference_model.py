@@ -76,6 +76,8 @@ class InferenceModel(nn.Module):
         self.outputs_on_cpu = outputs_on_cpu
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
+        self._pad_blocks = []
+        self.batch_decoders = True       # the clips of an encoder pass go through each decoder stage in one launch (False: clip by clip; A/B, same bits)
         self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
         self.lane = 0
         self.eval()
@@ -144,14 +146,24 @@ class InferenceModel(nn.Module):
             getattr(self._model, n_).precision = v
 
     # ---- one clip ----------------------------------------------------------------------------------
-    def _padded_feature_buffers(self, T, H, W, dev, slot=0):
-        """Four zero-haloed buffers [256][T+2][h+2][pitch], allocated once per shape (halos stay zero); ``slot`` selects one
-        of several independent sets (one per clip when clips share an encoder pass)."""
-        key = (T, H, W, dev.index, slot, self.lane)
-        if key not in self._pads:
+    def _pad_block(self, T, H, W, dev, n):
+        """>= n sets ("slots") of four zero-haloed buffers [256][T+2][h+2][pitch] (halos stay zero), one set per clip of an encoder pass.
+        The slots of a block are ONE allocation per level, a fixed stride apart: what a clip-batched decoder call needs
+        (StemsegDecoderDesc.feat_clip_stride).  A request for more slots than the current block holds makes a larger block current;
+        earlier blocks stay alive (captured graphs replay on them)."""
+        key = (T, H, W, dev.index, self.lane)
+        blk = self._pads.get(key)
+        if blk is None or blk["n"] < n:
             Cn = self._model.backbone.out_channels
-            self._pads[key] = [hip.alloc_padded(Cn, T, H // s, W // s, dev) for s in (32, 16, 8, 4)]
-        return self._pads[key]
+            levels = [hip.alloc_padded_batch(n, Cn, T, H // s, W // s, dev) for s in (32, 16, 8, 4)]
+            blk = dict(n=n, pads=[[(levels[k][0][c], levels[k][1]) for k in range(4)] for c in range(n)], strides=[levels[k][2] for k in range(4)])
+            self._pad_blocks.append(blk)
+            self._pads[key] = blk
+        return blk
+
+    def _padded_feature_buffers(self, T, H, W, dev, slot=0):
+        """The four buffers of ``slot`` in the current block (see _pad_block)."""
+        return self._pad_block(T, H, W, dev, slot + 1)["pads"][slot]
 
     @torch.no_grad()
     def embed_clip(self, feature_maps, T, H, W):
@@ -191,13 +203,16 @@ class InferenceModel(nn.Module):
         NT, _, H, W = frames.shape
         assert NT % n_clips == 0
         T, dev, Cn = NT // n_clips, frames.device, m.backbone.out_channels
-        pads = [self._padded_feature_buffers(T, H, W, dev, slot=c) for c in range(n_clips)]
+        blk = self._pad_block(T, H, W, dev, n_clips)
+        pads = blk["pads"]
         vols = []
         for c in range(n_clips):
             v = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads[c], (32, 16, 8, 4))}
             vols += [v[s] for s in (4, 8, 16, 32)]
         m.backbone.run_backbone_into(frames, vols)
-        return [self._run_heads(pads[c], T, H, W, dev, slot=c) for c in range(n_clips)]
+        if not self.batch_decoders:
+            return [self._run_heads(pads[c], T, H, W, dev, slot=c) for c in range(n_clips)]
+        return self._run_heads(pads[0], T, H, W, dev, batch=(n_clips, blk["strides"]))
 
     @torch.no_grad()
     def embed_frames_windows(self, frames, n_clips, clip_frames, clip_stride):
@@ -211,27 +226,46 @@ class InferenceModel(nn.Module):
         NT, _, H, W = frames.shape
         assert NT == (n_clips - 1) * clip_stride + clip_frames
         T, dev, Cn = clip_frames, frames.device, m.backbone.out_channels
-        pads = [self._padded_feature_buffers(T, H, W, dev, slot=c) for c in range(n_clips)]
+        blk = self._pad_block(T, H, W, dev, n_clips)
+        pads = blk["pads"]
         vols = []
         for c in range(n_clips):
             v = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads[c], (32, 16, 8, 4))}
             vols += [v[s] for s in (4, 8, 16, 32)]
         m.backbone.run_backbone_into(frames, vols, window=(clip_frames, clip_stride))
-        return [self._run_heads(pads[c], T, H, W, dev, slot=c) for c in range(n_clips)]
+        if not self.batch_decoders:
+            return [self._run_heads(pads[c], T, H, W, dev, slot=c) for c in range(n_clips)]
+        return self._run_heads(pads[0], T, H, W, dev, batch=(n_clips, blk["strides"]))
 
     @torch.no_grad()
-    def _run_heads(self, pads, T, H, W, dev, slot=0):
+    def _run_heads(self, pads, T, H, W, dev, slot=0, batch=None):
+        """Both decoders + heads on the clip whose features sit in ``pads`` -> (emb, bw, seed).  ``batch = (n, strides)``: ``pads`` is
+        slot 0 of a block (_pad_block) and the n clips of the block go through every decoder stage in ONE launch (the decoders'
+        clip batch) -> list of n (emb, bw, seed)."""
+        if batch is not None:
+            emb, bw, seed = self._run_heads_impl(pads, T, H, W, dev, batch)
+            return [(emb[c], bw[c], seed[c]) for c in range(batch[0])]
+        return self._run_heads_impl(pads, T, H, W, dev, None)
+
+    def _run_heads_impl(self, pads, T, H, W, dev, batch):
         m = self._model
         feats = ([b for b, _ in pads], (T, H // 4, W // 4))
+        r = int(self.resize_scale)
+
+        def resized(seed):
+            if batch is None:
+                return hip.upsample_trilinear(seed.contiguous(), 1, r, r)
+            return torch.stack([hip.upsample_trilinear(seed[c].contiguous(), 1, r, r) for c in range(batch[0])], 0)
+        ch = (lambda t, a, b: t[a:b]) if batch is None else (lambda t, a, b: t[:, a:b])
         eh = m.embedding_head
         eh.fuse_bandwidth_activation = True                                             # inference_model.py:148 fused
         seed = None
         eh.concurrency = 1 if self.overlap_decoders else 0
         if eh.seediness_channels == 0 and not self.overlap_decoders:
             m.seediness_head.concurrency, m.seediness_head.detached = 0, False
-            seed = m.seediness_head.forward_single(feats, 2)
+            seed = m.seediness_head.forward_single(feats, 2, clip_batch=batch)
             if self.resize_scale != 1.0:
-                seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+                seed = resized(seed)
             main = None
         elif eh.seediness_channels == 0:
             # the seediness decoder shares nothing with the embedding decoder but its (read-only) inputs: enqueue it
@@ -240,18 +274,18 @@ class InferenceModel(nn.Module):
             assert m.seediness_head is not None
             sh = m.seediness_head
             sh.concurrency, sh.detached = 2, True
-            seed = sh.forward_single(feats, 2)
+            seed = sh.forward_single(feats, 2, clip_batch=batch)
             main = sh
-        out = eh.forward_single(feats, 2)
+        out = eh.forward_single(feats, 2, clip_batch=batch)
         E, Ev = eh.embedding_size, eh.variance_channels
-        emb, bw = out[:E], out[E:E + Ev]
+        emb, bw = ch(out, 0, E), ch(out, E, E + Ev)
         if seed is None:
-            seed = out[E + Ev:]
+            seed = ch(out, E + Ev, out.shape[0 if batch is None else 1])
         elif main is not None:
             main.join()
             main.detached = False
             if self.resize_scale != 1.0:                                                # inference_model.py:156 quirk
-                seed = hip.upsample_trilinear(seed.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
+                seed = resized(seed)
         return emb, bw, seed
 
     @torch.no_grad()

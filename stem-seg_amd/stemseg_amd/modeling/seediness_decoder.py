@@ -31,5 +31,5 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
         return torch.stack([self.run_hip([f[n] for f in x], 0) for n in range(x[0].shape[0])], 0)
 
     @torch.no_grad()
-    def forward_single(self, feats, input_layout):
-        return self.run_hip(feats, input_layout, None)
+    def forward_single(self, feats, input_layout, clip_batch=None):
+        return self.run_hip(feats, input_layout, None, clip_batch=clip_batch)

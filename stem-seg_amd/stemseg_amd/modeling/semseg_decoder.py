@@ -47,6 +47,7 @@ class SqueezeExpandDecoder(SqueezeExpandTrunk):
         return torch.stack([self.run_hip([f[n] for f in x], 0)[:self.out_channels] for n in range(x[0].shape[0])], 0)
 
     @torch.no_grad()
-    def forward_single(self, feats, input_layout):
+    def forward_single(self, feats, input_layout, clip_batch=None):
         """feats in the trunk's order (32x, 16x, 8x, 4x)."""
-        return self.run_hip(feats, input_layout, None)[:self.out_channels]
+        out = self.run_hip(feats, input_layout, None, clip_batch=clip_batch)
+        return out[:self.out_channels] if clip_batch is None else out[:, :self.out_channels]

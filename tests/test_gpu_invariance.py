@@ -167,6 +167,52 @@ def test_embeddings_are_bit_identical_for_every_batch_shape_and_entry_point(hip)
         config.load_preset("defaults")
 
 
+# ------------------------------------------------------------------------------------------------ the decoders' clip batch
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("which", ["embedding", "seediness", "semseg_wide", "embedding_no_norm"])
+def test_decoder_clip_batch_is_bit_identical_to_single_clip_calls(hip, which, precision):
+    """The decoders run all clips of a step in ONE launch per stage (StemsegDecoderDesc.n_clips: the clip is a grid dimension of every
+    kernel -- conv + GroupNorm partial sums + split-K reduce, finalize, apply + pool, trilinear up-sampling, 1x1x1 fuse, heads).
+    Every launch decision is taken on one clip's shape, so clip c of a batch of 3 must equal the single-clip call on clip c's
+    inputs BIT FOR BIT -- for the fused 6-channel heads, the seediness decoder, the 41-class head that goes through the MFMA conv
+    and a decoder without normalisation layers (max pooling)."""
+    from stemseg_amd.modeling.embedding_decoder import SqueezingExpandDecoder as Emb
+    from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
+    from stemseg_amd.modeling.semseg_decoder import SqueezeExpandDecoder as Sem
+    T, h32, w32, N = 8, 3, 5, 3
+    gn = lambda c: torch.nn.GroupNorm(32, c)     # noqa: E731
+    if which == "embedding":
+        m = Emb(256, [256, 256, 128, 128], 4, True, False, "xyff", NormType=gn, num_frames=T)
+    elif which == "embedding_no_norm":
+        m = Emb(256, [256, 256, 128, 128], 5, True, True, "xytff", PoolType=torch.nn.MaxPool3d, NormType=lambda c: torch.nn.Identity(), num_frames=T)
+    elif which == "seediness":
+        m = Seed(256, [256, 256, 128, 128], NormType=gn, num_frames=T)
+    else:
+        m = Sem(256, 40, [128, 128, 64, 64], (4, 8, 16, 32), foreground_channel=True, NormType=gn, num_frames=T)
+    sd = synth.synth_state_dict([(k, v.shape) for k, v in m.state_dict().items()], 19, prefix="x.")
+    if which == "embedding_no_norm":
+        sd = {k: (np.asarray(v) * (0.35 if np.asarray(v).ndim == 5 and np.asarray(v).shape[-1] == 3 else 1.0)).astype(np.float32) for k, v in sd.items()}
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(m.state_dict()[k].shape) for k, v in sd.items()})
+    m = m.cuda().eval()
+    m.precision = precision
+    Cn = 256
+    levels = [hip.alloc_padded_batch(N, Cn, T, h32 * s, w32 * s, "cuda") for s in (1, 2, 4, 8)]      # 32x, 16x, 8x, 4x
+    for c in range(N):
+        feats = synth.synth_features(T, h32, w32, seed=60 + c)
+        for (bufs, g, _), f, s in zip(levels, feats, (1, 2, 4, 8)):
+            hip.copy_to_volume(dev(f), 0, hip.padded_interior_view(bufs[c], g, Cn, T, h32 * s, w32 * s))
+    shape = (T, h32 * 8, w32 * 8)
+    singles = [m.forward_single(([lv[0][c] for lv in levels], shape), 2).clone() for c in range(N)]
+    batch = m.forward_single(([lv[0][0] for lv in levels], shape), 2, clip_batch=(N, [lv[2] for lv in levels]))
+    torch.cuda.synchronize()
+    assert batch.shape[0] == N and batch.shape[1:] == singles[0].shape
+    assert not torch.equal(singles[0], singles[1])
+    for c in range(N):
+        assert torch.equal(batch[c], singles[c]), "%s %s: clip %d of the batch differs from its single-clip call" % (which, precision, c)
+    bad, where = m.check_workspaces()
+    assert bad == 0, "guard words clobbered: %s" % (where,)
+
+
 # ------------------------------------------------------------------------------------------------ the sequence, world 1 / 2 / 3 / 8
 def test_sequence_label_checksum_is_the_same_at_world_1_2_3_8(hip):
     """bench.py --sequence at reduced size (52 frames -> 12 clips, R-50, 96 x 160) with the REAL embedding path of every rank: rank r
