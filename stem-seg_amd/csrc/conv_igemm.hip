@@ -170,7 +170,7 @@ struct ConvCfg {
     static constexpr int IN_PLANE_STRIDE = (CK / 2) * IN_PAIR_STRIDE;   // X6: words of one bf16 plane
     static constexpr int IN_FLOATS = X6 ? NPX * IN_PLANE_STRIDE : CK * IN_CH_STRIDE;
     // k-groups of 16 (split-staged modes): taps per group / channels per lane-half, by kernel class (27 taps: 4 x 2, 9 taps: 2 x 4, 1 tap: 1 x 8)
-    static constexpr int TPG = TAPS >= 27 ? 4 : (TAPS >= 9 ? 2 : 1);
+    static constexpr int TPG = TAPS >= 27 ? 4 : ((TAPS >= 9 && CK_ < 16) ? 2 : 1);   // (9 taps in 16-channel chunks: one tap x 16 channels per group -- nine groups, no padded tap slot)
     static constexpr int CPH = 8 / TPG;
     static constexpr int NTG = (TAPS + TPG - 1) / TPG;                  // tap groups
     static constexpr int NCG = BF ? CK / (2 * CPH) : 1;                 // channel groups per chunk
@@ -1345,20 +1345,24 @@ using K3FlatSmall56 = ConvCfg<3, 3, 3, 4, 2, 1, 2, 2, 2, true, 0, false, 56>;
 // workgroup per CU, two waves per SIMD); 2-D and 1x1 tiles keep four-wave shapes (two workgroups per CU) except the big ones
 template <int BFV>
 struct SplitTiles {
+    // 1x3x3 chunks: f16x3 takes 16 channels -- a k-group is then ONE tap x 16 channels and the nine taps fill nine groups exactly; with 8
+    // channels a group is two taps x 8 channels and the ninth tap drags a zero tap along: 10 % of the class's MFMAs multiplied zeros
+    // (the chip is power-bound under these streams, so MFMAs not issued are time).  bf16x6's three planes of 16 channels do not fit the LDS.
+    static constexpr int CK2 = BFV == 3 ? 16 : 8;
     using Y3Big = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 1, false, BFV>;   // 128 co x (16 rows x 32 cols), 512 threads
     using Y3Med = ConvCfg<3, 3, 3, 4, 2, 2, 2, 4, 1, false, BFV>;   // 128 co x ( 8 rows x 32 cols), 512 threads
     using Y3Small = ConvCfg<3, 3, 3, 4, 2, 1, 2, 4, 1, false, BFV>; // 128 co x ( 4 rows x 32 cols), 512 threads
-    using Y2Big = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 1, false, BFV>;   // 128 co x (16 rows x 32 cols), 512 threads (the weight prefetch of a four-wave tile spills)
-    using Y2Med = ConvCfg<1, 3, 3, 8, 2, 2, 2, 2, 1, false, BFV>;   // 128 co x (4 rows x 32 cols)
-    using Y2Small = ConvCfg<1, 3, 3, 8, 2, 1, 2, 2, 1, false, BFV>; // 128 co x (2 rows x 32 cols)
-    using Y2M64 = ConvCfg<1, 3, 3, 8, 2, 2, 1, 4, 1, false, BFV>;   //  64 co x (8 rows x 32 cols)
+    using Y2Big = ConvCfg<1, 3, 3, CK2, 4, 2, 1, 8, 1, false, BFV>;   // 128 co x (16 rows x 32 cols), 512 threads (the weight prefetch of a four-wave tile spills)
+    using Y2Med = ConvCfg<1, 3, 3, CK2, 2, 2, 2, 2, 1, false, BFV>;   // 128 co x (4 rows x 32 cols)
+    using Y2Small = ConvCfg<1, 3, 3, CK2, 2, 1, 2, 2, 1, false, BFV>; // 128 co x (2 rows x 32 cols)
+    using Y2M64 = ConvCfg<1, 3, 3, CK2, 2, 2, 1, 4, 1, false, BFV>;   //  64 co x (8 rows x 32 cols)
     using Y1Big = ConvCfg<1, 1, 1, 32, 4, 2, 1, 4, 8, false, BFV>;  // 128 co x 256 voxels
     using Y1Small = ConvCfg<1, 1, 1, 32, 2, 2, 2, 2, 4, false, BFV>; // 128 co x 128 voxels
     using Y1M64 = ConvCfg<1, 1, 1, 32, 2, 2, 1, 4, 8, false, BFV>;  //  64 co x 256 voxels
     using Y1Wide = ConvCfg<1, 1, 1, 32, 4, 2, 2, 4, 8, false, BFV>; // 256 co x 256 voxels, 512 threads: an input element is split once per 256 output channels
     // flat (ragged-width) form of the big 2-D tile: 128 co x 512 flat positions of the whole [T][H + 2][pitch] run (across the
     // frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
-    template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, 8, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
+    template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, CK2, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
     // Measured in round 5 and not kept (profiles/r05b_conv_sweep_f16x3_T32.txt, tile_cfg 6 / 7 / 8 of that build): four-wave halves of the
     // eight-wave tiles, two per CU so that one's staging phases run under the other's MFMA stream -- block_4x 1 076 vs 1 006 us, layer-3 3x3
     // 214 vs 203, 1024 -> 256 110 vs 107, 256 -> 1024 + residual 170 vs 154; and 64-channel chunks for the 1x1 tiles (half the chunk
@@ -1822,16 +1826,23 @@ extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32
 }
 
 // bytes of the split-staged packing with `planes` 16-bit planes: per channel chunk [k-group][plane][lane half][Cout] x 16 B
-static int64_t split_packed_bytes(int32_t Cout, int32_t Cin, int32_t taps, int planes) {
-    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
+// (channel chunk, taps per k-group) of the split-staged packing: must match SplitTiles<precision>
+static void split_chunking(int taps, int precision, int& CK, int& TPG) {
+    if (taps == 27) { CK = 4; TPG = 4; }
+    else if (taps == 9) { CK = precision == STEMSEG_PRECISION_F16X3 ? 16 : 8; TPG = precision == STEMSEG_PRECISION_F16X3 ? 1 : 2; }
+    else { CK = 32; TPG = 1; }
+}
+static int64_t split_packed_bytes(int32_t Cout, int32_t Cin, int32_t taps, int planes, int precision) {
+    int CK, TPG;
+    split_chunking(taps, precision, CK, TPG);
     const int CPH = 8 / TPG, NTG = (taps + TPG - 1) / TPG, NCG = CK / (2 * CPH);
     return (int64_t)((Cin + CK - 1) / CK) * planes * (NTG * NCG) * 2 * Cout * 16;
 }
 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
     if (Cout <= 0 || Cin <= 0 || !(taps == 27 || taps == 9 || taps == 1)) return 0;
-    if (precision == STEMSEG_PRECISION_BF16X6) return split_packed_bytes(Cout, Cin, taps, 3);
-    if (precision == STEMSEG_PRECISION_F16X3) return split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES) + 8 * (int64_t)Cout;      // planes + per output channel: float 1 / scale, uint32 bits of max|w|
+    if (precision == STEMSEG_PRECISION_BF16X6) return split_packed_bytes(Cout, Cin, taps, 3, precision);
+    if (precision == STEMSEG_PRECISION_F16X3) return split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES, precision) + 8 * (int64_t)Cout;      // planes + per output channel: float 1 / scale, uint32 bits of max|w|
     return 0;
 }
 
@@ -1840,17 +1851,18 @@ extern "C" int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, i
     SS_CHECK_ARG(precision == STEMSEG_PRECISION_BF16X6 || precision == STEMSEG_PRECISION_F16X3, "pack_conv_weight_prec: precision must be 2 (bf16x6) or 3 (f16x3)");
     SS_CHECK_ARG(w && packed, "pack_conv_weight_prec: null pointer");
     SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_prec: taps must be 27, 9 or 1");
-    const int CK = taps == 27 ? 4 : (taps == 9 ? 8 : 32), TPG = taps == 27 ? 4 : (taps == 9 ? 2 : 1);
+    int CK, TPG;
+    split_chunking(taps, precision, CK, TPG);
     SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_prec: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);
     if (precision == STEMSEG_PRECISION_BF16X6) {
-        const int64_t n = split_packed_bytes(Cout, Cin, taps, 3) / 16;
+        const int64_t n = split_packed_bytes(Cout, Cin, taps, 3, precision) / 16;
         const int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
         hipLaunchKernelGGL(pack_conv_weight_bf16x6_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, reinterpret_cast<uint4*>(packed), Cout, Cin,
                            taps, CK, TPG);
         SS_LAUNCH_CHECK();
         return STEMSEG_OK;
     }
-    const int64_t n = split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES) / 16;
+    const int64_t n = split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES, precision) / 16;
     unsigned int* max_bits = reinterpret_cast<unsigned int*>(reinterpret_cast<float*>(reinterpret_cast<uint4*>(packed) + n) + Cout);
     hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)Cout), dim3(256), 0, as_stream(stream), w, (int64_t)Cin * taps, max_bits);
     SS_LAUNCH_CHECK();

@@ -600,6 +600,26 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             }
             continue;
         }
+        // ... in ONE launch when the clips' consumer volumes lie a fixed stride apart (the decoders' clip batch allocates them so): the clip
+        // is a grid dimension of the conv (decided, like every launch of the pass, on the planning shape: same bits either way)
+        bool uniform = desc->n_clips > 1 && desc->n_clips <= 65535;
+        const int64_t obs = uniform ? out[4 + k].ptr - out[k].ptr : 0;
+        for (int c = 1; c < desc->n_clips && uniform; ++c) {
+            const StemsegVolume &a = out[4 * c + k], &b = out[k];
+            uniform = a.ptr == b.ptr + c * obs && a.c_stride == b.c_stride && a.t_stride == b.t_stride && a.y_stride == b.y_stride && a.limit == b.limit;
+        }
+        if (uniform && obs > 0 && obs % 4 == 0) {
+            StemsegVolume in = halo2d_view(ws + p.L[k], 256, T, h, w);
+            ConvEpilogue ec = epi_for(Tc);
+            ec.nb = desc->n_clips;
+            ec.in_bs = (int64_t)Ts * in.t_stride;
+            ec.out_bs = obs;
+            in.limit -= (int64_t)(desc->n_clips - 1) * ec.in_bs;        // (the last clip's room: every clip reads Tc frames from its own origin)
+            in.T = Tc;
+            rc = launch_conv3d(in, wts->fpn_layer_w[k], wts->fpn_layer_b[k], out[k], 1, 3, 3, 0, s, ws + p.SK, p.SKfloats, &ec);
+            if (rc) return rc;
+            continue;
+        }
         for (int c = 0; c < desc->n_clips; ++c) {
             StemsegVolume in = halo2d_view(ws + p.L[k], 256, T, h, w);
             in.ptr += (int64_t)c * Ts * in.t_stride;

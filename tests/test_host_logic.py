@@ -89,6 +89,10 @@ def test_cabi_struct_sizes_and_argument_errors():
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 1) == 0                       # (code 1, the retired two-term bf16 split)
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f16x3"]) in (split2 + 8 * 128, split3 + 8 * 128)      # (two or three staged weight planes: SS_F16_WPLANES)
     assert l.stemseg_hip_packed_weight_bytes_prec(256, 1024, 1, hip.PRECISIONS["f16x3"]) in (32 * 2 * 2 * 2 * 256 * 16 + 8 * 256, 32 * 2 * 3 * 2 * 256 * 16 + 8 * 256)
+    # 1x3x3: bf16x6 packs 8-channel chunks of five k-groups (two taps x 8 channels, the ninth tap beside a zero one), f16x3 16-channel chunks of
+    # nine (one tap x 16 channels: no padded tap slot)
+    assert l.stemseg_hip_packed_weight_bytes_prec(256, 256, 9, hip.PRECISIONS["bf16x6"]) == (256 // 8) * 3 * 5 * 2 * 256 * 16
+    assert l.stemseg_hip_packed_weight_bytes_prec(256, 256, 9, hip.PRECISIONS["f16x3"]) in ((256 // 16) * 2 * 9 * 2 * 256 * 16 + 8 * 256, (256 // 16) * 3 * 9 * 2 * 256 * 16 + 8 * 256)
     assert l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, hip.PRECISIONS["f32"]) == 0 and l.stemseg_hip_packed_weight_bytes_prec(128, 256, 27, 7) == 0
     assert sorted(hip.PRECISIONS) == sorted(hip.PRECISION_INFO) and hip.PRECISION_INFO["f16x3"]["operand_significand_bits"] == 22
     # encoder plan offsets (debugging aid): distinct offsets, the first buffer at 0, the last value = the workspace size in floats
