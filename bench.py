@@ -679,12 +679,14 @@ def main():
                 hbm.append({"kernel": name, "launches_per_clip": round(n_ * per_clip, 2), "mb_per_clip": round(by * per_clip / 1e6, 2),
                             "us_per_clip": round(1e3 * m_ * per_clip, 1), "gb_per_s": round(by / m_ / 1e6, 1),
                             "frac_of_hbm_peak": round(by / m_ / 1e6 / PEAK_HBM_GBPS, 3)})
+        eff_clock = None
         traffic, traffic_note = None, "not collected in this process: PMC counters need their own rocprofv3 --pmc passes (tools/gpu_round.sh pmc)"
         tfile = TRAFFIC_FILE if args.precision == "f32" else TRAFFIC_FILE.replace("_latest", "_%s_latest" % args.precision)
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 traffic, traffic_note = tj["gb_per_launch_group"], "offline, %s: %s" % (os.path.relpath(tfile, ROOT), tj["note"])
+                eff_clock = tj.get("effective_clock_ghz")
             except Exception as e:  # noqa: BLE001
                 traffic_note = "could not read %s: %r" % (tfile, e)
         res = {
@@ -707,6 +709,12 @@ def main():
                          "frac_note": "the roof is the 16-bit MFMA peak / products per fp32 product (f16x3 3, bf16x6 6): it doubles whenever a mode halves the "
                                       "matrix work, so frac is not comparable across modes -- the two achieved_vs_* keys restate it against the earlier roofs",
                          "traffic": traffic, "traffic_note": traffic_note,
+                         "power_bound": {"sustained_clock_ghz": eff_clock, "nominal_clock_ghz": 2.4,
+                                         "frac_of_roof_at_sustained_clock": round(ach / (peak * eff_clock / 2.4), 4) if eff_clock else None,
+                                         "note": "the roof assumes 2.4 GHz; under these MFMA streams the chip clocks to its power budget (effective clock = "
+                                                 "GRBM_GUI_ACTIVE / kernel time, same offline PMC file as `traffic`), and the same launches on all-zero "
+                                                 "activations -- identical instruction stream -- run 20-25 % faster (profiles/r05i_dvfs_zero_inputs.txt): a better "
+                                                 "schedule of the same work comes back as a lower clock, only work not done is time (DESIGN.md section 5f)"},
                          "launches": launches, "avg_launch_ms": round(ms / max(launches, 1), 4),
                          "how": "hipEvent pairs (in-library profiler, on the launch's own stream) around every tagged launch over %d eager "
                                 "single-stream steps right after the timed region; conv launches include their split-K reduce; a launch = one "

@@ -578,6 +578,9 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
                            ws + p.SK, p.SKfloats, &e);
         if (rc) return rc;
         if (k < 3) {
+            // (Measured in round 5 and not kept: the add fused into the lateral conv's epilogue -- four gathered coarse loads per output
+            // element in the by-element epilogue of a flat launch.  The separate pass goes (-0.22 ms per clip), the 1x1 class pays +0.38 ms
+            // and every tile's kernel arguments grow: the step 103.0 vs 104.8 clips/s, interleaved on one box.)
             Padded2D gf(256, T, h, w), gc(256, T, p.h[k + 1], p.w[k + 1]);
             void* ev = profile_begin(50, 4.0 * 256.0 * (2.0 * p.V[k] + p.V[k + 1]), s);         // fine read + written, coarse read
             hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid1d(256 * p.V[k])), dim3(256), 0, s, ws + p.L[k] + gf.interior,

@@ -56,6 +56,20 @@ if "SQ_WAIT_ANY" in sq and "SQ_WAVE_CYCLES" in sq:
     wc = sum(v[0] for v in sq["SQ_WAVE_CYCLES"].values())
     lines.append("wave time parked (s_waitcnt / barrier)  %.1f %%, issue-stalled %.1f %%, issuing %.1f %%" % tuple(
         100.0 * sum(v[0] for v in sq[k].values()) / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")))
+# effective clock of the conv kernel in the pass that carried GRBM_GUI_ACTIVE: active cycles per XCD / kernel time of the same dispatches (the
+# chip clocks to its power budget: MI355X_MICROARCH.md "DVFS give-back"; 2.4 GHz is what the roofline's peak assumes)
+if "GRBM_GUI_ACTIVE" in sq:
+    try:
+        dbs = glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_SQ_WAVES*", "**", "*.db"), recursive=True)
+        con = sqlite3.connect(dbs[0])
+        ns = sum(e - b for name, b, e in con.execute("select name, start, end from kernels") if "conv_igemm" in name)
+        cyc = sq["GRBM_GUI_ACTIVE"].get("conv_igemm", [0.0])[0] / 8.0
+        if ns > 0 and cyc > 0:
+            ghz = cyc / ns
+            lines.append("effective clock               %.2f GHz  (GRBM_GUI_ACTIVE per XCD / kernel time of the same dispatches; the roofline's peak assumes 2.4)" % ghz)
+            res["effective_clock_ghz"] = round(ghz, 3)
+    except Exception as e:      # (older rocprofv3 schema: no kernels view)
+        lines.append("effective clock               n/a (%r)" % (e,))
 lines += [l.rstrip() for l in open(os.path.join(ROOT, "gpurun_out", "pmc_FETCH_SIZE.log")).read().splitlines() if l.startswith("conv3d_k3")][:1] \
     if os.path.exists(os.path.join(ROOT, "gpurun_out", "pmc_FETCH_SIZE.log")) else []
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
