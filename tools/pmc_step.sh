@@ -25,7 +25,7 @@ db = glob.glob("gpurun_out/pmc_step_FETCH_SIZE/**/*.db", recursive=True)[0]
 con = sqlite3.connect(db)
 n_enc = con.execute("select count(*) from counters_collection where kernel_name like '%stem_conv7x7%' and counter_name='FETCH_SIZE'").fetchone()[0]
 n_dec = con.execute("select count(*) from counters_collection where kernel_name like '%heads_kernel%' and counter_name='FETCH_SIZE'").fetchone()[0]
-clips = n_dec / 2.0
+clips = n_enc * 4.0                                   # (bench default: 4 clips per encoder pass; the decoders take all of them per launch)
 print("encoder passes %d, clips %.1f" % (n_enc, clips))
 keys = sorted(set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"]), key=lambda k: -(tot["FETCH_SIZE"].get(k, 0) + tot["WRITE_SIZE"].get(k, 0)))
 print("%-44s %10s %10s   (GB per clip)" % ("kernel family", "fetch", "write"))

@@ -25,7 +25,8 @@ for name, s, e, gx, gy, wx, lds, vg in rows:
     a[0] += 1
     a[1] += (e - s) / 1e3
 tot = sum(a[1] for a in agg.values())
-print("# steady state: %d steps, wall %.2f ms/step, kernel-busy %.2f ms/step" % (n, (t1 - t0) / 1e6 / n, tot / 1e3 / n))
+print("# steady state: %d steps, wall %.2f ms/step, kernel-busy %.2f ms/step, %.1f kernel launches per step (%d kernel names; the 40 busiest below)"
+      % (n, (t1 - t0) / 1e6 / n, tot / 1e3 / n, sum(a[0] for a in agg.values()) / n, len(agg)))
 print("%-102s %9s %11s %10s %6s %7s %5s" % ("kernel", "calls/stp", "us/step", "avg_us", "%", "lds", "vgpr"))
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%-102s %9.1f %11.1f %10.1f %6.2f %7d %5d" % (k, a[0] / n, a[1] / n, a[1] / a[0], 100 * a[1] / tot, a[2], a[3]))

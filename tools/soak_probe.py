@@ -33,8 +33,9 @@ def padded_total(Cn, T, H, W):
     return Cn * (T + 2) * (H + 2) * pitch + 64
 
 
-def decoder_segments(mod, T, H4, W4, layout):
-    """csrc/decoder.hip make_plan, restated: [(name, offset in floats)] in workspace order."""
+def decoder_segments(mod, T, H4, W4, layout, nb=1):
+    """csrc/decoder.hip make_plan, restated: [(name, offset in floats)] in workspace order -- ``nb`` clip plans (c<clip>.<slice>), then the
+    split-K scratch the clips share."""
     cin, (c32, c16, c8, c4) = mod.in_channels, mod.inter_channels
     h = [H4 >> (3 - i) for i in range(4)]
     w = [W4 >> (3 - i) for i in range(4)]
@@ -55,8 +56,6 @@ def decoder_segments(mod, T, H4, W4, layout):
     cs = [c32, c16, c8, c4]
     for i in range(4):
         take("D%d" % i, cs[i] * T * h[i] * w[i])
-    for i, k in enumerate((16, 4, 4, 2)):
-        take("S%d" % i, k * cs[i] * T * h[i] * w[i])
     take("P32b", padded_total(c32, Ta1, h[0], w[0])); take("P32c", padded_total(c32, Ta2, h[0], w[0]))
     take("X32", c32 * Ta3 * h[0] * w[0]); take("cat16", (c32 + c16) * T16 * h[1] * w[1])
     take("P16b", padded_total(c16, Tb1, h[1], w[1])); take("X16", c16 * T16 * h[1] * w[1])
@@ -65,6 +64,11 @@ def decoder_segments(mod, T, H4, W4, layout):
     for i in range(4):
         take("stats%d" % i, 128)
         take("gn_scratch%d" % i, 2 * max((mod.gn_groups or 1) * 32768 * 2, (mod.gn_groups or 1) * 128))
+    clip_floats = ru(off, 256)
+    segs = [("c%d.%s" % (c, n), c * clip_floats + o) for c in range(nb) for n, o in segs]
+    off = nb * clip_floats
+    for i, k in enumerate((16, 4, 4, 2)):
+        take("S%d" % i, nb * k * cs[i] * T * h[i] * w[i])
     segs.append(("total", off))
     return segs
 
@@ -81,17 +85,18 @@ def lane_tensors(pipe, graph, lane, NC):
         hip.check(hip.lib().stemseg_hip_encoder_plan_offsets(C.byref(bb._desc(k[0], k[1], k[2], NC)), offs))
         segs = sorted((o, n) for o, n in zip(list(offs), ENC_NAMES) if o >= 0)
         out["encoder_ws"] = (v, [(n, o) for o, n in segs])
-    for k, v in sorted(pipe.model._pads.items()):
+    for k, blk in sorted(pipe.model._pads.items()):
         if k[-1] == lane:
-            for lvl, (bf, _) in enumerate(v):
-                out["fpn_pad_slot%d_%dx" % (k[4], (32, 16, 8, 4)[lvl])] = (bf, None)
+            for slot, v in enumerate(blk["pads"]):
+                for lvl, (bf, _) in enumerate(v):
+                    out["fpn_pad_slot%d_%dx" % (slot, (32, 16, 8, 4)[lvl])] = (bf, None)
     for name in ("embedding_head", "seediness_head", "semseg_head"):
         mod = getattr(m, name)
         if mod is None:
             continue
         for k, v in mod._workspaces.items():
-            if k[-1] == lane:
-                out["%s_ws" % name] = (v, decoder_segments(mod, k[0], k[1], k[2], k[3]))
+            if k[5] == lane:
+                out["%s_ws_nb%d" % (name, k[6])] = (v, decoder_segments(mod, k[0], k[1], k[2], k[3], k[6]))
     for i, o in enumerate(graph.out):
         n = o["frame_offsets"][-1:] if "frame_offsets" in o else None      # (device scalar: rows beyond N are never written)
         for kk, v in o.items():
