@@ -413,6 +413,7 @@ def main():
                          "label-pair tables (see the module docstring)")
     ap.add_argument("--frames", type=int, default=64, help="--sequence: frames of the sequence (64 -> 15 clips at overlap 4; 36 -> 8)")
     ap.add_argument("--workload", default="davis", choices=sorted(WORKLOADS), help="BASELINE config to run (default: configs[1], the metric's)")
+    ap.add_argument("--fp32-stem", action="store_true", help="A/B: the exact fp32-MFMA stem in f16x3 mode too (default there: space-to-depth + 4x4 conv in f16x3)")
     ap.add_argument("--no-decoder-batch", action="store_true", help="A/B: the decoders clip by clip instead of all clips of a step per launch (same bits)")
     ap.add_argument("--no-sequence-leg", action="store_true", help="clip bench: skip the attached BASELINE configs[3] leg (``sequence`` in the line)")
     ap.add_argument("--sequence-steps", type=int, default=4, help="timed sequences of the attached leg (1 warm-up)")
@@ -516,6 +517,7 @@ def main():
         meta = None
         pipe.model.set_lane(lane0)
         pipe.model.batch_decoders = not args.no_decoder_batch
+        pipe.model._model.backbone.stem_s2d = not args.fp32_stem
         if not overlap:
             pipe.model.overlap_decoders = False      # (the captured graph is single-stream; warm up in the same mode)
         for i in range(max(warmup, 1)):

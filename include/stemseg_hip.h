@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STEMSEG_HIP_ABI_VERSION 8
+#define STEMSEG_HIP_ABI_VERSION 9
 
 #define STEMSEG_OK              0
 #define STEMSEG_E_INVALID      -1   /* bad argument / unsupported shape               */
@@ -283,6 +283,10 @@ typedef struct StemsegEncoderDesc {
 typedef struct StemsegEncoderWeights {
     const float* stem_w;         /* [147][64] tap-major ((c*7+dy)*7+dx), BN folded */
     const float* stem_b;         /* [64] */
+    const float* stem_w_s2d;     /* optional, f16x3 mode: the stem as a stride-1 4x4 convolution over the space-to-depth image -- weights
+                                    [64][12][1][4][4] with W2[co][(p*2+q)*3+c][a][b] = w[co][c][2a+p-1][2b+q-1] (0 where an index is -1),
+                                    packed by stemseg_hip_pack_conv_weight_prec(taps = 16, STEMSEG_PRECISION_F16X3).  NULL: the exact
+                                    fp32-MFMA stem from stem_w in every mode */
     /* per bottleneck block, in network order; conv weights in the packed layout of stemseg_hip_pack_conv_weight */
     const float* conv1_w[STEMSEG_MAX_ENCODER_BLOCKS];   const float* conv1_b[STEMSEG_MAX_ENCODER_BLOCKS];
     const float* conv2_w[STEMSEG_MAX_ENCODER_BLOCKS];   const float* conv2_b[STEMSEG_MAX_ENCODER_BLOCKS];

@@ -1363,6 +1363,9 @@ struct SplitTiles {
     // flat (ragged-width) form of the big 2-D tile: 128 co x 512 flat positions of the whole [T][H + 2][pitch] run (across the
     // frames); PMAX = largest row pitch served (the staged run is tile + 2 PMAX + 8 words)
     template <int PMAX> using Y2Flat = ConvCfg<1, 3, 3, CK2, 4, 2, 1, 8, 16, false, BFV, false, PMAX>;
+    // 1x4x4 taps on 16-channel chunks (16 k-groups of one tap x 16 channels): the 7x7 stride-2 stem as a stride-1 4x4 convolution over the
+    // space-to-depth image (encoder.hip); 64 co x (16 rows x 32 cols), 512 threads
+    using Y4Stem = ConvCfg<1, 4, 4, 16, 2, 2, 1, 8, 1, false, BFV>;
     // Measured in round 5 and not kept (profiles/r05b_conv_sweep_f16x3_T32.txt, tile_cfg 6 / 7 / 8 of that build): four-wave halves of the
     // eight-wave tiles, two per CU so that one's staging phases run under the other's MFMA stream -- block_4x 1 076 vs 1 006 us, layer-3 3x3
     // 214 vs 203, 1024 -> 256 110 vs 107, 256 -> 1024 + residual 170 vs 154; and 64-channel chunks for the 1x1 tiles (half the chunk
@@ -1474,7 +1477,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), (unsigned)p.nb, (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T_all * p.H * p.W * p.nb;
     constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
-    const int tag = C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : (tile_rows == 16 ? 9 : tile_rows));   // 9/8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
+    const int tag = C::TAPS == 16 ? -1 : C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : (tile_rows == 16 ? 9 : tile_rows));   // (4x4 taps = the stem: its caller's own tag)   // 9/8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
     if (ksplit > 1) {
@@ -1656,7 +1659,8 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     SS_CHECK_ARG(prec == STEMSEG_PRECISION_F32 || prec == STEMSEG_PRECISION_BF16X6 || prec == STEMSEG_PRECISION_F16X3,
                  "conv3d: precision %d (0 f32, 2 bf16x6, 3 f16x3)", prec);
     const bool k3 = (kt == 3 && kh == 3 && kw == 3), k1 = (kt == 1 && kh == 1 && kw == 1), k2 = (kt == 1 && kh == 3 && kw == 3);
-    SS_CHECK_ARG(k3 || k1 || k2, "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3 or 1x1x1)", kt, kh, kw);
+    const bool k4 = (kt == 1 && kh == 4 && kw == 4);        // (f16x3 only: the space-to-depth form of the 7x7 stride-2 stem)
+    SS_CHECK_ARG(k3 || k1 || k2 || (k4 && prec == STEMSEG_PRECISION_F16X3), "conv3d: kernel %dx%dx%d unsupported (3x3x3, 1x3x3, 1x1x1; 1x4x4 in f16x3 mode)", kt, kh, kw);
     const bool flat = epi && epi->dec_W > 0;
     if (flat) {
         SS_CHECK_ARG(k1 && in.T == 1 && in.H == 1 && epi->dec_H > 0 && (int64_t)out.T * out.H * out.W == in.W &&
@@ -1716,6 +1720,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
         pc = &pc_store;
     }
     const ConvKParams& d = pc ? pc->shape : p;
+    if (k4) return launch_cfg<SplitTiles<3>::Y4Stem>(p, s, nullptr, 0, 0, pc);
     if (prec == STEMSEG_PRECISION_BF16X6) return launch_split_family<2>(p, d, pc, s, scratch, scratch_floats, tile_cfg, k3, k2);
     if (prec == STEMSEG_PRECISION_F16X3) return launch_split_family<3>(p, d, pc, s, scratch, scratch_floats, tile_cfg, k3, k2);
     const bool auto_cfg = tile_cfg <= 0 || tile_cfg > 3;
@@ -1830,6 +1835,7 @@ extern "C" int stemseg_hip_pack_conv_weight(const float* w, float* packed, int32
 static void split_chunking(int taps, int precision, int& CK, int& TPG) {
     if (taps == 27) { CK = 4; TPG = 4; }
     else if (taps == 9) { CK = precision == STEMSEG_PRECISION_F16X3 ? 16 : 8; TPG = precision == STEMSEG_PRECISION_F16X3 ? 1 : 2; }
+    else if (taps == 16) { CK = 16; TPG = 1; }
     else { CK = 32; TPG = 1; }
 }
 static int64_t split_packed_bytes(int32_t Cout, int32_t Cin, int32_t taps, int planes, int precision) {
@@ -1840,7 +1846,7 @@ static int64_t split_packed_bytes(int32_t Cout, int32_t Cin, int32_t taps, int p
 }
 
 extern "C" int64_t stemseg_hip_packed_weight_bytes_prec(int32_t Cout, int32_t Cin, int32_t taps, int32_t precision) {
-    if (Cout <= 0 || Cin <= 0 || !(taps == 27 || taps == 9 || taps == 1)) return 0;
+    if (Cout <= 0 || Cin <= 0 || !(taps == 27 || taps == 9 || taps == 1 || (taps == 16 && precision == STEMSEG_PRECISION_F16X3))) return 0;
     if (precision == STEMSEG_PRECISION_BF16X6) return split_packed_bytes(Cout, Cin, taps, 3, precision);
     if (precision == STEMSEG_PRECISION_F16X3) return split_packed_bytes(Cout, Cin, taps, SS_F16_WPLANES, precision) + 8 * (int64_t)Cout;      // planes + per output channel: float 1 / scale, uint32 bits of max|w|
     return 0;
@@ -1850,7 +1856,7 @@ extern "C" int stemseg_hip_pack_conv_weight_prec(const float* w, void* packed, i
     using namespace stemseg;
     SS_CHECK_ARG(precision == STEMSEG_PRECISION_BF16X6 || precision == STEMSEG_PRECISION_F16X3, "pack_conv_weight_prec: precision must be 2 (bf16x6) or 3 (f16x3)");
     SS_CHECK_ARG(w && packed, "pack_conv_weight_prec: null pointer");
-    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1, "pack_conv_weight_prec: taps must be 27, 9 or 1");
+    SS_CHECK_ARG(taps == 27 || taps == 9 || taps == 1 || (taps == 16 && precision == STEMSEG_PRECISION_F16X3), "pack_conv_weight_prec: taps must be 27, 9 or 1 (16: f16x3, the stem)");
     int CK, TPG;
     split_chunking(taps, precision, CK, TPG);
     SS_CHECK_ARG(Cin % 4 == 0 && Cout % 32 == 0, "pack_conv_weight_prec: Cin %% 4, Cout %% 32 (got %d, %d)", Cin, Cout);

@@ -218,6 +218,30 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_mfma_kernel(const float* 
     }
 }
 
+// ---- the stem in f16x3 mode: space-to-depth, then a stride-1 4x4 convolution on the split-staged MFMA kernel (conv_igemm.hip, Y4Stem).
+// out[oy][ox] = sum w[c][ky][kx] in[c][2 oy + ky - 3][2 ox + kx - 3]; with ky + 1 = 2 a + p, kx + 1 = 2 b + q (a, b in 0..3, p, q in 0..1; the
+// index 0 is a zero tap) the input index is 2 (oy - 2 + a) + p: a 4x4 convolution over S[(p, q, c)][Y][X] = in[c][2 Y + p][2 X + q] with two
+// halo positions before and one after.  12 channels (one 16-channel chunk), K = 16 taps x 16 = 256 per output in three fp16 products:
+// 3/8 of the matrix time of the exact fp32-MFMA stem (84 steps of K = 2), which the default mode no longer needs: every other convolution of
+// the mode carries 22-bit operands as well.  One thread = one input pixel pair (q = 0, 1) of one (t, c, row).
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const float* __restrict__ frames, float* __restrict__ s2d, int T, int H, int W, int64_t ts, int pitch) {
+    const int W2 = W / 2, H2 = H / 2;
+    const int64_t total = (int64_t)T * 3 * H * W2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W2);
+        int64_t r = i / W2;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % 3), t = (int)(r / 3);
+        const float2 v = *reinterpret_cast<const float2*>(frames + (((int64_t)t * 3 + c) * H + y) * W + 2 * X);
+        const int p = y & 1, Y = y >> 1;
+        (void)H2;
+        float* o = s2d + ((int64_t)((p * 2 + 0) * 3 + c) * T + t) * ts + (int64_t)(Y + 2) * pitch + X + 2;
+        o[0] = v.x;
+        o[(int64_t)3 * T * ts] = v.y;                          // q = 1: three channels further
+    }
+}
+
 // max-pool 3x3 stride 2 pad 1 over every [c][t] plane (resnet.py:303)
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int H, int W) {
     const int Ho = H / 2, Wo = W / 2;
@@ -325,6 +349,7 @@ struct EncoderPlan {
     int h[4], w[4];            // 4x, 8x, 16x, 32x
     int64_t V[4];
     int64_t S0, X1, A, B, Cst[4], M1[4], M2, DS, XS, L[4], FO[4], SK, SKfloats, total;
+    int64_t S2D, s2d_ts, s2d_pitch;
     int plan_frames;           // 0: launches decide on their real shape
     int64_t plan_SKfloats;     // split-K scratch a planned launch may count on
 };
@@ -362,6 +387,10 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
         return o;
     };
     p.S0 = take(64 * 4 * p.V[0]);
+    // space-to-depth image of the frames for the f16x3 stem: [12][T][H/2 + 3][pitch], two halo rows / columns before, one after (zero, written once)
+    p.s2d_pitch = round_up(d->W / 2 + 3, 4);
+    p.s2d_ts = (int64_t)(d->H / 2 + 3) * p.s2d_pitch;
+    p.S2D = take(12 * (int64_t)d->T * p.s2d_ts + 64);
     p.X1 = take(64 * p.V[0]);
     p.A = take(256 * p.V[0]);
     p.B = take(256 * p.V[0]);
@@ -505,7 +534,18 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         const int Ho = p.H / 2, Wo = p.W / 2;
         const int blocks = (int)(ceil_div(Wo, ST_COLS) * ceil_div(Ho, ST_ROWS) * T);
         void* ev = profile_begin(47, 4.0 * ((double)3 * T * p.H * p.W + 64.0 * T * Ho * Wo), s);
-        SS_LAUNCH_STEM(blocks, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        if (wts->stem_w_s2d && prec == STEMSEG_PRECISION_F16X3 && p.W % 2 == 0) {
+            // space-to-depth + 4x4 convolution on the split-staged kernel (see stem_s2d_kernel)
+            hipLaunchKernelGGL(stem_s2d_kernel, dim3(grid1d((int64_t)T * 3 * p.H * (p.W / 2))), dim3(256), 0, s, frames, ws + p.S2D, T, p.H, p.W, p.s2d_ts, (int)p.s2d_pitch);
+            SS_LAUNCH_CHECK();
+            const StemsegVolume in = make_volume(ws + p.S2D, (int64_t)T * p.s2d_ts, p.s2d_ts, p.s2d_pitch, 12, T, Ho + 3, Wo + 3, 12 * (int64_t)T * p.s2d_ts + 64);
+            ConvEpilogue es = epi_for(T);
+            es.relu = 1;
+            rc = launch_conv3d(in, wts->stem_w_s2d, wts->stem_b, dense_volume(ws + p.S0, 64, T, Ho, Wo), 1, 4, 4, 0, s, nullptr, 0, &es);
+            if (rc) return rc;
+        } else {
+            SS_LAUNCH_STEM(blocks, s, frames, wts->stem_w, wts->stem_b, ws + p.S0, T, p.H, p.W);
+        }
         profile_end(ev, s);
         SS_LAUNCH_CHECK();
         ev = profile_begin(48, 4.0 * 64.0 * T * ((double)Ho * Wo + (double)p.V[0] / T), s);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Volume(C.Structure):
@@ -57,7 +57,7 @@ _BLK = C.c_void_p * MAX_ENCODER_BLOCKS
 
 
 class EncoderWeights(C.Structure):
-    _fields_ = [("stem_w", C.c_void_p), ("stem_b", C.c_void_p),
+    _fields_ = [("stem_w", C.c_void_p), ("stem_b", C.c_void_p), ("stem_w_s2d", C.c_void_p),
                 ("conv1_w", _BLK), ("conv1_b", _BLK), ("conv2_w", _BLK), ("conv2_b", _BLK), ("conv3_w", _BLK), ("conv3_b", _BLK),
                 ("down_w", _BLK), ("down_b", _BLK),
                 ("fpn_inner_w", C.c_void_p * 4), ("fpn_inner_b", C.c_void_p * 4), ("fpn_layer_w", C.c_void_p * 4), ("fpn_layer_b", C.c_void_p * 4)]

@@ -110,6 +110,7 @@ class ResNetFPN(nn.Module):
         # ClipPipeline.embed_many run; a job whose ranks must agree bit for bit keeps ONE value on all of them.  0: plan every pass on
         # its own frame count (fastest for a lone small pass; results then depend on the batch).
         self.plan_frames = 32
+        self.stem_s2d = True             # f16x3 mode: the stem as space-to-depth + 4x4 conv on the split-staged MFMA kernel (False: the exact fp32-MFMA stem; A/B)
 
     # ---- FrozenBN folding: w' = w * scale[:, None, None, None], b' = shift (exact: eps == 0) -------------------
     def _signature(self):
@@ -143,7 +144,7 @@ class ResNetFPN(nn.Module):
         return f
 
     def _pack(self):
-        sig = self._signature()
+        sig = (self._signature(), bool(self.stem_s2d))
         hit = self._packed.get(self.precision)
         if hit is not None and hit[0] == sig:      # (one packing per precision: an overflow re-run in bf16x6 keeps the f16x3 one)
             return hit[1]
@@ -165,6 +166,15 @@ class ResNetFPN(nn.Module):
         sw, sb = f["stem"]
         w.stem_w = dev(sw.reshape(64, 147).t()).data_ptr()
         w.stem_b = dev(sb).data_ptr()
+        if self.precision == "f16x3" and self.stem_s2d:
+            # the stem as a stride-1 4x4 convolution over the space-to-depth image (csrc/encoder.hip, stem_s2d_kernel):
+            # W2[co][(p*2+q)*3+c][a][b] = w[co][c][2a+p-1][2b+q-1], zero where an index is -1
+            w8 = torch.zeros(64, 3, 8, 8, dtype=torch.float32, device=sw.device)
+            w8[:, :, 1:, 1:] = sw.reshape(64, 3, 7, 7)
+            w2 = w8.reshape(64, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(64, 12, 1, 4, 4)      # [co][p][q][c][a][b]
+            pw2 = hip.pack_conv_weight_any(dev(w2), "f16x3")
+            keep.append(pw2)
+            w.stem_w_s2d = pw2.data_ptr()
         for i, blk in enumerate(self.blocks()):
             w.conv1_w[i], w.conv1_b[i] = packed("b%d.conv1" % i)
             w.conv2_w[i], w.conv2_b[i] = packed("b%d.conv2" % i)

@@ -1026,6 +1026,40 @@ def test_stem_conv_vs_fp64(hip, shape):
     assert err <= 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 96, 160), (3, 70, 134)])
+def test_stem_as_4x4_conv_over_space_to_depth_vs_fp64(hip, shape):
+    """The f16x3 mode's stem: space-to-depth (S[(p*2+q)*3+c][Y][X] = in[c][2Y+p][2X+q], two halo positions before, one after) followed by a
+    stride-1 1x4x4 convolution on the split-staged MFMA kernel with W2[co][(p,q,c)][a][b] = w[co][c][2a+p-1][2b+q-1] -- here the
+    transform in torch and the convolution through stemseg_hip_conv3d (kernel (1, 4, 4), 12 input channels = one 16-channel chunk),
+    against the fp64 7x7 stride-2 convolution and next to the exact fp32-MFMA stem: the same fp32-level error (22-bit operands)."""
+    import torch.nn.functional as F
+    T, H, W = shape
+    rs = np.random.RandomState(T * 1000 + H + 7)
+    frames = (rs.randint(0, 256, (T, 3, H, W)).astype(np.float32) - np.array([102.9801, 115.9465, 122.7717], np.float32)[None, :, None, None])
+    w = (rs.standard_normal((64, 3, 7, 7)) * (2.0 / 147) ** 0.5).astype(np.float32)
+    b = rs.standard_normal(64).astype(np.float32)
+    ref = F.relu(F.conv2d(torch.from_numpy(frames).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=3)).permute(1, 0, 2, 3).numpy()
+    H2, W2 = H // 2, W // 2
+    x = torch.from_numpy(frames)
+    s2d = x.reshape(T, 3, H2, 2, W2, 2).permute(3, 5, 1, 0, 2, 4).reshape(12, T, H2, W2)          # [(p, q, c)][T][Y][X]
+    pitch = (W2 + 3 + 3) // 4 * 4
+    buf = torch.zeros(12, T, H2 + 3, pitch)
+    buf[:, :, 2:2 + H2, 2:2 + W2] = s2d
+    buf = buf.cuda()
+    w8 = torch.zeros(64, 3, 8, 8)
+    w8[:, :, 1:, 1:] = torch.from_numpy(w)
+    w2 = w8.reshape(64, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4).reshape(64, 12, 1, 4, 4).contiguous().cuda()
+    vin = hip.Volume(buf.data_ptr(), T * (H2 + 3) * pitch, (H2 + 3) * pitch, pitch, 12, T, H2 + 3, W2 + 3, buf.numel())
+    out = torch.empty(64, T, H2, W2, device="cuda")
+    hip.conv3d(vin, hip.pack_conv_weight_any(w2, "f16x3"), dev(b), hip.dense_volume(out), (1, 4, 4), 0, None, dict(relu=1, precision="f16x3"))
+    torch.cuda.synchronize()
+    exact = hip.stem_conv(dev(frames), dev(w), dev(b)).cpu().numpy()
+    e_new = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    e_old = np.abs(exact - ref).max() / np.abs(ref).max()
+    print("[stem s2d] %s max rel err vs fp64: f16x3 4x4 form %.3e, exact fp32-MFMA stem %.3e" % (shape, e_new, e_old))
+    assert e_new <= 2e-6
+
+
 def test_chainer_exact_cost_ties_on_gpu_vs_golden(hip, golden):
     """tests/golden/chainer_ties.npz through the HIP chainer: exact Hungarian cost ties resolved in the reference's id enumeration
     order (online_chainer.reference_id_order) -- device-side id sets now also report whether the outlier id occurs."""
