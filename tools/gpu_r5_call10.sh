@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the probe libraries: STEMSEG_BUILD_DEFINES="-DSS_EXPERIMENTS -DSS_PROBE=<n>" STEMSEG_BUILD_TAG=p<n> python stem-seg_amd/build.py, n = 1..5)
 # timing probes of the split-staged chunk loop (SS_PROBE builds: results wrong by construction, times only)
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 L=$PWD/stem-seg_amd/stemseg_amd/lib

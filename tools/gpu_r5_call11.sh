@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a removed experiment: libstemseg_hip_pp.so was the build with the ping-pong tiles behind tile_cfg 6; profiles/r05i_pingpong_tiles.txt)
 # ping-pong tiles (tile_cfg 6) against the launcher's choice (0) and the plain big tile (1), same library
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export STEMSEG_HIP_LIB=$PWD/stem-seg_amd/stemseg_amd/lib/libstemseg_hip_pp.so

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record: libstemseg_hip_ck16.so was the first build with the 16-channel chunks, against the then-product library)
 # 16-channel chunks for the f16x3 1x3x3 tiles (no padded tap slot) against the product build: conv parity tests on the new library, then times
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 N=$PWD/stem-seg_amd/stemseg_amd/lib/libstemseg_hip_ck16.so

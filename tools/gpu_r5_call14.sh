@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a removed experiment: libstemseg_hip_prev.so was the previous commit's build)
 # FPN top-down add fused into the lateral conv's epilogue (HEAD) against the previous build: encoder parity, kernel times, the step
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 P=$PWD/stem-seg_amd/stemseg_amd/lib/libstemseg_hip_prev.so
