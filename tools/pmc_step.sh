@@ -23,7 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # the run executes: 1 warm-up + 2 pre-runs... count clips from the stem kernel launches instead
 db = glob.glob("gpurun_out/pmc_step_FETCH_SIZE/**/*.db", recursive=True)[0]
 con = sqlite3.connect(db)
-n_enc = con.execute("select count(*) from counters_collection where kernel_name like '%stem_conv7x7%' and counter_name='FETCH_SIZE'").fetchone()[0]
+n_enc = con.execute("select count(*) from counters_collection where (kernel_name like '%stem_conv7x7%' or kernel_name like '%stem_s2d%') and counter_name='FETCH_SIZE'").fetchone()[0]
 n_dec = con.execute("select count(*) from counters_collection where kernel_name like '%heads_kernel%' and counter_name='FETCH_SIZE'").fetchone()[0]
 clips = n_enc * 4.0                                   # (bench default: 4 clips per encoder pass; the decoders take all of them per launch)
 print("encoder passes %d, clips %.1f" % (n_enc, clips))

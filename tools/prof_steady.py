@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Steady-state per-step kernel breakdown from a rocprofv3 rocpd trace of bench.py: uses the last `n` steps, a step
-being delimited by the encoder's stem kernel (one launch per clip).
+being delimited by the encoder's stem kernel (one launch per encoder pass).
 Usage: tools/prof_steady.py results.db [n_steps]"""
 import sqlite3
 import sys
@@ -8,7 +8,7 @@ import sys
 c = sqlite3.connect(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = c.execute("select name, start, end, grid_x, grid_y, workgroup_x, lds_size, vgpr_count from kernels order by start").fetchall()
-stem = [r for r in rows if "stem_conv7x7" in r[0]]
+stem = [r for r in rows if "stem_conv7x7" in r[0] or "stem_s2d" in r[0]]          # (one of the two per encoder pass: the exact stem, or the f16x3 mode's space-to-depth pass)
 assert len(stem) >= n + 1, "not enough steps in the trace"
 t0, t1 = stem[-n - 1][1], stem[-1][1]
 agg = {}
