@@ -299,6 +299,18 @@ class InferenceModel(nn.Module):
             logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return logits.contiguous()
 
+    @torch.no_grad()
+    def semseg_logits_batch(self, T, H, W, dev, n_clips, resize=True):
+        """``semseg_logits_clip`` for the ``n_clips`` clips of the encoder pass just run (slots 0 .. n_clips - 1 of the current block): the
+        third decoder takes them in one launch per stage (the decoders' clip batch; each clip's logits are bit-identical to its own
+        call).  -> list of [C, T, h4*r, w4*r]."""
+        blk = self._pad_block(T, H, W, dev, n_clips)
+        sh = self._model.semseg_head
+        sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
+        logits = sh.forward_single(([b for b, _ in blk["pads"][0]], (T, H // 4, W // 4)), 2, clip_batch=(n_clips, blk["strides"]))
+        r = int(self.resize_scale)
+        return [(hip.upsample_trilinear(logits[c].contiguous(), 1, r, r) if (r != 1 and resize) else logits[c]).contiguous() for c in range(n_clips)]
+
     def semseg_fg_logits_clip(self, T, H, W, dev, slot=0):
         """The channels of the clip's class logits that decide foreground (inference_model.py:207-225), at the head's resolution:
         [1, T, h4, w4] (the last channel of a multi-class head) or [2, T, h4, w4] (a binary head) -- what the clip-parallel

@@ -52,15 +52,16 @@ class ClipPipeline(object):
         g.update(labels=labels, meta=meta_dev)
         return g
 
-    def _finish_clip(self, emb, bw, seed, T, H, W, slot=0, defer_clustering=False):
+    def _finish_clip(self, emb, bw, seed, T, H, W, slot=0, defer_clustering=False, logits=None):
         """Everything after the embedding decoder of one independent clip.  Presets with a semseg head (YouTube-VIS, KITTI-MOTS):
         third decoder -> class logits (x resize_scale, inference_model.py:121-124) -> foreground = its fg probability > 0.5
         (inference_model.py:197-231, inference/main.py:142-144); under --resize_embeddings the head outputs are up-sampled x4 and
         the clip is clustered at full resolution (online_chainer.py:127-140)."""
-        fg, logits = None, None
+        fg = None
         emb0, bw0, seed0 = emb, bw, seed                     # the decoders' own outputs (before any resize)
         if self.model.has_semseg_head:
-            logits = self.model.semseg_logits_clip(T, H, W, emb.device, slot=slot)
+            if logits is None:                               # (step_batch hands over the clip's share of a batched third-decoder call)
+                logits = self.model.semseg_logits_clip(T, H, W, emb.device, slot=slot)
             fg, _ = hip.semseg_fg_clip(logits, 0.5)
         r = int(self.model.resize_scale)
         if r != 1:
@@ -108,8 +109,12 @@ class ClipPipeline(object):
         gather + clustering per clip.  Returns a list of ``step``-style dicts."""
         NT, _, H, W = frames.shape
         # (with a semseg head its decoder reads clip c's zero-haloed FPN buffers, slot c, which stay valid after the pass)
-        outs = [self._finish_clip(emb, bw, seed, NT // n_clips, H, W, slot=c, defer_clustering=self.batch_clustering)
-                for c, (emb, bw, seed) in enumerate(self.model.embed_frames_batch(frames.contiguous(), n_clips))]
+        heads = self.model.embed_frames_batch(frames.contiguous(), n_clips)
+        sem = [None] * n_clips
+        if self.model.has_semseg_head and self.model.batch_decoders and n_clips > 1:
+            sem = self.model.semseg_logits_batch(NT // n_clips, H, W, frames.device, n_clips)      # the third decoder: all clips per launch
+        outs = [self._finish_clip(emb, bw, seed, NT // n_clips, H, W, slot=c, defer_clustering=self.batch_clustering, logits=sem[c])
+                for c, (emb, bw, seed) in enumerate(heads)]
         if self.batch_clustering:
             # the clips are independent point sets: ONE sequence of clustering launches serves all of them (grid.y = clip)
             res = self.clusterer.enqueue_batch([o.pop("points") for o in outs], 1)
