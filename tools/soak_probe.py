@@ -6,6 +6,10 @@ round that differs, which buffers differ, where (segment, channel / voxel range)
 execution order is where the difference entered.
 
     python tools/soak_probe.py --workload ytvis --lanes 3 --reps 200 [--precision f16x3] [--small]
+
+Memory: the probe keeps TWO reference copies of everything a lane owns (one per input batch).  At the DAVIS / YouTube-VIS sizes that is a few
+tens of GB; at the KITTI size (608 x 1952) with three lanes it asks for more than the 288 GB of the card (torch raises OutOfMemoryError
+before anything runs) -- use --small or two lanes there; the -m gpu soaks (tests/test_gpu_soak.py) compare signatures, not buffers.
 """
 import argparse
 import ctypes as C
