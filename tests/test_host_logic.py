@@ -66,6 +66,24 @@ def test_cabi_struct_sizes_and_argument_errors():
         d.pool[i], d.t_scale[i] = p, s
     nbytes = l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d))
     assert nbytes > 4 * 256 * 10 * 26 * 36
+    # the clip batch (ABI 8): n_clips clip plans a fixed stride apart + ONE split-K area for all of them behind -- linear in n_clips, and the
+    # strides the caller announces are checked
+    d.input_layout = 2
+    n1 = l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d))
+    d.n_clips = 4
+    for i, (h, w) in enumerate(((3, 4), (6, 8), (12, 16), (24, 32))):
+        d.feat_clip_stride[i] = (hip.padded_geometry(256, 8, h, w)["total"] + 63) // 64 * 64
+    n4 = l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d))
+    d.n_clips = 2
+    n2 = l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d))
+    assert 0 < n1 < n2 < n4 and n4 - n2 == 2 * (n2 - n1) and (n2 - n1) % 1024 == 0
+    d.feat_clip_stride[3] = 16                                        # clips would overlap
+    assert l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d)) == 0 and b"feat_clip_stride" in l.stemseg_hip_last_error()
+    d.feat_clip_stride[3] = (hip.padded_geometry(256, 8, 24, 32)["total"] + 63) // 64 * 64
+    d.out_clip_stride = 8                                             # smaller than one clip's output
+    assert l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d)) == 0 and b"out_clip_stride" in l.stemseg_hip_last_error()
+    d.out_clip_stride, d.n_clips, d.input_layout = 0, 0, 0
+    assert l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d)) == nbytes
     d.t_scale[0] = 2                                                  # inconsistent topology
     assert l.stemseg_hip_decoder_workspace_bytes(ctypes.byref(d)) == 0
     g = hip.padded_geometry(256, 8, 120, 216)
