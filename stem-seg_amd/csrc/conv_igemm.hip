@@ -61,8 +61,9 @@
                                   // the three-lane soak stays at 0 differing lane-rounds and the step is 1.0 % faster (A/B on one box, interleaved).
 #endif
 #ifndef SS_X6_SPREAD_DIV
-#define SS_X6_SPREAD_DIV 2          // the spread loads go out over the first 1 / DIV of a phase's (k-group, mi) steps (A/B, step throughput vs DIV 2:
-                                  // 1: +0.4 %, 3: -0.5 %, 4: -1.0 %)
+#define SS_X6_SPREAD_DIV 1          // the spread loads go out over the first 1 / DIV of a phase's (k-group, mi) steps.  A/B on the step, interleaved on one box:
+                                  // round 4 (8-channel 1x3x3 chunks) 1 vs 2: +0.4 %, 3: -0.5 %, 4: -1.0 %, and 2 shipped; round 5 (16-channel chunks, nine
+                                  // k-groups per phase pair) 1 vs 2: +1.2 / +0.7 % in two interleaved pairs, 3: -0.6 / -0.3 %: over the whole phase now
 #endif
 
 #ifndef SS_PROBE
