@@ -85,9 +85,12 @@ static inline StemsegVolume padded_interior_view(float* base, int C, int T, int 
 // *_init_workspace writes them, stemseg_hip_{encoder,decoder}_check_workspace counts the words that no longer hold it.
 constexpr int WS_GUARD_FLOATS = 64;
 constexpr uint32_t WS_CANARY = 0x7fc5ca7au;
+constexpr int WS_MAX_GUARDS = 64;
 struct GuardList {
     int n = 0;
-    int64_t off[64];              // float offset of every guard block inside the workspace
+    int64_t off[WS_MAX_GUARDS];   // float offset of every guard block inside the workspace
+    bool full = false;            // a plan asked for more slices than the list holds (the plan functions fail on it)
+    void push(int64_t o) { if (n < WS_MAX_GUARDS) off[n++] = o; else full = true; }
 };
 int launch_canary_fill(float* ws, const GuardList& g, hipStream_t s);
 // synchronises `s`; *n_bad_host = clobbered guard words, *first_bad_host = float offset of the first one (-1: none)

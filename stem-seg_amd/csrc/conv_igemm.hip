@@ -48,6 +48,18 @@
                                   // multiply; round 4 traced every one of them to the VALU stem kernel -- with that gone both
                                   // forms are bit-stable in the three-lane soak, and numerically identical to each other.
 #endif
+// A/B and probe switches of the split-staged chunk loop exist in EXPERIMENT builds only (-DSS_EXPERIMENTS, STEMSEG_BUILD_DEFINES): a product
+// build pins them to the shipped values below and refuses any of them on its command line -- it is never one -D away from a kernel that is
+// wrong by construction (SS_PROBE) or from an un-soaked schedule.
+#ifndef SS_EXPERIMENTS
+#if defined(SS_PROBE) || defined(SS_X6_WMODE_SMALLG) || defined(SS_X6_SPREAD) || defined(SS_X6_SPREAD_DIV)
+#error "SS_PROBE / SS_X6_WMODE_SMALLG / SS_X6_SPREAD / SS_X6_SPREAD_DIV are experiment switches: add -DSS_EXPERIMENTS"
+#endif
+#define SS_X6_WMODE_SMALLG -1
+#define SS_X6_SPREAD 1
+#define SS_X6_SPREAD_DIV 1
+#define SS_PROBE 0
+#else
 #ifndef SS_X6_WMODE_SMALLG
 #define SS_X6_WMODE_SMALLG -1      // weight staging of the split-staged tiles with <= 2 k-groups per chunk (1x1 taps), see ConvCfg::WMODE.  -1: f16x3 takes
                                   // mode 1 (one phase, the whole next chunk in registers under the chunk's MFMA stream), bf16x6 mode 2 where its second
@@ -71,6 +83,8 @@
                                   // 1 no global loads of the next chunk, 2 loads waited for but neither split nor written to LDS, 3 no MFMAs
                                   // (fragments still read), 4 no LDS fragment reads (MFMAs on stale registers), 5 no barriers
 #endif
+
+#endif  // SS_EXPERIMENTS
 
 #if SS_PROBE == 5
 #define SS_CHUNK_SYNC() do { } while (0)

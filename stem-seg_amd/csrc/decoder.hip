@@ -147,7 +147,7 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
     auto take = [&](int64_t floats) {            // a slice + its guard block
         int64_t o = off;
         off += round_up(floats, 64);
-        p.guards.off[p.guards.n++] = off;
+        p.guards.push(off);
         off += WS_GUARD_FLOATS;
         return o;
     };
@@ -186,10 +186,11 @@ static int make_plan(const StemsegDecoderDesc* d, DecoderPlan& p) {
         p.Sfloats[i] *= p.nb;
         p.S[i] = off;
         off += round_up(p.Sfloats[i], 64);
-        p.tail_guards.off[p.tail_guards.n++] = off;
+        p.tail_guards.push(off);
         off += WS_GUARD_FLOATS;
     }
     p.total = off;
+    SS_CHECK_ARG(!p.guards.full && !p.tail_guards.full, "decoder: the plan has more than %d workspace slices (GuardList)", WS_MAX_GUARDS);
     return STEMSEG_OK;
 }
 

@@ -382,7 +382,7 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     auto take = [&](int64_t floats) {            // a slice + its guard block
         int64_t o = off;
         off += round_up(floats, 64);
-        p.guards.off[p.guards.n++] = off;
+        p.guards.push(off);
         off += WS_GUARD_FLOATS;
         return o;
     };
@@ -413,6 +413,7 @@ static int make_encoder_plan(const StemsegEncoderDesc* d, EncoderPlan& p) {
     p.SKfloats = ENC_PLAN_SK_FLOATS * (d->plan_frames > 0 ? std::max<int64_t>(1, ceil_div(d->T, d->plan_frames)) : 1);
     p.SK = take(p.SKfloats);
     p.total = off;
+    SS_CHECK_ARG(!p.guards.full, "encoder: the plan has more than %d workspace slices (GuardList)", WS_MAX_GUARDS);
     return STEMSEG_OK;
 }
 

@@ -63,6 +63,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.conv_8 = nn.Conv3d(c16 + c8, c8, 1, bias=False)
         self.conv_4 = nn.Conv3d(c8 + c4, c4, 1, bias=False)
         self._cache = {}          # precision -> packed weights (valid while the parameter versions match)
+        self._retired = []        # superseded packings, kept alive for captured graphs
         self._workspaces, self._ws_desc = {}, {}     # (T, H4, W4, layout, device, lane) -> workspace tensor / the descriptor it was sized for
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
         self.concurrency = 1      # 0: single stream; k>=1: branch streams of the library's set k-1 (see stemseg_hip.h)
@@ -80,8 +81,10 @@ class SqueezeExpandTrunk(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _packed(self):
-        # one packing per precision: an overflow re-run in bf16x6 (ClipPipeline.step_checked, GraphedStep.run_checked) must not
-        # throw the f16x3 packing away and pack it again on the way back
+        # one packing per precision: an overflow re-run in bf16x6 (ClipPipeline.step_checked, GraphedStep.collect) must not throw the
+        # f16x3 packing away and pack it again on the way back.  A packing superseded by a parameter update is RETIRED, not freed: a
+        # captured hipGraph holds raw pointers into it (a replay then computes with the old weights -- re-capture after an update -- but
+        # never reads freed memory)
         sig = self._param_signature()
         c = self._cache.setdefault(self.precision, {})
         if c.get("sig") != sig:
@@ -99,6 +102,8 @@ class SqueezeExpandTrunk(nn.Module):
                     gn_b.append(torch.zeros(conv.out_channels, dtype=torch.float32, device=dev))
             fuse = [hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8, self.conv_4)]
             hw, hb, act, axes = self._head_spec()
+            if c:
+                self._retired.append(dict(c))
             c.clear()
             c.update(sig=sig, conv_w=conv_w, conv_b=conv_b, gn_w=gn_w, gn_b=gn_b, fuse=fuse,
                      head_w=hw.detach().float().contiguous().to(dev), head_b=hb.detach().float().contiguous().to(dev),

@@ -77,10 +77,22 @@ class InferenceModel(nn.Module):
         self.EmbeddingMapEntry = EmbeddingMapEntry
         self._pads = {}
         self._pad_blocks = []
+        self._last_written = {}          # (T, H, W, device, lane) -> the block the last encoder pass of that lane filled
         self.batch_decoders = True       # the clips of an encoder pass go through each decoder stage in one launch (False: clip by clip; A/B, same bits)
         self.overlap_decoders = True     # seediness decoder on a side stream + branch streams inside each decoder
         self.lane = 0
         self.eval()
+
+    @property
+    def plan_frames(self):
+        """Frames every encoder launch is PLANNED for (ResNetFPN.plan_frames, default 32): one value per job and per set of ranks that
+        must agree bit for bit.  A deployment that only ever passes lone 8-frame clips (the latency path) may set 8 -- its small-map
+        layers then split K as a lone clip wants (about 0.5 % faster there) -- at the price of bits that differ from a 32-frame plan."""
+        return self._model.backbone.plan_frames
+
+    @plan_frames.setter
+    def plan_frames(self, n):
+        self._model.backbone.plan_frames = int(n)
 
     semseg_outputs_on_cpu = False       # True under stemseg_amd.overlay: the reference's writers index these on the host
     overflow_fallback = "bf16x6"        # mode a sequence is re-run in when a head output comes back non-finite (None: raise instead)
@@ -146,12 +158,17 @@ class InferenceModel(nn.Module):
             getattr(self._model, n_).precision = v
 
     # ---- one clip ----------------------------------------------------------------------------------
-    def _pad_block(self, T, H, W, dev, n):
+    def _pad_block(self, T, H, W, dev, n, use_last=False):
         """>= n sets ("slots") of four zero-haloed buffers [256][T+2][h+2][pitch] (halos stay zero), one set per clip of an encoder pass.
         The slots of a block are ONE allocation per level, a fixed stride apart: what a clip-batched decoder call needs
         (StemsegDecoderDesc.feat_clip_stride).  A request for more slots than the current block holds makes a larger block current;
-        earlier blocks stay alive (captured graphs replay on them)."""
+        earlier blocks stay alive (captured graphs replay on them).  ``use_last``: a READER of the lane's last encoder pass (the semseg
+        helpers) -- it gets the block that pass wrote (``_mark_written``), which is not the current one when a graph captured on a smaller
+        block has just been replayed (reading the current block would silently see stale or zero FPN maps)."""
         key = (T, H, W, dev.index, self.lane)
+        blk = self._last_written.get(key) if use_last else None      # (the block the lane's last encoder pass wrote: see below)
+        if blk is not None and blk["n"] >= n:
+            return blk
         blk = self._pads.get(key)
         if blk is None or blk["n"] < n:
             Cn = self._model.backbone.out_channels
@@ -161,9 +178,12 @@ class InferenceModel(nn.Module):
             self._pads[key] = blk
         return blk
 
-    def _padded_feature_buffers(self, T, H, W, dev, slot=0):
+    def _padded_feature_buffers(self, T, H, W, dev, slot=0, use_last=False):
         """The four buffers of ``slot`` in the current block (see _pad_block)."""
-        return self._pad_block(T, H, W, dev, slot + 1)["pads"][slot]
+        return self._pad_block(T, H, W, dev, slot + 1, use_last)["pads"][slot]
+
+    def _mark_written(self, T, H, W, dev, blk):
+        self._last_written[(T, H, W, dev.index, self.lane)] = blk
 
     @torch.no_grad()
     def embed_clip(self, feature_maps, T, H, W):
@@ -172,7 +192,9 @@ class InferenceModel(nn.Module):
         hip.require_gpu()
         m = self._model
         dev = feature_maps[0][4].device
-        pads = self._padded_feature_buffers(T, H, W, dev)
+        blk = self._pad_block(T, H, W, dev, 1)
+        pads = blk["pads"][0]
+        self._mark_written(T, H, W, dev, blk)
         Cn = m.backbone.out_channels
         for (buf, g), s in zip(pads, (32, 16, 8, 4)):
             stack = torch.stack([fm[s] for fm in feature_maps], 1)                      # [C,T,h,w]  (layout 0)
@@ -187,7 +209,9 @@ class InferenceModel(nn.Module):
         m = self._model
         T, _, H, W = frames.shape
         dev = frames.device
-        pads = self._padded_feature_buffers(T, H, W, dev)
+        blk = self._pad_block(T, H, W, dev, 1)
+        pads = blk["pads"][0]
+        self._mark_written(T, H, W, dev, blk)
         Cn = m.backbone.out_channels
         vols = {s: hip.padded_interior_view(buf, g, Cn, T, H // s, W // s) for (buf, g), s in zip(pads, (32, 16, 8, 4))}
         m.backbone.run_backbone_into(frames, [vols[s] for s in (4, 8, 16, 32)])
@@ -204,6 +228,7 @@ class InferenceModel(nn.Module):
         assert NT % n_clips == 0
         T, dev, Cn = NT // n_clips, frames.device, m.backbone.out_channels
         blk = self._pad_block(T, H, W, dev, n_clips)
+        self._mark_written(T, H, W, dev, blk)
         pads = blk["pads"]
         vols = []
         for c in range(n_clips):
@@ -227,6 +252,7 @@ class InferenceModel(nn.Module):
         assert NT == (n_clips - 1) * clip_stride + clip_frames
         T, dev, Cn = clip_frames, frames.device, m.backbone.out_channels
         blk = self._pad_block(T, H, W, dev, n_clips)
+        self._mark_written(T, H, W, dev, blk)
         pads = blk["pads"]
         vols = []
         for c in range(n_clips):
@@ -294,7 +320,7 @@ class InferenceModel(nn.Module):
         ``resize=False``: at the head's own resolution."""
         sh = self._model.semseg_head
         sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
-        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot)], (T, H // 4, W // 4)), 2)
+        logits = sh.forward_single(([b for b, _ in self._padded_feature_buffers(T, H, W, dev, slot=slot, use_last=True)], (T, H // 4, W // 4)), 2)
         if self.resize_scale != 1.0 and resize:
             logits = hip.upsample_trilinear(logits.contiguous(), 1, int(self.resize_scale), int(self.resize_scale))
         return logits.contiguous()
@@ -304,7 +330,7 @@ class InferenceModel(nn.Module):
         """``semseg_logits_clip`` for the ``n_clips`` clips of the encoder pass just run (slots 0 .. n_clips - 1 of the current block): the
         third decoder takes them in one launch per stage (the decoders' clip batch; each clip's logits are bit-identical to its own
         call).  -> list of [C, T, h4*r, w4*r]."""
-        blk = self._pad_block(T, H, W, dev, n_clips)
+        blk = self._pad_block(T, H, W, dev, n_clips, use_last=True)
         sh = self._model.semseg_head
         sh.concurrency, sh.detached = (1 if self.overlap_decoders else 0), False
         logits = sh.forward_single(([b for b, _ in blk["pads"][0]], (T, H // 4, W // 4)), 2, clip_batch=(n_clips, blk["strides"]))

@@ -247,6 +247,9 @@ class GraphedStep(object):
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = fn(self.static_in)
             torch.cuda.synchronize(dev)
+            # the zero-haloed FPN blocks this graph's encoder pass writes (this lane's entries): a replay re-marks them as the lane's last
+            # written ones, so an eager semseg call that follows reads what the replay produced (InferenceModel._pad_block, use_last)
+            self._written = {k: v for k, v in pipe.model._last_written.items() if k[-1] == lane}
         finally:
             pipe.model.overlap_decoders = prev
             pipe.model.set_lane(0)
@@ -255,6 +258,7 @@ class GraphedStep(object):
         """Device-to-device copy of the clip into the graph's input, one graph launch; returns the static output dict."""
         self.static_in.copy_(frames, non_blocking=True)
         self.graph.replay()
+        self.pipe.model._last_written.update(self._written)
         return self.out
 
     def run_async(self, frames):
@@ -273,8 +277,9 @@ class GraphedStep(object):
         ``ClipPipeline.step_checked``: -> (list of step dicts, list of StemsegClusterMeta).  When a head output of one of the clips is
         non-finite (an activation left the split convolution mode's range) the lane's batch -- its frames are still in the graph's
         static input -- is run ONCE more, eagerly, in ``fallback_precision`` on this lane's own stream and workspaces, and those
-        results are returned (fresh tensors, not the graph's static ones); the model's mode is restored.  A production lane therefore
-        never hands out NaN maps and never just raises (``fallback_precision=None`` restores raising)."""
+        results are returned (fresh tensors, not the graph's static ones, allocated on ``self.stream``: consume them under that stream or
+        after ``wait()``); the model's mode and lane are restored.  A production lane therefore never hands out NaN maps and never just
+        raises (``fallback_precision=None`` restores raising)."""
         outs = self.out if isinstance(self.out, (list, tuple)) else [self.out]
         with torch.cuda.stream(self.stream):
             try:
@@ -284,7 +289,7 @@ class GraphedStep(object):
                 before = model.precisions()
                 if fallback_precision is None or all(v == fallback_precision for v in before.values()):
                     raise
-                prev = model.overlap_decoders
+                prev, prev_lane = model.overlap_decoders, model.lane
                 model.set_precision(fallback_precision)
                 model.set_lane(self.lane)
                 model.overlap_decoders = self._overlap
@@ -295,7 +300,7 @@ class GraphedStep(object):
                 finally:
                     model.restore_precisions(before)
                     model.overlap_decoders = prev
-                    model.set_lane(0)
+                    model.set_lane(prev_lane)         # (the caller's lane, not lane 0: its workspaces may be in use by in-flight eager work)
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU
