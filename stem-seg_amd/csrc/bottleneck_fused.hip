@@ -1,0 +1,365 @@
+// Back-to-back GEMM for the bottleneck tail (f16x3 mode): conv3 of block b (1x1, MID -> 4 MID, + bias + identity + ReLU) and conv1 of
+// block b + 1 (1x1, 4 MID -> MID, + bias + ReLU) in ONE launch.
+//
+// Reference: /root/reference/stemseg/modeling/backbone/resnet.py:262-282 (Bottleneck.forward: conv1 -> conv2 -> conv3 -> += identity ->
+// relu), two consecutive blocks of a stage (:105-113).  As two launches of conv_igemm.hip the 4 MID-channel block output is written by
+// conv3 and read again by the next conv1 (and later by the next conv3 as its identity): at layer 3 (MID = 256, 32 frames) 212 MB of the
+// 742 MB the pair moves.  Here a workgroup owns 256 positions and walks ALL 4 MID output channels of conv3 in co-tiles of CT: the co-tile's
+// accumulators get scale / bias / identity / ReLU in registers, are written to HBM once (the next block's identity needs them) and -- split
+// into the fp16 (hi, lo * 2^11) pairs -- ARE the B operand of conv1's next K-chunk: the MFMA C/D layout gives a lane 16 of a 32-channel
+// tile's rows for its own position, a v_permlane32_swap between the lane halves turns them into the two 16-deep k-groups in the standalone
+// kernel's k order.  conv1's MID x 256 accumulators stay in registers through the whole launch.
+//
+// Same operands, same split arithmetic (split_pair_f16), same k order per accumulator as conv_igemm_kernel's 1x1 tiles (32-channel chunks, two
+// k-groups of one tap x 16 channels, products lo_w*hi_x, (hi_w 2^-11)*(lo_x 2^11), hi_w*hi_x) => BIT-IDENTICAL to the two launches whenever
+// those run without split-K (tests/test_gpu_fused_tail.py).
+//
+// Data movement: everything staged by LDS-DMA (global_load_lds_dwordx4, no staging registers, no VALU):
+//   * conv3's input -- conv2's output -- arrives ALREADY SPLIT: conv2's epilogue writes the fp16 pair planes ("P16", conv_igemm.hip) instead
+//     of fp32, same 4 bytes per value, in octets: word [plane][channel / 8][position][(channel % 8) / 2] -- a lane's eight k-values of a
+//     k-group are ONE ds_read_b128;
+//   * weights in the packed f16x3 layout of stemseg_hip_pack_conv_weight_prec, unchanged: conv3's [chunk][grp][plane][half][4 MID][16 B]
+//     has the co-tile's CT channels as one 16 CT-byte run per row, conv1's chunks [..][MID][16 B] for a co-tile are one contiguous block.
+// Stages: per co-tile MID / 32 conv3 sub-stages (x chunk + w3 chunk double-buffered, a share of the co-tile's w1 block streamed in beside
+// them), then ONE epilogue + conv1 stage.  One barrier per stage, vmcnt(0) in front of it.
+#include "common.h"
+
+namespace stemseg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct FusedTailParams {
+    const unsigned int* x16;     // conv2's output as fp16 pair planes: [2][MID / 8][V][4] words
+    const char* w3;              // packed f16x3 weights of conv3 (Cout = 4 MID, Cin = MID, 1 tap) + float inv[4 MID] behind the slabs
+    const float* b3;
+    const float* res;            // identity: dense [4 MID][V]
+    float* y;                    // block output: dense [4 MID][V]
+    const char* w1;              // packed f16x3 weights of the next block's conv1 (Cout = MID, Cin = 4 MID) + float inv[MID]
+    const float* b1;
+    float* z;                    // conv1 output (+ bias, ReLU) at (t, y, x) of a [MID][T][h + 2][pitch] zero-haloed interior view
+    int64_t z_cs, z_ts, z_ys;
+    int dec_H, dec_W;
+    int V;                       // positions: T * h * w
+};
+
+// the split of conv_igemm.hip (split_pair_f16), bit for bit: hi = fp16(x / 4), lo = fp16((x / 4 - hi) * 2^11) of a channel pair
+__device__ __forceinline__ void ft_split_pair(const float x0, const float x1, unsigned int& hw, unsigned int& lw) {
+    const float qs = 0.25f, ks = 2048.0f;
+    unsigned int h, l;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "s"(qs));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "s"(qs));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x0), "s"(qs), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x1), "s"(qs), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(r0), "s"(ks));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(r1), "s"(ks));
+    hw = h;
+    lw = l;
+}
+
+template <int MID_, int CT_>
+struct FusedTailCfg {
+    static constexpr int MID = MID_, CT = CT_, COUT = 4 * MID_;
+    static constexpr int P = 256, NW = 8, NTHREADS = 512;
+    static constexpr int NC3 = MID / 32;                   // conv3 K-chunks (32 channels)
+    static constexpr int NCT = COUT / CT;                  // co-tiles
+    static constexpr int MI3 = CT / 32, MI1 = MID / 32;    // 32-row accumulator tiles per wave: conv3 co-tile, conv1
+    static constexpr int X_BYTES = 2 * 4 * P * 16;          // x chunk: [plane][octet][position][4 words]
+    static constexpr int W3_BYTES = 8 * CT * 16;            // w3 chunk of the co-tile: [grp][plane][half][CT][16 B]
+    static constexpr int W1_CHUNK = 8 * MID * 16;           // one 32-channel chunk of w1: [grp][plane][half][MID][16 B]
+    static constexpr int W1_BYTES = MI3 * W1_CHUNK;         // the co-tile's chunks (contiguous in the packed blob)
+    static constexpr int TAB_BYTES = 2 * (COUT + MID) * 4;  // per-channel (1 / scale, bias) of conv3 and conv1, staged once
+    static constexpr int LDS_BYTES = 2 * X_BYTES + 2 * W3_BYTES + W1_BYTES + TAB_BYTES;
+    static constexpr int W1_PIECES = W1_BYTES / 1024;       // 1 KB wave-instructions
+    static constexpr int W1_PER_STAGE = (W1_PIECES + NC3 - 1) / NC3;
+    static_assert(MID % 32 == 0 && CT % 32 == 0 && COUT % CT == 0, "tile shapes");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert((8 * CT * 16) % 1024 == 0 && W1_BYTES % 1024 == 0, "whole DMA pieces");
+    static_assert(MI1 * 16 + MI3 * 16 <= 176, "accumulators must leave room for fragments at 256 registers");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedTailParams p) {
+#pragma clang fp contract(off)       // scale, bias and identity are separately rounded steps in the standalone kernels: no multiply-add contraction here
+    __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];
+    char* const xbuf = smem;                               // 2 buffers
+    char* const w3buf = smem + 2 * C::X_BYTES;             // 2 buffers
+    char* const w1buf = smem + 2 * C::X_BYTES + 2 * C::W3_BYTES;
+    float* const tab = reinterpret_cast<float*>(smem + 2 * C::X_BYTES + 2 * C::W3_BYTES + C::W1_BYTES);     // [COUT] 1 / scale, [COUT] bias
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int pos0 = blockIdx.x * C::P;
+    const int pos = pos0 + wave * 32 + l31;                // this lane's position (column of every accumulator tile of the wave)
+    const bool pos_ok = pos < p.V;
+    const int pos_c = min(pos, p.V - 1);                    // (loads of a column past V read the last valid one: the column is never stored)
+    const int64_t V = p.V;
+    // Addressing: every global access below is (wave-uniform 64-bit base in SGPRs) + (ONE loop-invariant 32-bit per-lane byte offset), so that
+    // no 64-bit per-lane pointer stays live across the stages (the first build kept ~50 of them and spilled them around every DMA issue).
+    // The channel of accumulator register r of lane half h is base + (r & 3) + 8 (r >> 2) + 4 h: the 4 h part goes into the lane offset.
+    const unsigned int lane_off = (unsigned int)(((int64_t)(4 * half) * V + pos_c) * 4);      // bytes: (4 half) channels down, this lane's column
+    auto opaque = [](unsigned int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };   // (keeps address arithmetic inside its stage)
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- DMA issue helpers (each call = this wave's share; 1 KB per wave instruction, LDS image lane-linear) -------------------------
+    // x chunk c: 32 wave-instructions (plane, octet, quarter of the 256 positions), 4 per wave
+    const int xpos = min(pos0 + lane, p.V - 1);             // (clamped: columns past V are computed and never stored)
+    auto dma_x = [&](const int c, const int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = wave * 4 + k, pl = idx >> 4, o = (idx >> 2) & 3, q = idx & 3;
+            const unsigned int xp = (unsigned int)min((int)opaque((unsigned int)xpos) + q * 64, p.V - 1);
+            const char* src = reinterpret_cast<const char*>(p.x16) + ((int64_t)(pl * (C::MID / 8) + 4 * c + o)) * V * 16 + (size_t)(xp * 16u);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xbuf + buf * C::X_BYTES + ((pl * 4 + o) * C::P + q * 64) * 16), 16, 0, 0);
+        }
+    };
+    // w3 chunk (co-tile j, K-chunk c): 8 rows of CT x 16 B
+    auto dma_w3 = [&](const int j, const int c, const int buf) __attribute__((always_inline)) {
+        constexpr int PIECES = C::W3_BYTES / 1024, PER_ROW = C::CT * 16 / 1024;     // (CT = 64: one piece per row, one row per wave)
+#pragma unroll
+        for (int k = 0; k < (PIECES + C::NW - 1) / C::NW; ++k) {
+            const int idx = wave + k * C::NW;
+            if (idx < PIECES) {
+                const int row = idx / PER_ROW, part = idx % PER_ROW;
+                const char* src = p.w3 + ((int64_t)c * 8 + row) * (C::COUT * 16) + (int64_t)j * (C::CT * 16) + part * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w3buf + buf * C::W3_BYTES + idx * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // share `sub` (of NC3) of the co-tile's contiguous w1 block
+    auto dma_w1 = [&](const int j, const int sub) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < (C::W1_PER_STAGE + C::NW - 1) / C::NW; ++k) {
+            const int local = wave + k * C::NW;
+            const int idx = sub * C::W1_PER_STAGE + local;
+            if (local < C::W1_PER_STAGE && idx < C::W1_PIECES) {
+                const char* src = p.w1 + (int64_t)j * C::W1_BYTES + (int64_t)idx * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w1buf + idx * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_sync = [&]() __attribute__((always_inline)) {
+        // vmcnt(0): this wave's DMA pieces (and loads / stores) have landed.  The BUILTIN, not inline assembly: the compiler's wait-count
+        // pass must see it, or it guards the first use of a residual value loaded a stage earlier with a vmcnt(0) of its own -- behind the
+        // DMA just issued for the next stage
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    };
+
+    f32x16 acc1[C::MI1];
+#pragma unroll
+    for (int m = 0; m < C::MI1; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[m][r] = 0.f;
+
+    const float* inv3 = reinterpret_cast<const float*>(p.w3 + (int64_t)C::NC3 * 8 * C::COUT * 16);
+    const float* inv1 = reinterpret_cast<const float*>(p.w1 + (int64_t)(C::COUT / 32) * 8 * C::MID * 16);
+    const f16x8 k2048 = {(_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f),
+                         (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f)};
+
+    // three products per (A, B) fragment pair, smallest first -- the order of conv_igemm.hip's f16x3 stream
+    auto mma3 = [&](f32x16& acc, const f16x8 a_hi, const f16x8 a_lo, const f16x8 b_hi, const f16x8 b_lo) __attribute__((always_inline)) {
+        const f16x8 a_his = a_hi * k2048;                    // hi_w * 2^-11 (exact: a power of two on a normal number)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_his, b_lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
+    };
+
+    dma_x(0, 0);
+    dma_w3(0, 0, 0);
+    for (int i = tid; i < C::COUT; i += C::NTHREADS) { tab[i] = inv3[i]; tab[C::COUT + i] = p.b3[i]; }
+    for (int i = tid; i < C::MID; i += C::NTHREADS) { tab[2 * C::COUT + i] = inv1[i]; tab[2 * C::COUT + C::MID + i] = p.b1[i]; }
+    stage_sync();
+    int sb = 0;                                              // buffer of the conv3 sub-stage about to run
+#pragma unroll 1
+    for (int j = 0; j < C::NCT; ++j) {
+        f32x16 acc3[C::MI3];
+#pragma unroll
+        for (int m = 0; m < C::MI3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[m][r] = 0.f;
+        const int co_j = j * C::CT;
+        float rres[16];                                      // identity values of the co-tile's first 32-channel tile (loaded in the last sub-stage)
+#pragma unroll 1
+        for (int c = 0; c < C::NC3; ++c) {
+            // prefetch: the next conv3 sub-stage (this co-tile's, or the next co-tile's first) and this co-tile's w1 share
+            if (c + 1 < C::NC3) { dma_x(c + 1, sb ^ 1); dma_w3(j, c + 1, sb ^ 1); }
+            else if (j + 1 < C::NCT) { dma_x(0, sb ^ 1); dma_w3(j + 1, 0, sb ^ 1); }     // (it waits in its buffer through the epilogue stage)
+            dma_w1(j, c);
+            if (c == C::NC3 - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rres[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res + (int64_t)(co_j + (r & 3) + 8 * (r >> 2)) * V) + (size_t)lane_off);
+            }
+            const char* xb = xbuf + sb * C::X_BYTES + (half * C::P + wave * 32 + l31) * 16;
+            const char* wb = w3buf + sb * C::W3_BYTES + (half * C::CT + l31) * 16;
+            // software pipeline over the (k-group, 32-row tile) steps: the A fragments of step s + 1 are requested before the MFMAs of step s
+            // issue; fenced, or the scheduler hoists every fragment of the stage to its top (and spills) or sinks each to its use
+            constexpr int NS = 2 * C::MI3;
+            f16x8 b_hi[2], b_lo[2], a_hi[2], a_lo[2];
+            auto ld_b = [&](const int g, const int k) __attribute__((always_inline)) {
+                b_hi[k] = *reinterpret_cast<const f16x8*>(xb + ((0 * 4 + 2 * g) * C::P) * 16);
+                b_lo[k] = *reinterpret_cast<const f16x8*>(xb + ((1 * 4 + 2 * g) * C::P) * 16);
+            };
+            auto ld_a = [&](const int st, const int k) __attribute__((always_inline)) {
+                const int g = st / C::MI3, m = st % C::MI3;
+                a_hi[k] = *reinterpret_cast<const f16x8*>(wb + (((g * 2 + 0) * 2) * C::CT + m * 32) * 16);
+                a_lo[k] = *reinterpret_cast<const f16x8*>(wb + (((g * 2 + 1) * 2) * C::CT + m * 32) * 16);
+            };
+            ld_b(0, 0);
+            ld_b(1, 1);
+            ld_a(0, 0);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) ld_a(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma3(acc3[st % C::MI3], a_hi[st & 1], a_lo[st & 1], b_hi[st / C::MI3], b_lo[st / C::MI3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stage_sync();
+            sb ^= 1;
+        }
+        // ---- epilogue of the co-tile + its K-chunks of conv1 -------------------------------------------------------------------------
+        // (no DMA is issued in this stage: the compiler guards the first LDS read behind an LDS-DMA it cannot tell apart from the read's
+        // target with a vmcnt(0) -- the next co-tile's first chunk was requested in the last sub-stage above)
+#pragma unroll
+        for (int m = 0; m < C::MI3; ++m) {
+            const int co_m = co_j + m * 32;
+            // scale back, + bias, + identity, ReLU, store; C/D layout: register r of lane (half, l31) = row (r & 3) + 8 (r >> 2) + 4 half
+            unsigned int hw[8], lw[8];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co4 = co_m + 8 * q + 4 * half;
+                const float4 sc = *reinterpret_cast<const float4*>(tab + co4);
+                const float4 bv = *reinterpret_cast<const float4*>(tab + C::COUT + co4);
+                // (explicitly rounded steps: the standalone kernel scales its accumulators in one place and adds bias / identity in another -- no
+                // multiply-add contraction there, none here)
+                float v0 = __fmul_rn(acc3[m][4 * q + 0], sc.x), v1 = __fmul_rn(acc3[m][4 * q + 1], sc.y), v2 = __fmul_rn(acc3[m][4 * q + 2], sc.z),
+                      v3 = __fmul_rn(acc3[m][4 * q + 3], sc.w);
+                v0 = relu_keep_nan(__fadd_rn(__fadd_rn(v0, bv.x), rres[4 * q + 0]));
+                v1 = relu_keep_nan(__fadd_rn(__fadd_rn(v1, bv.y), rres[4 * q + 1]));
+                v2 = relu_keep_nan(__fadd_rn(__fadd_rn(v2, bv.z), rres[4 * q + 2]));
+                v3 = relu_keep_nan(__fadd_rn(__fadd_rn(v3, bv.w), rres[4 * q + 3]));
+                if (pos_ok) {
+                    char* yo = reinterpret_cast<char*>(p.y + (int64_t)(co_m + 8 * q) * V);       // (uniform; the 4 half rows are in lane_off)
+                    *reinterpret_cast<float*>(yo + (size_t)lane_off) = v0;
+                    *reinterpret_cast<float*>(yo + V * 4 + (size_t)lane_off) = v1;
+                    *reinterpret_cast<float*>(yo + V * 8 + (size_t)lane_off) = v2;
+                    *reinterpret_cast<float*>(yo + V * 12 + (size_t)lane_off) = v3;
+                }
+                ft_split_pair(v0, v1, hw[2 * q], lw[2 * q]);
+                ft_split_pair(v2, v3, hw[2 * q + 1], lw[2 * q + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // identity values of the NEXT 32-channel tile of this co-tile: they land under this tile's conv1 MFMAs
+            if (m + 1 < C::MI3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rres[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res + (int64_t)(co_m + 32 + (r & 3) + 8 * (r >> 2)) * V) + (size_t)lane_off);
+            }
+            // k-groups of 16 channels in the standalone kernel's order: lane half 0 channels 0..7, half 1 channels 8..15 of the group.  The lane
+            // halves hold (q even: ch 0-3 | 4-7), (q odd: 8-11 | 12-15): swapping the upper half of the q-even words with the lower half of the
+            // q-odd words gives (0-3, 4-7) to half 0 and (8-11, 12-15) to half 1.
+            __builtin_amdgcn_sched_barrier(0);
+            const char* w1b = w1buf + m * C::W1_CHUNK + (half * C::MID + l31) * 16;
+            f16x8 b_hi[2], b_lo[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                unsigned int xh[2], yh[2], xl[2], yl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    auto sh = __builtin_amdgcn_permlane32_swap(hw[4 * g + i], hw[4 * g + 2 + i], false, false);
+                    xh[i] = sh[0]; yh[i] = sh[1];
+                    auto sl = __builtin_amdgcn_permlane32_swap(lw[4 * g + i], lw[4 * g + 2 + i], false, false);
+                    xl[i] = sl[0]; yl[i] = sl[1];
+                }
+                const u32x4 bh = {xh[0], xh[1], yh[0], yh[1]}, bl = {xl[0], xl[1], yl[0], yl[1]};
+                b_hi[g] = __builtin_bit_cast(f16x8, bh);
+                b_lo[g] = __builtin_bit_cast(f16x8, bl);
+            }
+            constexpr int NS1 = 2 * C::MI1;
+            f16x8 a_hi[2], a_lo[2];
+            auto ld_a1 = [&](const int st, const int k) __attribute__((always_inline)) {
+                const int g = st / C::MI1, m1 = st % C::MI1;
+                a_hi[k] = *reinterpret_cast<const f16x8*>(w1b + (((g * 2 + 0) * 2) * C::MID + m1 * 32) * 16);
+                a_lo[k] = *reinterpret_cast<const f16x8*>(w1b + (((g * 2 + 1) * 2) * C::MID + m1 * 32) * 16);
+            };
+            ld_a1(0, 0);
+#pragma unroll
+            for (int st = 0; st < NS1; ++st) {
+                if (st + 1 < NS1) ld_a1(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma3(acc1[st % C::MI1], a_hi[st & 1], a_lo[st & 1], b_hi[st / C::MI1], b_lo[st / C::MI1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        stage_sync();
+    }
+    // ---- conv1's epilogue: scale back, + bias, ReLU, flat position -> (t, y, x) of the zero-haloed consumer layout -------------------------
+    if (pos_ok) {
+        const int hwp = p.dec_H * p.dec_W;
+        const int t2 = pos / hwp, r2 = pos - t2 * hwp, y2 = r2 / p.dec_W, x2 = r2 - y2 * p.dec_W;
+        const unsigned int z_off = (unsigned int)(((int64_t)(4 * half) * p.z_cs + (int64_t)t2 * p.z_ts + (int64_t)y2 * p.z_ys + x2) * 4);      // bytes
+#pragma unroll
+        for (int m1 = 0; m1 < C::MI1; ++m1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co4 = m1 * 32 + 8 * q + 4 * half;
+                const float4 sc = *reinterpret_cast<const float4*>(tab + 2 * C::COUT + co4);
+                const float4 bv = *reinterpret_cast<const float4*>(tab + 2 * C::COUT + C::MID + co4);
+                char* zo = reinterpret_cast<char*>(p.z + (int64_t)(m1 * 32 + 8 * q) * p.z_cs);     // (uniform)
+                *reinterpret_cast<float*>(zo + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 0], sc.x), bv.x));
+                *reinterpret_cast<float*>(zo + p.z_cs * 4 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 1], sc.y), bv.y));
+                *reinterpret_cast<float*>(zo + p.z_cs * 8 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 2], sc.z), bv.z));
+                *reinterpret_cast<float*>(zo + p.z_cs * 12 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 3], sc.w), bv.w));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+// workgroups the fused kernel makes of V positions (the planning twin of the launch: 256 positions each)
+static int64_t fused_tail_workgroups(int64_t V) { return ceil_div(V, 256); }
+
+template <class C>
+static int launch_fused_cfg(const FusedTailParams& p, hipStream_t s) {
+    const double flops = 2.0 * 2.0 * (double)C::MID * C::COUT * (double)p.V;        // both GEMMs
+    void* ev = profile_begin(19, flops, s);
+    hipLaunchKernelGGL(fused_tail_kernel<C>, dim3((unsigned)fused_tail_workgroups(p.V)), dim3(C::NTHREADS), 0, s, p);
+    profile_end(ev, s);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+// (the kernel reads the two-plane weight packing, SS_F16_WPLANES 2: the three-plane A/B build keeps the separate launches)
+#if defined(SS_F16_WPLANES) && SS_F16_WPLANES != 2
+bool fused_tail_supported(int) { return false; }
+#else
+bool fused_tail_supported(int mid) { return mid == 64 || mid == 128 || mid == 256; }
+#endif
+
+int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const float* b3, const float* res, float* y, const float* w1, const float* b1,
+                      const StemsegVolume& z, int dec_H, int dec_W, int64_t V, hipStream_t s) {
+    SS_CHECK_ARG(x16 && w3 && b3 && res && y && w1 && b1 && z.ptr, "fused_tail: null pointer");
+    SS_CHECK_ARG(fused_tail_supported(mid), "fused_tail: mid = %d (64, 128 or 256)", mid);
+    SS_CHECK_ARG(V > 0 && V <= (1ll << 27) && z.c_stride <= (1ll << 27) && dec_H > 0 && dec_W > 0 && V % ((int64_t)dec_H * dec_W) == 0, "fused_tail: V = %lld positions of %d x %d planes",
+                 (long long)V, dec_H, dec_W);
+    SS_CHECK_ARG(z.C == mid, "fused_tail: consumer volume has %d channels, conv1 makes %d", z.C, mid);
+    SS_CHECK_ARG(reinterpret_cast<uintptr_t>(x16) % 16 == 0 && reinterpret_cast<uintptr_t>(w3) % 16 == 0 && reinterpret_cast<uintptr_t>(w1) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(b3) % 16 == 0 && reinterpret_cast<uintptr_t>(b1) % 16 == 0, "fused_tail: 16-byte aligned operands");
+    FusedTailParams p;
+    p.x16 = x16; p.w3 = reinterpret_cast<const char*>(w3); p.b3 = b3; p.res = res; p.y = y;
+    p.w1 = reinterpret_cast<const char*>(w1); p.b1 = b1;
+    p.z = z.ptr; p.z_cs = z.c_stride; p.z_ts = z.t_stride; p.z_ys = z.y_stride; p.dec_H = dec_H; p.dec_W = dec_W;
+    p.V = (int)V;
+    if (mid == 256) return launch_fused_cfg<FusedTailCfg<256, 64>>(p, s);
+    if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64>>(p, s);
+    return launch_fused_cfg<FusedTailCfg<64, 64>>(p, s);
+}
+
+}  // namespace stemseg

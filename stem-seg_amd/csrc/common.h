@@ -121,10 +121,19 @@ struct ConvEpilogue {            // fused into the conv epilogue (or the split-K
     // the split-K scratch must hold nb times a single clip's slabs.
     int nb = 1;
     int64_t in_bs = 0, out_bs = 0, gn_bs = 0;
+    // f16x3: write the output as fp16 pair planes (the fused bottleneck tail's operand form, conv_igemm.hip ConvKParams::out_p16) into p16_out
+    // INSTEAD of fp32 into the output volume's memory; *p16_done = 1 when the launch did so, 0 when it fell back to the plain fp32 output
+    // (a split-K plan).  Decided on the planning shape like every launch decision.
+    unsigned int* p16_out = nullptr;
+    int* p16_done = nullptr;
 };
 int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* bias, const StemsegVolume& out,
                   int kt, int kh, int kw, int tile_cfg, hipStream_t s, float* splitk_scratch = nullptr, int64_t splitk_scratch_floats = 0,
                   const ConvEpilogue* epi = nullptr);
+// conv3 of a bottleneck block (+ bias + identity + ReLU) and conv1 of the next (+ bias + ReLU) in one launch (bottleneck_fused.hip, f16x3)
+bool fused_tail_supported(int mid);
+int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const float* b3, const float* res, float* y, const float* w1, const float* b1,
+                      const StemsegVolume& z, int dec_H, int dec_W, int64_t V, hipStream_t s);
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s);
 // conv + GroupNorm statistics of its output in one pass: the conv's epilogue (or its split-K reduce) leaves per-tile partial
 // sums in `gn_scratch` (>= gn_scratch_doubles(Cout, groups) doubles), one more tiny launch turns them into stats[2g] = mean,

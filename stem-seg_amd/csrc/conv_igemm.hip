@@ -135,6 +135,11 @@ struct ConvKParams {
     // launch decision is taken on ONE clip's shape, so a clip's result does not depend on how many share the launch.
     int nb;
     int64_t in_bs, out_bs, gn_bs;   // floats, floats, doubles
+    // f16x3: the output as fp16 PAIR PLANES instead of fp32 -- the operand form the fused bottleneck tail (bottleneck_fused.hip) stages by
+    // LDS-DMA: word [plane hi | lo * 2^11][channel / 8][position][(channel % 8) / 2] = the split of split_pair_f16 applied by the PRODUCER,
+    // same 4 bytes per value.  Dense outputs, by-element epilogue, no split-K (the launcher falls back to fp32 and says so through
+    // gn_used_host, which then points at the caller's "done" flag).
+    unsigned int* out_p16;
 };
 
 // FLAT (PMAX > 0): the N tile is a run of NSEG * 32 consecutive positions of the zero-haloed PLANE (row pitch <= PMAX floats)
@@ -1117,6 +1122,32 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 off = (int64_t)te * p.out_ts + (int64_t)y * p.out_ys + x;
                 roff = (int64_t)te * p.res_ts + (int64_t)y * p.res_ys + x;
             }
+            if constexpr (C::F16) {
+                if (p.out_p16) {                                   // (uniform) pair planes in octets: lane half h holds channels 8 q + 4 h + 0..3 of a 32-row tile
+                    const int64_t plane_words = (int64_t)(p.Cout / 8) * p.out_cs * 4;
+#pragma unroll
+                    for (int mi = 0; mi < C::MI; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int co4 = co_base + mi * 32 + 8 * q + 4 * half;
+                            if (co4 < p.Cout) {
+                                float v[4];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    v[k] = acc[mi][ni][4 * q + k] + (p.bias ? p.bias[co4 + k] : 0.f);
+                                    if (p.relu) v[k] = relu_keep_nan(v[k]);
+                                }
+                                uint2 hw, lw;
+                                split_pair_f16(v[0], v[1], hw.x, lw.x);
+                                split_pair_f16(v[2], v[3], hw.y, lw.y);
+                                unsigned int* d = p.out_p16 + ((int64_t)(co4 / 8) * p.out_cs + off) * 4 + 2 * half;
+                                *reinterpret_cast<uint2*>(d) = hw;
+                                *reinterpret_cast<uint2*>(d + plane_words) = lw;
+                            }
+                        }
+                    continue;
+                }
+            }
             float* o = p.out + (int64_t)blockIdx.y * p.out_bs + (int64_t)blockIdx.z * p.out_split_stride + off;
 #pragma unroll
             for (int mi = 0; mi < C::MI; ++mi) {
@@ -1460,6 +1491,10 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     // (a planned launch never shrinks its K-partition to fit: that would be a batch-dependent summation order again)
     SS_CHECK_ARG(ksplit == 1 || (int64_t)p.nb * ksplit * slab <= scratch_floats, "conv3d: split-K scratch too small (%lld floats needed, %lld given)",
                  (long long)((int64_t)p.nb * ksplit * slab), (long long)scratch_floats);
+    if (p.out_p16) {                                     // pair-plane output: by-element epilogue of an un-split launch, else plain fp32
+        if (ksplit > 1 || !C::F16) p.out_p16 = nullptr;
+        else { p.vec_epi = 0; if (p.gn_used_host) *p.gn_used_host = 1; }
+    }
     SplitReduceParams rp;
     // 16-B reduce: the true output (and residual) rows are aligned (vec_epi as computed by the caller) and W % 4 == 0
     const bool rp_vec = out_vec && p.dec_W == 0 && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) && (slab % 4 == 0);
@@ -1698,6 +1733,15 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
     p.gn_part = epi ? epi->gn_part : nullptr;
     p.gn_cpg = epi ? epi->gn_cpg : 0; p.gn_cap = epi ? epi->gn_cap : 0; p.gn_slot0 = 0;
     p.gn_used_host = epi ? epi->gn_used : nullptr;
+    p.out_p16 = nullptr;
+    if (epi && epi->p16_out) {
+        const bool dense = out.t_stride == (int64_t)out.H * out.W && out.y_stride == out.W && out.c_stride == (int64_t)out.T * out.H * out.W;
+        SS_CHECK_ARG(epi->p16_done && dense && !flat && !epi->res && !epi->gn_part && out.C % 8 == 0 && prec == STEMSEG_PRECISION_F16X3 && (!epi || epi->nb <= 1),
+                     "conv3d: the pair-plane output needs f16x3, a dense output volume, no residual / statistics / clip batch");
+        *epi->p16_done = 0;
+        p.out_p16 = epi->p16_out;
+        p.gn_used_host = epi->p16_done;                    // (see ConvKParams::out_p16)
+    }
     p.nb = (epi && epi->nb > 1) ? epi->nb : 1;
     p.in_bs = p.nb > 1 ? epi->in_bs : 0; p.out_bs = p.nb > 1 ? epi->out_bs : 0; p.gn_bs = p.nb > 1 ? epi->gn_bs : 0;
     SS_CHECK_ARG(p.nb == 1 || (!p.res && p.nb <= 65535 && p.in_bs % 4 == 0 && p.out_bs % 4 == 0), "conv3d: a clip batch takes no residual and 16-byte aligned clip strides");

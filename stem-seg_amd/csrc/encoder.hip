@@ -341,6 +341,43 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(float* __restrict__
     }
 }
 
+// 16-B form: one thread = one ALIGNED group of four columns of the zero-haloed fine row (haloed columns 4k .. 4k + 3 = map columns 4k - 1 .. 4k + 2:
+// the interior starts at haloed column 1, so aligned groups straddle it by one).  The fine row is read and written as one float4 (a halo word
+// in the group is written back unchanged: zero), the two coarse rows contribute three columns each (2k - 1 .. 2k + 1, clamped exactly as the scalar
+// form clamps them), and every output evaluates the SAME expression as the scalar form, so the bits are the same.  Needs pitch % 4 == 0 and a
+// 16-B aligned plane base (the encoder's zero-haloed buffers are).  n_items = planes x H x groups per row.
+__global__ __launch_bounds__(256) void upsample2x_add_vec4_kernel(float* __restrict__ fine_halo, const float* __restrict__ coarse, int H, int W, unsigned gq,
+                                                                   unsigned n_items, int64_t f_ts, int f_pitch, int64_t c_ts, int c_pitch) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_items) return;
+    const unsigned row = idx / gq;                           // plane * H + y
+    const int k = (int)(idx - row * gq);
+    const unsigned pl = row / (unsigned)H;
+    const int y = (int)(row - pl * (unsigned)H);
+    const int Hc = H / 2, Wc = W / 2;
+    float sy = 0.5f * ((float)y + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    const int y0 = (int)sy, y1 = y0 + (y0 < Hc - 1 ? 1 : 0);
+    const float wy = sy - (float)y0;
+    const float* c0 = coarse + (int64_t)pl * c_ts + (int64_t)y0 * c_pitch;
+    const float* c1 = coarse + (int64_t)pl * c_ts + (int64_t)y1 * c_pitch;
+    float4* fp = reinterpret_cast<float4*>(fine_halo + (int64_t)pl * f_ts + (int64_t)(y + 1) * f_pitch + 4 * k);
+    float4 f = *fp;
+    float* fv = reinterpret_cast<float*>(&f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = 4 * k - 1 + j;
+        if (x < 0 || x >= W) continue;
+        float sx = 0.5f * ((float)x + 0.5f) - 0.5f;
+        sx = sx < 0.f ? 0.f : sx;
+        const int x0 = (int)sx, x1 = x0 + (x0 < Wc - 1 ? 1 : 0);
+        const float wx = sx - (float)x0;
+        const float v = (1.f - wy) * ((1.f - wx) * c0[x0] + wx * c0[x1]) + wy * ((1.f - wx) * c1[x0] + wx * c1[x1]);
+        fv[j] += v;
+    }
+    *fp = f;
+}
+
 static int grid1d(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 256 * 16)); }
 
 struct EncoderPlan {
@@ -562,6 +599,7 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
     // residual stages (resnet.py:105-113)
     float* x = ws + p.X1;
     int cin = 64, bi = 0;
+    bool conv1_done = false;            // this block's conv1 came out of the previous block's fused tail (bottleneck_fused.hip)
     for (int st = 0; st < 4; ++st) {
         const int mid = 64 << st, cout = 256 << st, h = p.h[st], w = p.w[st];
         const int64_t V = p.V[st];
@@ -584,13 +622,21 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
                 xin = ws + p.XS;
             }
             float* y = (b == p.nblk[st] - 1) ? ws + p.Cst[st] : ((b & 1) ? ws + p.B : ws + p.A);
-            ConvEpilogue e1 = epi_for(T);       // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
-            e1.relu = 1; e1.dec_H = h; e1.dec_W = w;
-            rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1[st], mid, T, h, w), 1, 1, 1, 0, s,
-                               ws + p.SK, p.SKfloats, &e1);
-            if (rc) return rc;
+            if (!conv1_done) {
+                ConvEpilogue e1 = epi_for(T);       // conv1 + bn1 + relu -> zero-haloed 2-D layout (input of the 3x3)
+                e1.relu = 1; e1.dec_H = h; e1.dec_W = w;
+                rc = launch_conv3d(flat_view(xin, cin, V), wts->conv1_w[bi], wts->conv1_b[bi], interior2d_view(ws + p.M1[st], mid, T, h, w), 1, 1, 1, 0, s,
+                                   ws + p.SK, p.SKfloats, &e1);
+                if (rc) return rc;
+            }
+            // Fused tail (f16x3): conv3 of this block and conv1 of the next in one back-to-back kernel.  conv2 then writes its output as the
+            // fp16 operand planes that kernel stages by LDS-DMA (same bytes, the M2 buffer) -- unless its plan splits K, in which case it
+            // says so and the block runs its three launches (a function of the planning shape: the same choice for every batch).
+            const bool want_fuse = desc->fuse_tail && prec == STEMSEG_PRECISION_F16X3 && b + 1 < p.nblk[st] && fused_tail_supported(mid) && V <= (1ll << 27) && (int64_t)T * (h + 2) * (w + 4) <= (1ll << 27);
+            int p16_done = 0;
             ConvEpilogue e2 = epi_for(T);       // conv2 (3x3) + bn2 + relu -> dense
             e2.relu = 1;
+            if (want_fuse) { e2.p16_out = reinterpret_cast<unsigned int*>(ws + p.M2); e2.p16_done = &p16_done; }
             rc = launch_conv3d(halo2d_view(ws + p.M1[st], mid, T, h, w), wts->conv2_w[bi], wts->conv2_b[bi], dense_volume(ws + p.M2, mid, T, h, w), 1, 3, 3, 0, s,
                                ws + p.SK, p.SKfloats, &e2);
             if (rc) return rc;
@@ -602,10 +648,19 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
                 if (rc) return rc;
                 idt = ws + p.DS;
             }
-            ConvEpilogue e3 = epi_for(T);       // conv3 + bn3 + identity + relu
-            e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0;
-            rc = launch_conv3d(flat_view(ws + p.M2, mid, V), wts->conv3_w[bi], wts->conv3_b[bi], flat_view(y, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats, &e3);
-            if (rc) return rc;
+            if (want_fuse && p16_done) {
+                SS_CHECK_ARG(wts->conv1_w[bi + 1] && wts->conv1_b[bi + 1], "encoder_forward: null weights for block %d", bi + 1);
+                rc = launch_fused_tail(mid, reinterpret_cast<const unsigned int*>(ws + p.M2), wts->conv3_w[bi], wts->conv3_b[bi], idt, y, wts->conv1_w[bi + 1],
+                                       wts->conv1_b[bi + 1], interior2d_view(ws + p.M1[st], mid, T, h, w), h, w, V, s);
+                if (rc) return rc;
+                conv1_done = true;
+            } else {
+                ConvEpilogue e3 = epi_for(T);       // conv3 + bn3 + identity + relu
+                e3.relu = 1; e3.res = idt; e3.res_cs = V; e3.res_ts = 0; e3.res_ys = 0;
+                rc = launch_conv3d(flat_view(ws + p.M2, mid, V), wts->conv3_w[bi], wts->conv3_b[bi], flat_view(y, cout, V), 1, 1, 1, 0, s, ws + p.SK, p.SKfloats, &e3);
+                if (rc) return rc;
+                conv1_done = false;
+            }
             x = y;
             cin = cout;
         }
@@ -624,8 +679,14 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             // and every tile's kernel arguments grow: the step 103.0 vs 104.8 clips/s, interleaved on one box.)
             Padded2D gf(256, T, h, w), gc(256, T, p.h[k + 1], p.w[k + 1]);
             void* ev = profile_begin(50, 4.0 * 256.0 * (2.0 * p.V[k] + p.V[k + 1]), s);         // fine read + written, coarse read
-            hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid1d(256 * p.V[k])), dim3(256), 0, s, ws + p.L[k] + gf.interior,
-                               (const float*)(ws + p.L[k + 1] + gc.interior), (int64_t)256 * T, h, w, gf.ts, gf.pitch, gc.ts, gc.pitch);
+            const unsigned gq = (unsigned)((w + 1) / 4 + 1);                              // aligned groups covering haloed columns 1 .. w
+            const int64_t ua_items = (int64_t)256 * T * h * gq;
+            if (gf.pitch % 4 == 0 && (int64_t)4 * gq <= gf.pitch && ua_items < (1ll << 32) - 256 && (reinterpret_cast<uintptr_t>(ws + p.L[k]) % 16 == 0) && gf.ts % 4 == 0)
+                hipLaunchKernelGGL(upsample2x_add_vec4_kernel, dim3((unsigned)ceil_div(ua_items, 256)), dim3(256), 0, s, ws + p.L[k],
+                                   (const float*)(ws + p.L[k + 1] + gc.interior), h, w, gq, (unsigned)ua_items, gf.ts, (int)gf.pitch, gc.ts, (int)gc.pitch);
+            else
+                hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid1d(256 * p.V[k])), dim3(256), 0, s, ws + p.L[k] + gf.interior,
+                                   (const float*)(ws + p.L[k + 1] + gc.interior), (int64_t)256 * T, h, w, gf.ts, gf.pitch, gc.ts, gc.pitch);
             profile_end(ev, s);
             SS_LAUNCH_CHECK();
         }

@@ -184,44 +184,44 @@ __global__ __launch_bounds__(256) void gn_relu_stream_kernel(GnApplyParams p, un
     }
 }
 
-// Pooled apply, 4 outputs along x per thread: the 3 x 3 x 3 window of 4 neighbouring outputs is 9 rows of 6 inputs, each
-// normalised / rectified ONCE (the scalar form does it 27 times per output), then three-term row sums slide along x.
-// grid.y = (channel, pooled t); the destination may be dense or zero-haloed (scalar stores: its rows start at +1).
-__global__ __launch_bounds__(256) void gn_relu_pool4_kernel(GnApplyParams p, unsigned wq, unsigned n_items) {
-    const unsigned item = blockIdx.x * 256u + threadIdx.x;
-    if (item >= n_items) return;
+// Pooled apply through LDS: a workgroup owns a band of `band` output rows of one (channel, pooled t) plane.  The 3 input planes x
+// (band + 2) rows x W floats it needs are read from HBM ONCE (coalesced along x), normalised / rectified once and staged; the window is
+// then separable -- the three planes are folded into one in place, and every output is nine staged values (3 rows x 3 columns).  Round 5's
+// form (4 outputs per thread straight from global memory) issued 54 scalar loads per 4 outputs and ran at 0.11 of the HBM roof; this one
+// loads each input 3 * (band + 2) / (2 * band) times.  Values are >= 0 after the ReLU, so zero padding serves the average (count_include_pad:
+// always / 27) and the maximum alike.  grid = (bands, C * To, clips); the destination may be dense or zero-haloed.
+__global__ __launch_bounds__(256) void gn_relu_pool_lds_kernel(GnApplyParams p, int band) {
+    extern __shared__ float pl[];                              // [3][band + 2][W]
     p.x += (int64_t)blockIdx.z * p.x_bs; p.out += (int64_t)blockIdx.z * p.out_bs; p.stats += (int64_t)blockIdx.z * p.stats_bs;
     const int c = blockIdx.y / p.To, to = blockIdx.y - c * p.To;
-    const int y = (int)(item / wq), x0 = (int)(item - (unsigned)y * wq) * 4;
+    const int y0 = blockIdx.x * band, rows_out = min(band, p.H - y0), rows_in = rows_out + 2;
     const int g = c / p.cpg;
     const float a = p.stats[2 * g + 1] * p.gamma[c];
     const float b = p.beta[c] - p.stats[2 * g] * a;
-    const int HW = p.H * p.W;
+    const int HW = p.H * p.W, W = p.W, plane = rows_in * W;
     const float* xc = p.x + (int64_t)c * p.T * HW;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dt = -1; dt <= 1; ++dt) {
-        const int t = 2 * to + dt;
-        if (t < 0 || t >= p.T) continue;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= p.H) continue;
-            const float* row = xc + t * HW + yy * p.W;
-            float r[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int xx = x0 - 1 + k;
-                r[k] = (xx >= 0 && xx < p.W) ? relu_keep_nan(fmaf(row[xx], a, b)) : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = p.pool_max ? max_keep_nan(acc[j], max_keep_nan(max_keep_nan(r[j], r[j + 1]), r[j + 2])) : acc[j] + ((r[j] + r[j + 1]) + r[j + 2]);
-        }
+    for (int i = threadIdx.x; i < 3 * plane; i += 256) {
+        const int dt = i / plane, r2 = i - dt * plane, r = r2 / W, x = r2 - r * W;
+        const int t = 2 * to + dt - 1, yy = y0 + r - 1;
+        float v = 0.f;
+        if (t >= 0 && t < p.T && yy >= 0 && yy < p.H) v = relu_keep_nan(fmaf(xc[t * HW + yy * W + x], a, b));
+        pl[i] = v;
     }
-    float* o = p.out + (int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)y * p.out_ys + x0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < plane; i += 256)             // fold the three planes (each thread its own elements: no hazard)
+        pl[i] = p.pool_max ? max_keep_nan(max_keep_nan(pl[i], pl[plane + i]), pl[2 * plane + i]) : (pl[i] + pl[plane + i]) + pl[2 * plane + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows_out * W; i += 256) {
+        const int r = i / W, x = i - r * W;
+        float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (x0 + j < p.W) o[j] = p.pool_max ? acc[j] : acc[j] / 27.0f;
+        for (int dy = 0; dy < 3; ++dy) {
+            const float* row = pl + (r + dy) * W + x;
+            const float l = x > 0 ? row[-1] : 0.f, m = row[0], rr = x + 1 < W ? row[1] : 0.f;
+            acc = p.pool_max ? max_keep_nan(acc, max_keep_nan(max_keep_nan(l, m), rr)) : acc + ((l + m) + rr);
+        }
+        p.out[(int64_t)c * p.out_cs + (int64_t)to * p.out_ts + (int64_t)(y0 + r) * p.out_ys + x] = p.pool_max ? acc : acc / 27.0f;
+    }
 }
 
 __global__ void gn_identity_stats_kernel(float* stats, int groups) {
@@ -277,9 +277,11 @@ int launch_gn_relu_pool(const float* x, int C, int T, int H, int W, int groups, 
     const int64_t S = (int64_t)T * H * W;
     const bool small = S < (1ll << 31) && total < (1ll << 40);      // 32-bit offsets inside a channel
     void* ev = profile_begin(pool ? 43 : 42, 4.0 * ((double)C * S + (double)total) * nb, s);
-    if (pool && small && C * To <= 65535) {
-        const unsigned wq = (unsigned)ceil_div(W, 4), items = wq * (unsigned)H;
-        hipLaunchKernelGGL(gn_relu_pool4_kernel, dim3((unsigned)ceil_div(items, 256), (unsigned)(C * To), nb), dim3(256), 0, s, p, wq, items);
+    // band of output rows per workgroup: 3 x (band + 2) x W floats of LDS, at most 48 KB (a function of the plane's shape only)
+    const int band = std::min(16, std::max(1, (int)(12288 / (3 * (int64_t)W)) - 2));
+    if (pool && small && C * To <= 65535 && 3 * (int64_t)(band + 2) * W <= 12288) {
+        const size_t lds = (size_t)3 * (band + 2) * W * sizeof(float);
+        hipLaunchKernelGGL(gn_relu_pool_lds_kernel, dim3((unsigned)ceil_div(H, band), (unsigned)(C * To), nb), dim3(256), lds, s, p, band);
     } else if (!pool && C <= 65535 && S % 4 == 0 && S / 4 < (1ll << 31) && out.t_stride == (int64_t)H * W && out.y_stride == W &&
                out.c_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out.ptr) % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0)) {
         const unsigned n4 = (unsigned)(S / 4);

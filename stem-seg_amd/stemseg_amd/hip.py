@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STEMSEG_HIP_LIB") or os.path.join(_HERE, "lib", "libs
 
 MAX_INSTANCES = 64
 MAX_EMB_DIMS = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class Volume(C.Structure):
@@ -50,7 +50,7 @@ class ConvEpilogue(C.Structure):
 class EncoderDesc(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("blocks", C.c_int32 * 4), ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("out_channels", C.c_int32), ("precision", C.c_int32), ("n_clips", C.c_int32), ("clip_frames", C.c_int32),
-                ("clip_stride", C.c_int32), ("plan_frames", C.c_int32)]
+                ("clip_stride", C.c_int32), ("plan_frames", C.c_int32), ("fuse_tail", C.c_int32)]
 
 
 _BLK = C.c_void_p * MAX_ENCODER_BLOCKS
@@ -193,7 +193,7 @@ def profile_enable(on):
 
 
 # profiler tags: convolutions by tile class (work = FLOP) and the streaming kernels (work = algorithmic bytes)
-PROFILE_CONV_TAGS = {"conv3x3x3": (9, 8, 4, 2), "conv1x3x3": (36, 28, 27, 24, 22), "conv1x1x1": (18, 17, 14, 16, 12)}
+PROFILE_CONV_TAGS = {"conv3x3x3": (9, 8, 4, 2), "conv1x3x3": (36, 28, 27, 24, 22), "conv1x1x1": (18, 17, 14, 16, 12, 19)}      # (19: the fused bottleneck tail, both of its 1x1 GEMMs)
 PROFILE_HBM_TAGS = {40: "upsample_trilinear", 41: "gn_stats (partial + finalize)", 42: "gn_relu (apply)", 43: "gn_relu_pool (apply + AvgPool3d)",
                     44: "heads", 45: "fg_gather (count + scan + scatter)", 46: "cluster (all rounds + final)", 47: "stem_conv7x7",
                     48: "maxpool3x3s2", 49: "subsample2", 50: "upsample2x_add (FPN top-down)"}
