@@ -524,6 +524,7 @@ def main():
     ap.add_argument("--plan-frames", type=int, default=None,
                     help="frames the encoder plans its launches for (default: the model's own constant, ResNetFPN.plan_frames = 32, whatever "
                          "--clips-per-step / --sequence say: two batchings of one job give the same bits).  A throughput knob for A/B runs only")
+    ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: stages whose bottleneck tails run fused (bit mask 1 | 2 | 4; default: the model's, 7; 0: none)")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -580,6 +581,8 @@ def main():
     if args.plan_frames is not None:
         pipe.model._model.backbone.plan_frames = int(args.plan_frames)
     args.plan_frames = int(pipe.model._model.backbone.plan_frames)
+    if args.fuse_tail is not None:
+        pipe.model._model.backbone.fuse_tail = int(args.fuse_tail)
     if args.sequence:
         sequence_mode(args, pipe, device, rank, world, use_dist)
         if use_dist:

@@ -278,11 +278,11 @@ typedef struct StemsegEncoderDesc {
                                     whatever T, n_clips and the windowing of the pass are -- one clip, a batch of clips, or the
                                     union of overlapping windows -- which is what makes an N-rank sequence job reproduce the
                                     one-rank labels.  0: decide on the real T (fastest for that T; results depend on it). */
-    int32_t fuse_tail;           /* f16x3 mode, stages 1-3: conv3 (+ bias + identity + ReLU) of a bottleneck block and conv1 (+ bias + ReLU) of
+    int32_t fuse_tail;           /* bit (stage - 1) set (1 | 2 | 4 = stages 1-3), f16x3 mode: conv3 (+ bias + identity + ReLU) of a bottleneck block and conv1 (+ bias + ReLU) of
                                     the next one run as ONE back-to-back kernel (resnet.py:262-282 of two consecutive blocks): the 4x-wide block
                                     output is written once and never read back by conv1, and conv2 hands its output over as fp16 operand
                                     planes.  Same operands and k order: bit-identical to the separate launches wherever those run without
-                                    split-K.  0: three launches per block (rounds 1-5). */
+                                    split-K.  0: three launches per block everywhere (rounds 1-5). */
 } StemsegEncoderDesc;
 
 typedef struct StemsegEncoderWeights {

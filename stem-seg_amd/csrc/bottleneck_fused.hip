@@ -24,6 +24,24 @@
 // them), then ONE epilogue + conv1 stage.  One barrier per stage, vmcnt(0) in front of it.
 #include "common.h"
 
+// Timing probes / A-B switches: EXPERIMENT builds only (-DSS_EXPERIMENTS), as in conv_igemm.hip.  SS_FT_PROBE (results WRONG for any value but 0):
+// 1 no identity loads and no block-output stores (the kernel's HBM traffic), 2 no LDS-DMA of the input chunks, 3 no MFMAs.
+// SS_FT_STAGGER n: workgroup b starts (b % 16) * n * ~0.5 us late (spreads the workgroups' HBM bursts; same results).
+#ifndef SS_EXPERIMENTS
+#if defined(SS_FT_PROBE) || defined(SS_FT_STAGGER)
+#error "SS_FT_PROBE / SS_FT_STAGGER are experiment switches: add -DSS_EXPERIMENTS"
+#endif
+#define SS_FT_PROBE 0
+#define SS_FT_STAGGER 0
+#else
+#ifndef SS_FT_PROBE
+#define SS_FT_PROBE 0
+#endif
+#ifndef SS_FT_STAGGER
+#define SS_FT_STAGGER 0
+#endif
+#endif
+
 namespace stemseg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,35 +77,42 @@ __device__ __forceinline__ void ft_split_pair(const float x0, const float x1, un
     lw = l;
 }
 
-template <int MID_, int CT_>
+template <int MID_, int CT_, int P_>
 struct FusedTailCfg {
     static constexpr int MID = MID_, CT = CT_, COUT = 4 * MID_;
-    static constexpr int P = 256, NW = 8, NTHREADS = 512;
+    static constexpr int P = P_, NW = P_ / 32, NTHREADS = 64 * NW;   // positions per workgroup; one 32-position column block per wave
     static constexpr int NC3 = MID / 32;                   // conv3 K-chunks (32 channels)
     static constexpr int NCT = COUT / CT;                  // co-tiles
     static constexpr int MI3 = CT / 32, MI1 = MID / 32;    // 32-row accumulator tiles per wave: conv3 co-tile, conv1
+    static constexpr int NH = 2 * MI3;                     // conv1 K-halves (k-groups of 16 channels) per co-tile
     static constexpr int X_BYTES = 2 * 4 * P * 16;          // x chunk: [plane][octet][position][4 words]
     static constexpr int W3_BYTES = 8 * CT * 16;            // w3 chunk of the co-tile: [grp][plane][half][CT][16 B]
-    static constexpr int W1_CHUNK = 8 * MID * 16;           // one 32-channel chunk of w1: [grp][plane][half][MID][16 B]
-    static constexpr int W1_BYTES = MI3 * W1_CHUNK;         // the co-tile's chunks (contiguous in the packed blob)
-    static constexpr int TAB_BYTES = 2 * (COUT + MID) * 4;  // per-channel (1 / scale, bias) of conv3 and conv1, staged once
-    static constexpr int LDS_BYTES = 2 * X_BYTES + 2 * W3_BYTES + W1_BYTES + TAB_BYTES;
-    static constexpr int W1_PIECES = W1_BYTES / 1024;       // 1 KB wave-instructions
-    static constexpr int W1_PER_STAGE = (W1_PIECES + NC3 - 1) / NC3;
-    static_assert(MID % 32 == 0 && CT % 32 == 0 && COUT % CT == 0, "tile shapes");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert((8 * CT * 16) % 1024 == 0 && W1_BYTES % 1024 == 0, "whole DMA pieces");
+    static constexpr int W1_HALF = 4 * MID * 16;            // one k-group of w1: [plane][half][MID][16 B]; a co-tile's NH of them are contiguous in the packed blob
+    static constexpr int LDS_BYTES = 2 * X_BYTES + 2 * W3_BYTES + 2 * W1_HALF;
+    static constexpr int NQ = P / 64;                       // 64-position quarters of an x row
+    static constexpr int X_PIECES = X_BYTES / 1024, W3_PIECES = W3_BYTES / 1024, W1_PIECES = W1_HALF / 1024;     // 1 KB wave-instructions
+    static_assert(P % 64 == 0 && MID % 32 == 0 && CT % 32 == 0 && COUT % CT == 0, "tile shapes");
+    static_assert(LDS_BYTES <= (P <= 128 ? 80 : 160) * 1024, "LDS: two 128-position workgroups, or one 256-position workgroup, per CU");
+    static_assert(W3_BYTES % 1024 == 0 && W1_HALF % 1024 == 0 && X_PIECES % NW == 0, "whole DMA pieces");
     static_assert(MI1 * 16 + MI3 * 16 <= 176, "accumulators must leave room for fragments at 256 registers");
 };
 
+// Stages of a workgroup, one barrier (behind a vmcnt(0)) each; every stage first requests what the NEXT stage reads (LDS-DMA into the idle
+// buffer of its kind), then computes:
+//   per co-tile j:  S(c), c < MID / 32   conv3 MFMAs of K-chunk c (x chunk c + w3 chunk (j, c)); the last one also requests w1 half 0 and the
+//                                        identity values of the co-tile's first 32-channel tile
+//                   E(h), h < 2 CT / 32  h even: scale / bias / identity / ReLU / store / split of 32-channel tile h / 2, its two k-groups as B
+//                                        fragments; then conv1's MFMAs of k-group h (w1 half h); the last one requests the next co-tile's S(0)
+// A stage is 0.4-0.8 us of matrix work against ~1 us from a DMA request to its landing, so one workgroup alone spends most of its time at the
+// barrier (measured: the 256-position form ran at 34 % MFMA-pipe occupancy, and removing ALL its MFMAs saved 9 %).  The 128-position form is
+// therefore the default: 80 KB of LDS, four waves -- TWO workgroups per CU, each filling the other's waits.
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedTailParams p) {
 #pragma clang fp contract(off)       // scale, bias and identity are separately rounded steps in the standalone kernels: no multiply-add contraction here
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];
     char* const xbuf = smem;                               // 2 buffers
     char* const w3buf = smem + 2 * C::X_BYTES;             // 2 buffers
-    char* const w1buf = smem + 2 * C::X_BYTES + 2 * C::W3_BYTES;
-    float* const tab = reinterpret_cast<float*>(smem + 2 * C::X_BYTES + 2 * C::W3_BYTES + C::W1_BYTES);     // [COUT] 1 / scale, [COUT] bias
+    char* const w1buf = smem + 2 * C::X_BYTES + 2 * C::W3_BYTES;      // 2 buffers (k-group halves)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,50 +130,81 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedT
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* inv3 = reinterpret_cast<const float*>(p.w3 + (int64_t)C::NC3 * 8 * C::COUT * 16);
+    const float* inv1 = reinterpret_cast<const float*>(p.w1 + (int64_t)(C::COUT / 32) * 8 * C::MID * 16);
 
     // ---- DMA issue helpers (each call = this wave's share; 1 KB per wave instruction, LDS image lane-linear) -------------------------
-    // x chunk c: 32 wave-instructions (plane, octet, quarter of the 256 positions), 4 per wave
     const int xpos = min(pos0 + lane, p.V - 1);             // (clamped: columns past V are computed and never stored)
-    auto dma_x = [&](const int c, const int buf) __attribute__((always_inline)) {
+    auto dma_x = [&](const int c, const int buf) __attribute__((always_inline)) {       // x chunk c: (plane, octet, 64-position quarter) pieces
+#if SS_FT_PROBE == 2
+        return;
+#endif
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = wave * 4 + k, pl = idx >> 4, o = (idx >> 2) & 3, q = idx & 3;
+        for (int k = 0; k < C::X_PIECES / C::NW; ++k) {
+            const int idx = wave * (C::X_PIECES / C::NW) + k, q = idx % C::NQ, o = (idx / C::NQ) & 3, pl = idx / (4 * C::NQ);
             const unsigned int xp = (unsigned int)min((int)opaque((unsigned int)xpos) + q * 64, p.V - 1);
             const char* src = reinterpret_cast<const char*>(p.x16) + ((int64_t)(pl * (C::MID / 8) + 4 * c + o)) * V * 16 + (size_t)(xp * 16u);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xbuf + buf * C::X_BYTES + ((pl * 4 + o) * C::P + q * 64) * 16), 16, 0, 0);
         }
     };
-    // w3 chunk (co-tile j, K-chunk c): 8 rows of CT x 16 B
-    auto dma_w3 = [&](const int j, const int c, const int buf) __attribute__((always_inline)) {
-        constexpr int PIECES = C::W3_BYTES / 1024, PER_ROW = C::CT * 16 / 1024;     // (CT = 64: one piece per row, one row per wave)
+    auto dma_w3 = [&](const int j, const int c, const int buf) __attribute__((always_inline)) {      // w3 chunk (co-tile j, K-chunk c): 8 rows of CT x 16 B
+        constexpr int PER_ROW = C::CT * 16 / 1024;
 #pragma unroll
-        for (int k = 0; k < (PIECES + C::NW - 1) / C::NW; ++k) {
+        for (int k = 0; k < (C::W3_PIECES + C::NW - 1) / C::NW; ++k) {
             const int idx = wave + k * C::NW;
-            if (idx < PIECES) {
+            if (idx < C::W3_PIECES) {
                 const int row = idx / PER_ROW, part = idx % PER_ROW;
                 const char* src = p.w3 + ((int64_t)c * 8 + row) * (C::COUT * 16) + (int64_t)j * (C::CT * 16) + part * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w3buf + buf * C::W3_BYTES + idx * 1024), 16, 0, 0);
             }
         }
     };
-    // share `sub` (of NC3) of the co-tile's contiguous w1 block
-    auto dma_w1 = [&](const int j, const int sub) __attribute__((always_inline)) {
+    auto dma_w1 = [&](const int j, const int h, const int buf) __attribute__((always_inline)) {      // k-group half h of co-tile j's w1 block
 #pragma unroll
-        for (int k = 0; k < (C::W1_PER_STAGE + C::NW - 1) / C::NW; ++k) {
-            const int local = wave + k * C::NW;
-            const int idx = sub * C::W1_PER_STAGE + local;
-            if (local < C::W1_PER_STAGE && idx < C::W1_PIECES) {
-                const char* src = p.w1 + (int64_t)j * C::W1_BYTES + (int64_t)idx * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w1buf + idx * 1024), 16, 0, 0);
+        for (int k = 0; k < (C::W1_PIECES + C::NW - 1) / C::NW; ++k) {
+            const int idx = wave + k * C::NW;
+            if (idx < C::W1_PIECES) {
+                const char* src = p.w1 + ((int64_t)j * C::NH + h) * C::W1_HALF + (int64_t)idx * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w1buf + buf * C::W1_HALF + idx * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // the co-tile's per-channel (1 / scale, bias): CT + CT floats into the head of the w3 buffer that idles through the epilogue stages
+    // (lanes 0 .. CT / 4 - 1 of wave 0 carry the scales, the next CT / 4 lanes the biases)
+    auto dma_tab = [&](const int j, const int buf) __attribute__((always_inline)) {
+        static_assert(2 * (C::CT / 4) <= 64 && 2 * C::CT * 4 <= C::W3_BYTES, "the table is one DMA piece");
+        if (wave == 0 && lane < 2 * (C::CT / 4)) {
+            const unsigned int l = opaque((unsigned int)lane);
+            const float* src = (l < C::CT / 4 ? inv3 : p.b3 - C::CT) + (int64_t)j * C::CT + (size_t)(l * 4u);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w3buf + buf * C::W3_BYTES), 16, 0, 0);
+        }
+    };
+    // conv1's own (1 / scale, bias): MID + MID floats into the (by then idle) x buffer, requested in the very last stage
+    auto dma_tail_tab = [&]() __attribute__((always_inline)) {
+        constexpr int PIECES = (2 * C::MID + 255) / 256;
+        if (wave < PIECES) {
+            const unsigned int f0 = (unsigned int)wave * 256u + opaque((unsigned int)lane) * 4u;
+            if (f0 < 2u * C::MID) {
+                const float* src = (f0 < (unsigned int)C::MID ? inv1 : p.b1 - C::MID) + (size_t)f0;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xbuf + wave * 1024), 16, 0, 0);
             }
         }
     };
     auto stage_sync = [&]() __attribute__((always_inline)) {
         // vmcnt(0): this wave's DMA pieces (and loads / stores) have landed.  The BUILTIN, not inline assembly: the compiler's wait-count
-        // pass must see it, or it guards the first use of a residual value loaded a stage earlier with a vmcnt(0) of its own -- behind the
-        // DMA just issued for the next stage
+        // pass must see it, or it guards the first use of a value loaded a stage earlier with a vmcnt(0) of its own -- behind the DMA
+        // just issued for the next stage
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
+    };
+    auto load_identity = [&](const int co_first, float (&rres)[16]) __attribute__((always_inline)) {   // rows of the 32-channel tile at co_first, this lane's column
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#if SS_FT_PROBE == 1
+            rres[r] = 0.f;
+#else
+            rres[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res + (int64_t)(co_first + (r & 3) + 8 * (r >> 2)) * V) + (size_t)lane_off);
+#endif
     };
 
     f32x16 acc1[C::MI1];
@@ -157,25 +213,28 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedT
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[m][r] = 0.f;
 
-    const float* inv3 = reinterpret_cast<const float*>(p.w3 + (int64_t)C::NC3 * 8 * C::COUT * 16);
-    const float* inv1 = reinterpret_cast<const float*>(p.w1 + (int64_t)(C::COUT / 32) * 8 * C::MID * 16);
     const f16x8 k2048 = {(_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f),
                          (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f)};
 
     // three products per (A, B) fragment pair, smallest first -- the order of conv_igemm.hip's f16x3 stream
     auto mma3 = [&](f32x16& acc, const f16x8 a_hi, const f16x8 a_lo, const f16x8 b_hi, const f16x8 b_lo) __attribute__((always_inline)) {
         const f16x8 a_his = a_hi * k2048;                    // hi_w * 2^-11 (exact: a power of two on a normal number)
+#if SS_FT_PROBE == 3
+        asm volatile("" ::"v"(a_his), "v"(a_lo), "v"(b_hi), "v"(b_lo));
+        return;
+#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_his, b_lo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc, 0, 0, 0);
     };
 
+#if SS_FT_STAGGER > 0
+    for (int i = 0; i < (int)(blockIdx.x % 16) * SS_FT_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     dma_x(0, 0);
     dma_w3(0, 0, 0);
-    for (int i = tid; i < C::COUT; i += C::NTHREADS) { tab[i] = inv3[i]; tab[C::COUT + i] = p.b3[i]; }
-    for (int i = tid; i < C::MID; i += C::NTHREADS) { tab[2 * C::COUT + i] = inv1[i]; tab[2 * C::COUT + C::MID + i] = p.b1[i]; }
     stage_sync();
-    int sb = 0;                                              // buffer of the conv3 sub-stage about to run
+    int sb = 0;                                              // x / w3 buffer of the conv3 sub-stage about to run
 #pragma unroll 1
     for (int j = 0; j < C::NCT; ++j) {
         f32x16 acc3[C::MI3];
@@ -184,18 +243,11 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedT
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[m][r] = 0.f;
         const int co_j = j * C::CT;
-        float rres[16];                                      // identity values of the co-tile's first 32-channel tile (loaded in the last sub-stage)
+        float rres[16];                                      // identity values of the 32-channel tile whose epilogue comes next
 #pragma unroll 1
         for (int c = 0; c < C::NC3; ++c) {
-            // prefetch: the next conv3 sub-stage (this co-tile's, or the next co-tile's first) and this co-tile's w1 share
             if (c + 1 < C::NC3) { dma_x(c + 1, sb ^ 1); dma_w3(j, c + 1, sb ^ 1); }
-            else if (j + 1 < C::NCT) { dma_x(0, sb ^ 1); dma_w3(j + 1, 0, sb ^ 1); }     // (it waits in its buffer through the epilogue stage)
-            dma_w1(j, c);
-            if (c == C::NC3 - 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rres[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res + (int64_t)(co_j + (r & 3) + 8 * (r >> 2)) * V) + (size_t)lane_off);
-            }
+            else { dma_w1(j, 0, 0); dma_tab(j, sb ^ 1); load_identity(co_j, rres); }
             const char* xb = xbuf + sb * C::X_BYTES + (half * C::P + wave * 32 + l31) * 16;
             const char* wb = w3buf + sb * C::W3_BYTES + (half * C::CT + l31) * 16;
             // software pipeline over the (k-group, 32-row tile) steps: the A fragments of step s + 1 are requested before the MFMAs of step s
@@ -224,82 +276,81 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedT
             stage_sync();
             sb ^= 1;
         }
-        // ---- epilogue of the co-tile + its K-chunks of conv1 -------------------------------------------------------------------------
-        // (no DMA is issued in this stage: the compiler guards the first LDS read behind an LDS-DMA it cannot tell apart from the read's
-        // target with a vmcnt(0) -- the next co-tile's first chunk was requested in the last sub-stage above)
+        // ---- epilogue of the co-tile + its K-halves of conv1 ---------------------------------------------------------------------------
+        f16x8 b_hi[2], b_lo[2];                              // the two k-groups of the current 32-channel tile as B fragments
 #pragma unroll
-        for (int m = 0; m < C::MI3; ++m) {
-            const int co_m = co_j + m * 32;
-            // scale back, + bias, + identity, ReLU, store; C/D layout: register r of lane (half, l31) = row (r & 3) + 8 (r >> 2) + 4 half
-            unsigned int hw[8], lw[8];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int h = 0; h < C::NH; ++h) {
+            const int m = h >> 1, g = h & 1;
+            if (g == 0) {
+                const int co_m = co_j + m * 32;
+                // scale back, + bias, + identity, ReLU, store; C/D layout: register r of lane (half, l31) = row (r & 3) + 8 (r >> 2) + 4 half
+                unsigned int hw[8], lw[8];
+                const float* tab = reinterpret_cast<const float*>(w3buf + sb * C::W3_BYTES);      // (dma_tab: requested in the last conv3 sub-stage)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co4 = co_m + 8 * q + 4 * half;
-                const float4 sc = *reinterpret_cast<const float4*>(tab + co4);
-                const float4 bv = *reinterpret_cast<const float4*>(tab + C::COUT + co4);
-                // (explicitly rounded steps: the standalone kernel scales its accumulators in one place and adds bias / identity in another -- no
-                // multiply-add contraction there, none here)
-                float v0 = __fmul_rn(acc3[m][4 * q + 0], sc.x), v1 = __fmul_rn(acc3[m][4 * q + 1], sc.y), v2 = __fmul_rn(acc3[m][4 * q + 2], sc.z),
-                      v3 = __fmul_rn(acc3[m][4 * q + 3], sc.w);
-                v0 = relu_keep_nan(__fadd_rn(__fadd_rn(v0, bv.x), rres[4 * q + 0]));
-                v1 = relu_keep_nan(__fadd_rn(__fadd_rn(v1, bv.y), rres[4 * q + 1]));
-                v2 = relu_keep_nan(__fadd_rn(__fadd_rn(v2, bv.z), rres[4 * q + 2]));
-                v3 = relu_keep_nan(__fadd_rn(__fadd_rn(v3, bv.w), rres[4 * q + 3]));
-                if (pos_ok) {
-                    char* yo = reinterpret_cast<char*>(p.y + (int64_t)(co_m + 8 * q) * V);       // (uniform; the 4 half rows are in lane_off)
-                    *reinterpret_cast<float*>(yo + (size_t)lane_off) = v0;
-                    *reinterpret_cast<float*>(yo + V * 4 + (size_t)lane_off) = v1;
-                    *reinterpret_cast<float*>(yo + V * 8 + (size_t)lane_off) = v2;
-                    *reinterpret_cast<float*>(yo + V * 12 + (size_t)lane_off) = v3;
+                for (int q = 0; q < 4; ++q) {
+                    const int co4 = co_m + 8 * q + 4 * half;
+                    const float4 sc = *reinterpret_cast<const float4*>(tab + (co4 - co_j));
+                    const float4 bv = *reinterpret_cast<const float4*>(tab + C::CT + (co4 - co_j));
+                    // (explicitly rounded steps: the standalone kernel scales its accumulators in one place and adds bias / identity in another)
+                    float v0 = __fmul_rn(acc3[m][4 * q + 0], sc.x), v1 = __fmul_rn(acc3[m][4 * q + 1], sc.y), v2 = __fmul_rn(acc3[m][4 * q + 2], sc.z),
+                          v3 = __fmul_rn(acc3[m][4 * q + 3], sc.w);
+                    v0 = relu_keep_nan(__fadd_rn(__fadd_rn(v0, bv.x), rres[4 * q + 0]));
+                    v1 = relu_keep_nan(__fadd_rn(__fadd_rn(v1, bv.y), rres[4 * q + 1]));
+                    v2 = relu_keep_nan(__fadd_rn(__fadd_rn(v2, bv.z), rres[4 * q + 2]));
+                    v3 = relu_keep_nan(__fadd_rn(__fadd_rn(v3, bv.w), rres[4 * q + 3]));
+                    if (pos_ok && SS_FT_PROBE != 1) {
+                        char* yo = reinterpret_cast<char*>(p.y + (int64_t)(co_m + 8 * q) * V);       // (uniform; the 4 half rows are in lane_off)
+                        *reinterpret_cast<float*>(yo + (size_t)lane_off) = v0;
+                        *reinterpret_cast<float*>(yo + V * 4 + (size_t)lane_off) = v1;
+                        *reinterpret_cast<float*>(yo + V * 8 + (size_t)lane_off) = v2;
+                        *reinterpret_cast<float*>(yo + V * 12 + (size_t)lane_off) = v3;
+                    }
+                    ft_split_pair(v0, v1, hw[2 * q], lw[2 * q]);
+                    ft_split_pair(v2, v3, hw[2 * q + 1], lw[2 * q + 1]);
                 }
-                ft_split_pair(v0, v1, hw[2 * q], lw[2 * q]);
-                ft_split_pair(v2, v3, hw[2 * q + 1], lw[2 * q + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // identity values of the NEXT 32-channel tile of this co-tile: they land under this tile's conv1 MFMAs
-            if (m + 1 < C::MI3) {
+                __builtin_amdgcn_sched_barrier(0);
+                // k-groups of 16 channels in the standalone kernel's order: lane half 0 channels 0..7, half 1 channels 8..15 of the group.  The
+                // lane halves hold (q even: ch 0-3 | 4-7), (q odd: 8-11 | 12-15): swapping the upper half of the q-even words with the lower half
+                // of the q-odd words gives (0-3, 4-7) to half 0 and (8-11, 12-15) to half 1.
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    rres[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res + (int64_t)(co_m + 32 + (r & 3) + 8 * (r >> 2)) * V) + (size_t)lane_off);
-            }
-            // k-groups of 16 channels in the standalone kernel's order: lane half 0 channels 0..7, half 1 channels 8..15 of the group.  The lane
-            // halves hold (q even: ch 0-3 | 4-7), (q odd: 8-11 | 12-15): swapping the upper half of the q-even words with the lower half of the
-            // q-odd words gives (0-3, 4-7) to half 0 and (8-11, 12-15) to half 1.
-            __builtin_amdgcn_sched_barrier(0);
-            const char* w1b = w1buf + m * C::W1_CHUNK + (half * C::MID + l31) * 16;
-            f16x8 b_hi[2], b_lo[2];
+                for (int gg = 0; gg < 2; ++gg) {
+                    unsigned int xh[2], yh[2], xl[2], yl[2];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                unsigned int xh[2], yh[2], xl[2], yl[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    auto sh = __builtin_amdgcn_permlane32_swap(hw[4 * g + i], hw[4 * g + 2 + i], false, false);
-                    xh[i] = sh[0]; yh[i] = sh[1];
-                    auto sl = __builtin_amdgcn_permlane32_swap(lw[4 * g + i], lw[4 * g + 2 + i], false, false);
-                    xl[i] = sl[0]; yl[i] = sl[1];
+                    for (int i = 0; i < 2; ++i) {
+                        auto sh = __builtin_amdgcn_permlane32_swap(hw[4 * gg + i], hw[4 * gg + 2 + i], false, false);
+                        xh[i] = sh[0]; yh[i] = sh[1];
+                        auto sl = __builtin_amdgcn_permlane32_swap(lw[4 * gg + i], lw[4 * gg + 2 + i], false, false);
+                        xl[i] = sl[0]; yl[i] = sl[1];
+                    }
+                    const u32x4 bh = {xh[0], xh[1], yh[0], yh[1]}, bl = {xl[0], xl[1], yl[0], yl[1]};
+                    b_hi[gg] = __builtin_bit_cast(f16x8, bh);
+                    b_lo[gg] = __builtin_bit_cast(f16x8, bl);
                 }
-                const u32x4 bh = {xh[0], xh[1], yh[0], yh[1]}, bl = {xl[0], xl[1], yl[0], yl[1]};
-                b_hi[g] = __builtin_bit_cast(f16x8, bh);
-                b_lo[g] = __builtin_bit_cast(f16x8, bl);
+            } else if (m + 1 < C::MI3) {
+                load_identity(co_j + (m + 1) * 32, rres);        // (they land under this k-group's MFMAs)
             }
-            constexpr int NS1 = 2 * C::MI1;
+            __builtin_amdgcn_sched_barrier(0);
+            // what the next stage reads (requested behind the epilogue: its table reads are LDS reads the compiler cannot tell from the DMA's target)
+            if (h + 1 < C::NH) dma_w1(j, h + 1, (h + 1) & 1);
+            else if (j + 1 < C::NCT) { dma_x(0, sb); dma_w3(j + 1, 0, sb); }
+            else dma_tail_tab();
+            const char* w1b = w1buf + (h & 1) * C::W1_HALF + (half * C::MID + l31) * 16;
             f16x8 a_hi[2], a_lo[2];
-            auto ld_a1 = [&](const int st, const int k) __attribute__((always_inline)) {
-                const int g = st / C::MI1, m1 = st % C::MI1;
-                a_hi[k] = *reinterpret_cast<const f16x8*>(w1b + (((g * 2 + 0) * 2) * C::MID + m1 * 32) * 16);
-                a_lo[k] = *reinterpret_cast<const f16x8*>(w1b + (((g * 2 + 1) * 2) * C::MID + m1 * 32) * 16);
+            auto ld_a1 = [&](const int m1, const int k) __attribute__((always_inline)) {
+                a_hi[k] = *reinterpret_cast<const f16x8*>(w1b + ((0 * 2) * C::MID + m1 * 32) * 16);
+                a_lo[k] = *reinterpret_cast<const f16x8*>(w1b + ((1 * 2) * C::MID + m1 * 32) * 16);
             };
             ld_a1(0, 0);
 #pragma unroll
-            for (int st = 0; st < NS1; ++st) {
-                if (st + 1 < NS1) ld_a1(st + 1, (st + 1) & 1);
+            for (int m1 = 0; m1 < C::MI1; ++m1) {
+                if (m1 + 1 < C::MI1) ld_a1(m1 + 1, (m1 + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
-                mma3(acc1[st % C::MI1], a_hi[st & 1], a_lo[st & 1], b_hi[st / C::MI1], b_lo[st / C::MI1]);
+                mma3(acc1[m1], a_hi[m1 & 1], a_lo[m1 & 1], b_hi[g], b_lo[g]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            stage_sync();
         }
-        stage_sync();
     }
     // ---- conv1's epilogue: scale back, + bias, ReLU, flat position -> (t, y, x) of the zero-haloed consumer layout -------------------------
     if (pos_ok) {
@@ -311,26 +362,23 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedT
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int co4 = m1 * 32 + 8 * q + 4 * half;
-                const float4 sc = *reinterpret_cast<const float4*>(tab + 2 * C::COUT + co4);
-                const float4 bv = *reinterpret_cast<const float4*>(tab + 2 * C::COUT + C::MID + co4);
+                const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xbuf) + co4);
+                const float4 bv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xbuf) + C::MID + co4);
                 char* zo = reinterpret_cast<char*>(p.z + (int64_t)(m1 * 32 + 8 * q) * p.z_cs);     // (uniform)
                 *reinterpret_cast<float*>(zo + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 0], sc.x), bv.x));
                 *reinterpret_cast<float*>(zo + p.z_cs * 4 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 1], sc.y), bv.y));
                 *reinterpret_cast<float*>(zo + p.z_cs * 8 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 2], sc.z), bv.z));
                 *reinterpret_cast<float*>(zo + p.z_cs * 12 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 3], sc.w), bv.w));
-                __builtin_amdgcn_sched_barrier(0);
             }
     }
 }
 
-// workgroups the fused kernel makes of V positions (the planning twin of the launch: 256 positions each)
-static int64_t fused_tail_workgroups(int64_t V) { return ceil_div(V, 256); }
 
 template <class C>
 static int launch_fused_cfg(const FusedTailParams& p, hipStream_t s) {
     const double flops = 2.0 * 2.0 * (double)C::MID * C::COUT * (double)p.V;        // both GEMMs
     void* ev = profile_begin(19, flops, s);
-    hipLaunchKernelGGL(fused_tail_kernel<C>, dim3((unsigned)fused_tail_workgroups(p.V)), dim3(C::NTHREADS), 0, s, p);
+    hipLaunchKernelGGL(fused_tail_kernel<C>, dim3((unsigned)ceil_div(p.V, C::P)), dim3(C::NTHREADS), 0, s, p);
     profile_end(ev, s);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
@@ -357,9 +405,15 @@ int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const f
     p.w1 = reinterpret_cast<const char*>(w1); p.b1 = b1;
     p.z = z.ptr; p.z_cs = z.c_stride; p.z_ts = z.t_stride; p.z_ys = z.y_stride; p.dec_H = dec_H; p.dec_W = dec_W;
     p.V = (int)V;
-    if (mid == 256) return launch_fused_cfg<FusedTailCfg<256, 64>>(p, s);
-    if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64>>(p, s);
-    return launch_fused_cfg<FusedTailCfg<64, 64>>(p, s);
+#if defined(SS_EXPERIMENTS) && defined(SS_FT_P256)
+    if (mid == 256) return launch_fused_cfg<FusedTailCfg<256, 64, 256>>(p, s);
+    if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64, 256>>(p, s);
+    return launch_fused_cfg<FusedTailCfg<64, 64, 256>>(p, s);
+#else
+    if (mid == 256) return launch_fused_cfg<FusedTailCfg<256, 64, 128>>(p, s);
+    if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64, 128>>(p, s);
+    return launch_fused_cfg<FusedTailCfg<64, 64, 128>>(p, s);
+#endif
 }
 
 }  // namespace stemseg

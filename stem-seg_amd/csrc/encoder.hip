@@ -632,7 +632,7 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             // Fused tail (f16x3): conv3 of this block and conv1 of the next in one back-to-back kernel.  conv2 then writes its output as the
             // fp16 operand planes that kernel stages by LDS-DMA (same bytes, the M2 buffer) -- unless its plan splits K, in which case it
             // says so and the block runs its three launches (a function of the planning shape: the same choice for every batch).
-            const bool want_fuse = desc->fuse_tail && prec == STEMSEG_PRECISION_F16X3 && b + 1 < p.nblk[st] && fused_tail_supported(mid) && V <= (1ll << 27) && (int64_t)T * (h + 2) * (w + 4) <= (1ll << 27);
+            const bool want_fuse = ((desc->fuse_tail >> st) & 1) && prec == STEMSEG_PRECISION_F16X3 && b + 1 < p.nblk[st] && fused_tail_supported(mid) && V <= (1ll << 27) && (int64_t)T * (h + 2) * (w + 4) <= (1ll << 27);
             int p16_done = 0;
             ConvEpilogue e2 = epi_for(T);       // conv2 (3x3) + bn2 + relu -> dense
             e2.relu = 1;

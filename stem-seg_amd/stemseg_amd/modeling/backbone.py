@@ -111,7 +111,8 @@ class ResNetFPN(nn.Module):
         # its own frame count (fastest for a lone small pass; results then depend on the batch).
         self.plan_frames = 32
         # f16x3: conv3 (+ identity + ReLU) of a bottleneck block and conv1 of the next in one back-to-back kernel (StemsegEncoderDesc.fuse_tail):
-        # bit-identical to the separate launches wherever those run un-split; False: three launches per block (A/B, tests)
+        # bit-identical to the separate launches wherever those run un-split; True / 7: stages 1-3, a bit mask (1, 2, 4) picks stages,
+        # False / 0: three launches per block everywhere (A/B, tests)
         self.fuse_tail = True
         self.stem_s2d = True             # f16x3 mode: the stem as space-to-depth + 4x4 conv on the split-staged MFMA kernel (False: the exact fp32-MFMA stem; A/B)
 
@@ -199,7 +200,7 @@ class ResNetFPN(nn.Module):
         d.precision = hip.PRECISIONS[self.precision]
         d.n_clips, d.clip_frames, d.clip_stride = n_clips, clip_frames, clip_stride
         d.plan_frames = int(self.plan_frames)
-        d.fuse_tail = int(bool(self.fuse_tail))
+        d.fuse_tail = 7 if self.fuse_tail is True else int(self.fuse_tail)      # (bit s - 1: stage s)
         return d
 
     @torch.no_grad()
