@@ -374,6 +374,281 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail_kernel(const FusedT
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 16-column form (MID = 256: layer 3, 22 of the 27 fused launches of an R-101 pass).  What bounds the 32-column form there is not its
+// matrix work but its memory-side traffic (profiles/r06e_pmc_fused_tail_256_p128.txt: FETCH + WRITE 1.5 GB per launch against 0.53 GB of
+// tensors): conv3's input tile -- 1 KB per position -- is re-read once per co-tile, 16 times, and with every position of the map in flight
+// at once those re-reads can only come from the Infinity Cache.  It cannot stay in LDS next to the weight streams (128 KB for 128 positions),
+// and as B fragments of 32 positions it is 128 registers beside 160 of accumulators.  With v_mfma_f32_16x16x32_f16 a wave owns 16 positions:
+// conv1's accumulators are 64 registers, a 128-channel co-tile's 32, and the wave's WHOLE conv3 input -- 256 channels x 16 positions as
+// fp16 pairs -- is 64 registers, loaded once.  LDS then holds weights only (two conv3 chunks and one conv1 k-step per stage, double
+// buffered: 128 KB), a stage is 48 MFMAs per wave, and the kernel's traffic is its tensors'.
+//   * one MFMA consumes a whole 32-channel chunk (k = 32): lane (n, kb) carries channels 8 kb .. 8 kb + 7 of the chunk -- for conv3 exactly the
+//     packed weights' (k-group kb / 2, half kb % 2) vector and the producer's octet 4 s + kb;
+//   * C/D layout: lane (n, rb) holds rows 4 rb .. 4 rb + 3 of a 16-row tile.  Two consecutive tiles (32 channels) of the finished co-tile become
+//     conv1's next B fragment -- lane (n, kb): channels 8 kb .. 8 kb + 7, the packed w1's own order -- by one v_permlane32_swap and one
+//     v_permlane16_swap per word.  (Leaving the rows where they are and fetching the matching A fragment as two 8-byte halves was measured first:
+//     the compiler fuses the halves into ds_read2_b64, whose 16-lane groups hit 32 banks at a 16-byte stride -- 39 % of the LDS cycles were
+//     bank conflicts, profiles/r06f_pmc_fused_tail16_first.txt.)
+// The summation order inside an MFMA differs from the 32x32x16 kernels' (32 channels per instruction instead of two groups of 16), so this
+// form agrees with the separate launches to fp32 round-off, not bit for bit; like every kernel here it has ONE summation order whatever the
+// batch (no split-K, no dependence on the launch shape).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MID_>
+struct FusedTail16Cfg {
+    static constexpr int MID = MID_, COUT = 4 * MID_, CT = 128;
+    static constexpr int NW = 8, NTHREADS = 512, P = 16 * NW;
+    static constexpr int NC3 = MID / 32, NCT = COUT / CT;
+    static constexpr int NT3 = CT / 16, NT1 = MID / 16;     // 16-row accumulator tiles: conv3 co-tile, conv1
+    static constexpr int SC = 2;                            // conv3 chunks per stage
+    static constexpr int NS = NC3 / SC, NU = CT / 32;       // conv3 stages / conv1 k-steps per co-tile
+    static constexpr int W3_CHUNK = 8 * CT * 16;            // [grp][plane][half][CT][16 B]
+    static constexpr int W3_BYTES = SC * W3_CHUNK;
+    static constexpr int W1_BYTES = 8 * MID * 16;           // one 32-channel k-step of conv1: [grp][plane][half][MID][16 B]
+    static constexpr int TAB_BYTES = 2 * CT * 4;
+    static constexpr int LDS_BYTES = 2 * W3_BYTES + 2 * W1_BYTES + 2 * TAB_BYTES;
+    static_assert(NC3 % SC == 0 && W3_BYTES % (1024 * NW) == 0 && W1_BYTES % (1024 * NW) == 0 && TAB_BYTES == 1024, "whole DMA pieces per wave");
+    static_assert(LDS_BYTES <= 160 * 1024 && 2 * MID * 4 <= W3_BYTES, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail16_kernel(const FusedTailParams p) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];
+    char* const w3buf = smem;
+    char* const w1buf = smem + 2 * C::W3_BYTES;
+    char* const tabbuf = smem + 2 * C::W3_BYTES + 2 * C::W1_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kb = lane >> 4;                 // column (position) of the wave's 16 / k-block (inputs) = row-block (accumulators)
+    const int pos = blockIdx.x * C::P + wave * 16 + n;
+    const bool pos_ok = pos < p.V;
+    const int pos_c = min(pos, p.V - 1);
+    const int64_t V = p.V;
+    const unsigned int lane_off = (unsigned int)(((int64_t)(4 * kb) * V + pos_c) * 4);       // bytes: rows 4 kb .. of a tile, this lane's column
+    auto opaque = [](unsigned int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* inv3 = reinterpret_cast<const float*>(p.w3 + (int64_t)C::NC3 * 8 * C::COUT * 16);
+    const float* inv1 = reinterpret_cast<const float*>(p.w1 + (int64_t)(C::COUT / 32) * 8 * C::MID * 16);
+
+    auto dma_w3 = [&](const int j, const int st, const int buf) __attribute__((always_inline)) {      // chunks SC st .. of co-tile j
+        constexpr int PER_ROW = C::CT * 16 / 1024, PER_CHUNK = C::W3_CHUNK / 1024;
+#pragma unroll
+        for (int k = 0; k < C::W3_BYTES / 1024 / C::NW; ++k) {
+            const int idx = wave + k * C::NW, sc = idx / PER_CHUNK, r = idx % PER_CHUNK, row = r / PER_ROW, part = r % PER_ROW;
+            const char* src = p.w3 + ((int64_t)(st * C::SC + sc) * 8 + row) * (C::COUT * 16) + (int64_t)j * (C::CT * 16) + part * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w3buf + buf * C::W3_BYTES + idx * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_w1 = [&](const int cc, const int buf) __attribute__((always_inline)) {                   // conv1 k-step (32-channel chunk) cc
+#pragma unroll
+        for (int k = 0; k < C::W1_BYTES / 1024 / C::NW; ++k) {
+            const int idx = wave + k * C::NW;
+            const char* src = p.w1 + (int64_t)cc * C::W1_BYTES + (int64_t)idx * 1024 + (size_t)(opaque((unsigned int)lane) * 16u);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w1buf + buf * C::W1_BYTES + idx * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_tab = [&](const int j) __attribute__((always_inline)) {        // co-tile j's (1 / scale | bias): lanes 0-31 scales, 32-63 biases
+        if (wave == 0) {
+            const unsigned int l = opaque((unsigned int)lane);
+            const float* src = (l < 32 ? inv3 : p.b3 - C::CT) + (int64_t)j * C::CT + (size_t)(l * 4u);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tabbuf + (j & 1) * C::TAB_BYTES), 16, 0, 0);
+        }
+    };
+    auto dma_tail_tab = [&]() __attribute__((always_inline)) {            // conv1's own (1 / scale | bias) into the idle w3 buffer
+        constexpr int PIECES = (2 * C::MID + 255) / 256;
+        if (wave < PIECES) {
+            const unsigned int f0 = (unsigned int)wave * 256u + opaque((unsigned int)lane) * 4u;
+            if (f0 < 2u * C::MID) {
+                const float* src = (f0 < (unsigned int)C::MID ? inv1 : p.b1 - C::MID) + (size_t)f0;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(w3buf + wave * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0), as a builtin: see fused_tail_kernel
+        __syncthreads();
+    };
+    auto load_identity = [&](const int co_first, float (&rres)[8]) __attribute__((always_inline)) {    // two 16-row tiles from co_first: rows 4 kb + r
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#if SS_FT_PROBE == 1
+            rres[i] = 0.f;
+#else
+            rres[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.res + (int64_t)(co_first + 16 * (i >> 2) + (i & 3)) * V) + (size_t)lane_off);
+#endif
+    };
+    const f16x8 k2048 = {(_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f),
+                         (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f)};
+    // two 16-row tiles per step, their MFMAs alternating: consecutive MFMAs never wait for each other's accumulator (same products, same order
+    // per accumulator as mma3)
+    auto mma3x2 = [&](f32x4& c0, f32x4& c1, const f16x8 a0_hi, const f16x8 a0_lo, const f16x8 a1_hi, const f16x8 a1_lo, const f16x8 b_hi, const f16x8 b_lo)
+        __attribute__((always_inline)) {
+        const f16x8 a0_his = a0_hi * k2048, a1_his = a1_hi * k2048;
+#if SS_FT_PROBE == 3
+        asm volatile("" ::"v"(a0_his), "v"(a0_lo), "v"(a1_his), "v"(a1_lo), "v"(b_hi), "v"(b_lo));
+        return;
+#endif
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0_lo, b_hi, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1_lo, b_hi, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0_his, b_lo, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1_his, b_lo, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0_hi, b_hi, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1_hi, b_hi, c1, 0, 0, 0);
+    };
+
+    // the first stage's weights, then the wave's whole conv3 input: chunk s, lane (n, kb) = octet 4 s + kb of both planes at its position
+    dma_w3(0, 0, 0);
+    f16x8 xh[C::NC3], xl[C::NC3];
+    {
+        const char* xs = reinterpret_cast<const char*>(p.x16) + (size_t)((unsigned int)pos_c * 16u);
+#pragma unroll
+        for (int s = 0; s < C::NC3; ++s) {
+            xh[s] = *reinterpret_cast<const f16x8*>(xs + ((int64_t)(4 * s + kb)) * V * 16);
+            xl[s] = *reinterpret_cast<const f16x8*>(xs + ((int64_t)(C::MID / 8 + 4 * s + kb)) * V * 16);
+        }
+    }
+    f32x4 acc1[C::NT1];
+#pragma unroll
+    for (int m = 0; m < C::NT1; ++m) acc1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage_sync();
+    int sb = 0, eb = 0;                                      // buffers of the conv3 stage / the conv1 k-step about to run
+#pragma unroll 1
+    for (int j = 0; j < C::NCT; ++j) {
+        f32x4 acc3[C::NT3];
+#pragma unroll
+        for (int t = 0; t < C::NT3; ++t) acc3[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int co_j = j * C::CT;
+        float rres[8];
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+            if (st + 1 < C::NS) dma_w3(j, st + 1, sb ^ 1);
+            else { dma_w1(j * C::NU, eb); dma_tab(j); load_identity(co_j, rres); }
+            const char* wb = w3buf + sb * C::W3_BYTES + (((kb >> 1) * 2 * 2 + (kb & 1)) * C::CT + n) * 16;       // row (g = kb / 2, plane 0, h = kb % 2), this lane's tile row
+            constexpr int NSTEP = C::SC * C::NT3 / 2;            // steps of two tiles
+            f16x8 a_hi[2][2], a_lo[2][2];                       // (two sets here: the fragments of step i + 1 are requested before the MFMAs of step i issue)
+            auto ld_a = [&](const int i, const int k) __attribute__((always_inline)) {
+                const int sc = (2 * i) / C::NT3, t = (2 * i) % C::NT3;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a_hi[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (0 * 2 * C::CT + (t + e) * 16) * 16);
+                    a_lo[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (1 * 2 * C::CT + (t + e) * 16) * 16);
+                }
+            };
+            ld_a(0, 0);
+#pragma unroll
+            for (int i = 0; i < NSTEP; ++i) {
+                if (i + 1 < NSTEP) ld_a(i + 1, (i + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int t = (2 * i) % C::NT3, ch = st * C::SC + (2 * i) / C::NT3;
+                mma3x2(acc3[t], acc3[t + 1], a_hi[i & 1][0], a_lo[i & 1][0], a_hi[i & 1][1], a_lo[i & 1][1], xh[ch], xl[ch]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stage_sync();
+            sb ^= 1;
+        }
+        const float* tab = reinterpret_cast<const float*>(tabbuf + (j & 1) * C::TAB_BYTES);
+#pragma unroll
+        for (int u = 0; u < C::NU; ++u) {
+            // ---- tiles 2 u, 2 u + 1 of the co-tile: scale back, + bias, + identity, ReLU, store, split: conv1's B fragment of k-step u -----------
+            unsigned int hw[4], lw[4];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * u + tt, co4 = 16 * t + 4 * kb;                      // (within the co-tile)
+                const float4 sc = *reinterpret_cast<const float4*>(tab + co4);
+                const float4 bv = *reinterpret_cast<const float4*>(tab + C::CT + co4);
+                float v0 = __fmul_rn(acc3[t][0], sc.x), v1 = __fmul_rn(acc3[t][1], sc.y), v2 = __fmul_rn(acc3[t][2], sc.z), v3 = __fmul_rn(acc3[t][3], sc.w);
+                v0 = relu_keep_nan(__fadd_rn(__fadd_rn(v0, bv.x), rres[4 * tt + 0]));
+                v1 = relu_keep_nan(__fadd_rn(__fadd_rn(v1, bv.y), rres[4 * tt + 1]));
+                v2 = relu_keep_nan(__fadd_rn(__fadd_rn(v2, bv.z), rres[4 * tt + 2]));
+                v3 = relu_keep_nan(__fadd_rn(__fadd_rn(v3, bv.w), rres[4 * tt + 3]));
+                if (pos_ok && SS_FT_PROBE != 1) {
+                    char* yo = reinterpret_cast<char*>(p.y + (int64_t)(co_j + 16 * t) * V);       // (uniform; rows 4 kb .. are in lane_off)
+                    *reinterpret_cast<float*>(yo + (size_t)lane_off) = v0;
+                    *reinterpret_cast<float*>(yo + V * 4 + (size_t)lane_off) = v1;
+                    *reinterpret_cast<float*>(yo + V * 8 + (size_t)lane_off) = v2;
+                    *reinterpret_cast<float*>(yo + V * 12 + (size_t)lane_off) = v3;
+                }
+                ft_split_pair(v0, v1, hw[2 * tt], lw[2 * tt]);
+                ft_split_pair(v2, v3, hw[2 * tt + 1], lw[2 * tt + 1]);
+            }
+            // The lane (n, rb) holds rows 4 rb + 0..3 of both tiles; conv1's k slots of lane (n, kb) are channels 8 kb + 0..7 of the 32 (the packed
+            // weights' order: one conflict-free 16-byte read per fragment).  Two half / row exchanges per word move them: after permlane32_swap the
+            // row blocks hold (T0 rb0, T0 rb1, T1 rb0, T1 rb1) | (T0 rb2, T0 rb3, T1 rb2, T1 rb3), after permlane16_swap (T0 rb0, T0 rb2, T1 rb0, T1 rb2) |
+            // (T0 rb1, T0 rb3, T1 rb1, T1 rb3): row block kb now has (8 kb + 0..3 | 8 kb + 4..7).
+            unsigned int bw[2][4];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned int t0 = pl ? lw[i] : hw[i], t1 = pl ? lw[2 + i] : hw[2 + i];
+                    auto s32 = __builtin_amdgcn_permlane32_swap(t0, t1, false, false);
+                    auto s16 = __builtin_amdgcn_permlane16_swap(s32[0], s32[1], false, false);
+                    bw[pl][i] = s16[0];
+                    bw[pl][2 + i] = s16[1];
+                }
+            const u32x4 bh = {bw[0][0], bw[0][1], bw[0][2], bw[0][3]}, bl = {bw[1][0], bw[1][1], bw[1][2], bw[1][3]};
+            const f16x8 b_hi = __builtin_bit_cast(f16x8, bh), b_lo = __builtin_bit_cast(f16x8, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < C::NU) { dma_w1(j * C::NU + u + 1, eb ^ 1); load_identity(co_j + 32 * (u + 1), rres); }
+            else if (j + 1 < C::NCT) dma_w3(j + 1, 0, sb);
+            else dma_tail_tab();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- conv1, k-step u ------------------------------------------------------------------------------------------------------------
+            const char* w1b = w1buf + eb * C::W1_BYTES + (((kb >> 1) * 2 * 2 + (kb & 1)) * C::MID + n) * 16;      // row (g = kb / 2, plane 0, h = kb % 2)
+            f16x8 a_hi[1][2], a_lo[1][2];
+            auto ld_a1 = [&](const int i, const int k) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a_hi[k][e] = *reinterpret_cast<const f16x8*>(w1b + (0 * 2 * C::MID + (2 * i + e) * 16) * 16);
+                    a_lo[k][e] = *reinterpret_cast<const f16x8*>(w1b + (1 * 2 * C::MID + (2 * i + e) * 16) * 16);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < C::NT1 / 2; ++i) {
+                ld_a1(i, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma3x2(acc1[2 * i], acc1[2 * i + 1], a_hi[0][0], a_lo[0][0], a_hi[0][1], a_lo[0][1], b_hi, b_lo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stage_sync();
+            eb ^= 1;
+        }
+    }
+    // ---- conv1's epilogue ------------------------------------------------------------------------------------------------------------------
+    if (pos_ok) {
+        const int hwp = p.dec_H * p.dec_W;
+        const int t2 = pos / hwp, r2 = pos - t2 * hwp, y2 = r2 / p.dec_W, x2 = r2 - y2 * p.dec_W;
+        const unsigned int z_off = (unsigned int)(((int64_t)(4 * kb) * p.z_cs + (int64_t)t2 * p.z_ts + (int64_t)y2 * p.z_ys + x2) * 4);      // bytes
+        const float* ttab = reinterpret_cast<const float*>(w3buf);
+#pragma unroll
+        for (int m1 = 0; m1 < C::NT1; ++m1) {
+            const int co4 = m1 * 16 + 4 * kb;
+            const float4 sc = *reinterpret_cast<const float4*>(ttab + co4);
+            const float4 bv = *reinterpret_cast<const float4*>(ttab + C::MID + co4);
+            char* zo = reinterpret_cast<char*>(p.z + (int64_t)(m1 * 16) * p.z_cs);     // (uniform)
+            *reinterpret_cast<float*>(zo + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][0], sc.x), bv.x));
+            *reinterpret_cast<float*>(zo + p.z_cs * 4 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][1], sc.y), bv.y));
+            *reinterpret_cast<float*>(zo + p.z_cs * 8 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][2], sc.z), bv.z));
+            *reinterpret_cast<float*>(zo + p.z_cs * 12 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][3], sc.w), bv.w));
+        }
+    }
+}
+
+template <class C>
+static int launch_fused16_cfg(const FusedTailParams& p, hipStream_t s) {
+    const double flops = 2.0 * 2.0 * (double)C::MID * C::COUT * (double)p.V;
+    void* ev = profile_begin(19, flops, s);
+    hipLaunchKernelGGL(fused_tail16_kernel<C>, dim3((unsigned)ceil_div(p.V, C::P)), dim3(C::NTHREADS), 0, s, p);
+    profile_end(ev, s);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
 template <class C>
 static int launch_fused_cfg(const FusedTailParams& p, hipStream_t s) {
     const double flops = 2.0 * 2.0 * (double)C::MID * C::COUT * (double)p.V;        // both GEMMs
@@ -410,7 +685,15 @@ int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const f
     if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64, 256>>(p, s);
     return launch_fused_cfg<FusedTailCfg<64, 64, 256>>(p, s);
 #else
+#if defined(SS_EXPERIMENTS) && defined(SS_FT_W32)
     if (mid == 256) return launch_fused_cfg<FusedTailCfg<256, 64, 128>>(p, s);
+#else
+    if (mid == 256) return launch_fused16_cfg<FusedTail16Cfg<256>>(p, s);
+#endif
+#if defined(SS_EXPERIMENTS) && defined(SS_FT_W16_ALL)
+    if (mid == 128) return launch_fused16_cfg<FusedTail16Cfg<128>>(p, s);
+    return launch_fused16_cfg<FusedTail16Cfg<64>>(p, s);
+#endif
     if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64, 128>>(p, s);
     return launch_fused_cfg<FusedTailCfg<64, 64, 128>>(p, s);
 #endif

@@ -2,9 +2,11 @@
 conv1 (+ bias + ReLU) of block b + 1 in ONE back-to-back kernel, conv2 handing its output over as fp16 operand planes.
 Reference: /root/reference/stemseg/modeling/backbone/resnet.py:262-282 of two consecutive blocks.
 
-Same operands, same split arithmetic, same k order per accumulator as the separate launches => the encoder's four FPN maps must be
-BIT-IDENTICAL with the fusion on and off wherever the separate launches run without split-K (the bench shape at its planning frame
-count), and within fp32 round-off of the oracle everywhere."""
+Stages 1-2 run the 32-column form: same operands, same split arithmetic, same k order per accumulator as the separate launches => the
+encoder's four FPN maps must be BIT-IDENTICAL with that fusion on and off wherever the separate launches run without split-K (the bench
+shape at its planning frame count).  Stage 3 (MID = 256) runs the 16-column form (the wave's conv3 input lives in registers; one
+v_mfma_f32_16x16x32_f16 sums a 32-channel chunk where the separate kernels issue two 16-deep groups): fp32 round-off apart from the
+separate launches, ONE result whatever the batch.  Everything within 1e-4 of the CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -43,22 +45,29 @@ def _run(hip, bb, x, fuse, precision="f16x3"):
     return outs, (prof.get(19, (0, 0, 0))[2])
 
 
-def test_fused_tail_is_bit_identical_to_the_three_launch_blocks_at_the_bench_shape(hip):
-    """480 x 864, R-101, 8 frames under the 32-frame plan (what a bench step runs): 2 + 3 + 22 fused launches (stages 1-3; stage 4 is
-    not fused), every FPN map torch.equal to the un-fused encoder's."""
+def test_fused_tail_vs_the_three_launch_blocks_at_the_bench_shape(hip):
+    """480 x 864, R-101, 8 frames under the 32-frame plan (what a bench step runs).  Stages 1-2 fused (mask 3, the 32-column kernels): 2 + 3
+    launches, every FPN map torch.equal to the un-fused encoder's.  All three stages (mask 7): 2 + 3 + 22 launches, fp32 round-off apart;
+    and the SAME bits whether the 8 frames pass alone or as the second clip of a 16-frame pass (batch invariance of the fused path)."""
     bb, _ = _backbone("R-101-FPN", 71)
     x = (torch.from_numpy(synth.synth_frames(8, 480, 864, seed=71).astype(np.float32)).permute(0, 3, 1, 2) - MEAN).cuda()
     ref, n0 = _run(hip, bb, x, False)
+    got3, n3 = _run(hip, bb, x, 3)
     got, n1 = _run(hip, bb, x, True)
-    assert n0 == 0 and n1 == 2 + 3 + 22, (n0, n1)
-    for r, g, s in zip(ref, got, (4, 8, 16, 32)):
+    assert n0 == 0 and n3 == 2 + 3 and n1 == 2 + 3 + 22, (n0, n3, n1)
+    for r, g3, g, s in zip(ref, got3, got, (4, 8, 16, 32)):
         assert torch.isfinite(g).all()
-        assert torch.equal(r, g), "1/%d: %d of %d values differ, max %g" % (s, int((r != g).sum()), r.numel(), float((r - g).abs().max()))
-    # a second pass of other frames through the same workspaces: still identical (no state left behind in the operand planes)
+        assert torch.equal(r, g3), "mask 3, 1/%d: %d of %d values differ, max %g" % (s, int((r != g3).sum()), r.numel(), float((r - g3).abs().max()))
+        scale = max(1.0, float(r.abs().max()))
+        err = float((r - g).abs().max()) / scale
+        print("[fused] 1/%d: stage-3 16-column form vs separate launches: max |diff| / scale = %.3g" % (s, err))
+        assert err <= 1e-5
+    # a second pass of other frames through the same workspaces (no state left behind in the operand planes), alone and behind another clip
     x2 = (torch.from_numpy(synth.synth_frames(8, 480, 864, seed=72).astype(np.float32)).permute(0, 3, 1, 2) - MEAN).cuda()
-    got2, _ = _run(hip, bb, x2, True)
-    ref2, _ = _run(hip, bb, x2, False)
-    assert all(torch.equal(a, b) for a, b in zip(ref2, got2))
+    alone, _ = _run(hip, bb, x2, True)
+    both, _ = _run(hip, bb, torch.cat([x, x2], 0), True)
+    for a, b, g in zip(alone, both, got):
+        assert torch.equal(a, b[:, 8:]) and torch.equal(g, b[:, :8])
     assert bb.check_workspaces()[0] == 0
 
 
