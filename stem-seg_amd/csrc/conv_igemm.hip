@@ -163,8 +163,14 @@ struct ConvKParams {
 // k-group are four ds_read_b32 per plane and the k-loop is ds_read + MFMA only.  Weights arrive pre-split; their slab is
 // staged in two k-group phases that ping-pong with the MFMA stream (phase A's slots are refilled for the next chunk while
 // phase B computes and vice versa, through registers), the input tile is prefetched into registers and written at the chunk end.
+// BLK_ (split-staged tiles): the 32 positions of an MFMA column block are 4 ROWS x 8 COLUMNS of the map instead of 32 columns of one row, and a
+// tile is TBR = BLK_ block rows x COLS_ block columns of them: 20 rows x 24 columns = 15 blocks for BLK_ = 5, COLS_ = 3.  120 x 216 maps (the
+// 4x level of a 480 x 864 frame: block_4x of both decoders, the FPN output conv, layer 1's 3x3 convs) are then tiled with NO junk position --
+// 16 x 32 tiles compute 128 x 224 -- and on a power-bound kernel MFMAs not issued are time.  The tile's LDS pitch is
+// == 8 (mod 32) words so that the four rows of a block fall on disjoint banks; a tap is still one compile-time immediate on a per-lane base.
+// The workgroup's 16th column block does not exist: the wave that would own it runs the chunk loop with one block (ni1_live below).
 template <int KT_, int KH_, int KW_, int CK_, int MI_, int NI_, int WM_, int WN_, int COLS_, bool PIPE_ = false, int BF_ = 0, bool DB_ = false,
-          int PMAX_ = 0, bool GL_ = false>
+          int PMAX_ = 0, bool GL_ = false, int BLK_ = 0>
 struct ConvCfg {
     // X6 = the split-staged path (operands split once, when a chunk is staged): BF_ 2 = bf16x6 (three bf16 planes, six products),
     // BF_ 3 = f16x3 (two fp16 planes of the SCALED operand, three products)
@@ -180,9 +186,13 @@ struct ConvCfg {
     static constexpr int NTHREADS = 64 * WM * WN;
     static constexpr int MT = WM * MI * 32;
     static constexpr int NSEG = WN * NI;
-    static constexpr int ROWS = NSEG / COLS;
+    static constexpr bool BLK = BLK_ > 0;
+    static constexpr int NLIVE = BLK ? BLK_ * COLS_ : NSEG;              // column blocks that exist (BLK: block rows x block columns <= NSEG)
+    static constexpr int ROWS = BLK ? 4 * BLK_ : NSEG / COLS;
+    static constexpr int TW = BLK ? 8 * COLS_ : COLS_ * 32;              // tile width in columns
     static constexpr int RH = ROWS + KH - 1;
-    static constexpr int XP = ((COLS * 32 + KW - 1) + 3) / 4 * 4;
+    static constexpr int XL = (TW + KW - 1 + 3) / 4;                     // 16-B pieces of a tile row that are staged
+    static constexpr int XP = BLK ? ((4 * XL + 23) / 32) * 32 + 8 : 4 * XL;   // LDS row pitch (BLK: the next value == 8 mod 32)
     static constexpr int NT = NSEG * 32;                                // FLAT: voxels (flat plane positions) per tile
     static constexpr int FL = NT + 2 * PMAX + 8;                        // FLAT: staged run per (channel, dt): tile + one row and 4 either side
     static constexpr int IN_CH_STRIDE = FLAT ? KT * FL : KT * RH * XP;
@@ -206,7 +216,8 @@ struct ConvCfg {
     static constexpr int BUF_FLOATS = IN_ALL + W_FLOATS;
     static constexpr int LDS_FLOATS = BUF_FLOATS * (DB ? 2 : 1);
     static_assert(!BF || CK % (2 * CPH) == 0, "split-staged: a chunk holds whole k-groups");
-    static_assert(NSEG % COLS == 0, "segments must fill whole rows");
+    static_assert(BLK || NSEG % COLS == 0, "segments must fill whole rows");
+    static_assert(!BLK || (BF_ >= 2 && PMAX_ == 0 && NI_ == 2 && NLIVE <= NSEG && NLIVE > NSEG - NI_ && XP % 32 == 8 && XP >= 4 * XL), "block tiles: split-staged, the last wave may lack its second block");
     static_assert(CK % 4 == 0 || (DB && GL_ && CK == 2 && !BF), "channel chunk is a multiple of the packed sub-chunk (4), or one channel pair (GL)");
     static_assert(LDS_FLOATS * 4 <= (X6 ? 160 : 80) * 1024, "two workgroups per CU (x6 eight-wave tiles: one)");
     static_assert(!X6 || (!DB && !GL && G >= 2 && CK % 2 == 0), "x6: 2-D / 3-D tiles, two weight phases");
@@ -277,7 +288,11 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         ty = bx % p.tiles_y;
         t = bx / p.tiles_y;
     }
-    const int x0 = C::FLAT ? 0 : tx * (C::COLS * 32), y0 = C::FLAT ? 0 : ty * C::ROWS;
+    const int x0 = C::FLAT ? 0 : tx * C::TW, y0 = C::FLAT ? 0 : ty * C::ROWS;
+    // position of lane column l (0..31) of column block s inside the tile: (row, column)
+    auto seg_row = [](const int sN, const int l) __attribute__((always_inline)) { return C::BLK ? (sN / C::COLS) * 4 + (l >> 3) : sN / C::COLS; };
+    auto seg_col = [](const int sN, const int l) __attribute__((always_inline)) { return C::BLK ? (sN % C::COLS) * 8 + (l & 7) : (sN % C::COLS) * 32 + l; };
+    const bool ni1_live = !C::BLK || (wn * C::NI + 1 < C::NLIVE);      // (wave-uniform) the wave's second column block exists
     const int pitch = (int)p.in_ys;                           // FLAT: row pitch of the haloed plane
     const int F0 = pitch + tx * C::NT;                        // FLAT: first flat position of this tile (row 1, column 0)
     const int co0 = co_tile * C::MT;
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
         b_ptr[ni] = C::FLAT ? in_lds + half * C::IN_CH_STRIDE + s * 32 + l31 + 3       // staged run starts at F0 - pitch - 4
-                            : in_lds + half * C::IN_CH_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+                            : in_lds + half * C::IN_CH_STRIDE + seg_row(s, l31) * C::XP + seg_col(s, l31);
     }
 
     const unsigned int* b_ptr6[C::NI];  // x6: word (channel pair) planes; lane half h owns the pairs [h*CPH/2, (h+1)*CPH/2) of every k-group
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
         b_ptr6[ni] = C::FLAT ? reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + s * 32 + l31 + 3   // (the staged run starts at F0 - pitch - 4)
-                             : reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + (s / C::COLS) * C::XP + (s % C::COLS) * 32 + l31;
+                             : reinterpret_cast<const unsigned int*>(in_lds) + half * (C::CPH / 2) * C::IN_PAIR_STRIDE + seg_row(min(s, C::NLIVE - 1), l31) * C::XP + seg_col(min(s, C::NLIVE - 1), l31);
     }
     const float* in_tile = p.in + (int64_t)blockIdx.y * p.in_bs + (int64_t)t * p.in_ts + x0;   // + c*cs + dt*ts + yy*ys
     const int64_t tile_base = (int64_t)t * p.in_ts + x0;
@@ -445,7 +460,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         }
     };
     constexpr int FQ6 = C::FL / 4;                                       // flat: 16-B pieces of one (pair, dt) run
-    constexpr int NQ6 = C::FLAT ? (C::CK / 2) * C::KT * FQ6 : (C::CK / 2) * C::KT * C::RH * XQ;   // 16-B pieces of a channel PAIR's rows: [pair][dt][row][xq] (flat: [pair][dt][run])
+    constexpr int XL6 = C::XL;                                           // staged 16-B pieces per tile row (BLK tiles: fewer than the LDS pitch holds)
+    constexpr int NQ6 = C::FLAT ? (C::CK / 2) * C::KT * FQ6 : (C::CK / 2) * C::KT * C::RH * XL6;   // 16-B pieces of a channel PAIR's rows: [pair][dt][row][xq] (flat: [pair][dt][run])
+    // word offset of piece q in a plane of the LDS tile (rows of pitch XP; without BLK the pieces ARE the linear image)
+    auto in6_lds = [](const int q) __attribute__((always_inline)) { return C::BLK ? (q / XL6) * C::XP + (q % XL6) * 4 : q * 4; };
     constexpr int IN_PT6 = C::X6 ? (NQ6 + C::NTHREADS - 1) / C::NTHREADS : 1;
     constexpr int NWQ_A = C::NPL * C::GA * 2 * C::MT, NWQ6 = C::NPL * C::G * 2 * C::MT;   // 16-B pieces of weight phase A / of the slab
     auto in6_rel = [&](int q, int& c) -> int64_t {                   // piece q -> float offset of its first channel (c0 = 0) from in_tile (< 0: not needed / outside)
@@ -456,8 +474,8 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             if (f < 0 || 4 * j4 >= C::NT + 2 * pitch + 8) return -1;  // before the volume (feeds halo-column outputs only) / beyond what this pitch needs
             return (int64_t)c * p.in_cs + (int64_t)dt * p.in_ts + f;
         }
-        const int xq = q % XQ;
-        int rr = q / XQ;
+        const int xq = q % XL6;
+        int rr = q / XL6;
         const int r = rr % C::RH;
         rr /= C::RH;
         const int dt = rr % C::KT;
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         if constexpr (C::F16) {                                       // (three mixed-precision FMAs per value, no packing: see split_pair_f16)
             split_pair_f16(v0.x, v1.x, ph.x, pm.x); split_pair_f16(v0.y, v1.y, ph.y, pm.y);
             split_pair_f16(v0.z, v1.z, ph.z, pm.z); split_pair_f16(v0.w, v1.w, ph.w, pm.w);
-            unsigned int* d16 = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
+            unsigned int* d16 = reinterpret_cast<unsigned int*>(in_lds) + in6_lds(q);
             *reinterpret_cast<uint4*>(d16) = ph;
             *reinterpret_cast<uint4*>(d16 + C::IN_PLANE_STRIDE) = pm;
             return;
@@ -520,7 +538,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
         split3(v0.y, h0, m0, l0); split3(v1.y, h1, m1, l1); ph.y = h0 | (h1 << 16); pm.y = m0 | (m1 << 16); pl.y = l0 | (l1 << 16);
         split3(v0.z, h0, m0, l0); split3(v1.z, h1, m1, l1); ph.z = h0 | (h1 << 16); pm.z = m0 | (m1 << 16); pl.z = l0 | (l1 << 16);
         split3(v0.w, h0, m0, l0); split3(v1.w, h1, m1, l1); ph.w = h0 | (h1 << 16); pm.w = m0 | (m1 << 16); pl.w = l0 | (l1 << 16);
-        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + q * 4;
+        unsigned int* d = reinterpret_cast<unsigned int*>(in_lds) + in6_lds(q);
         *reinterpret_cast<uint4*>(d) = ph;
         *reinterpret_cast<uint4*>(d + C::IN_PLANE_STRIDE) = pm;
         if constexpr (C::NPX == 3) *reinterpret_cast<uint4*>(d + 2 * C::IN_PLANE_STRIDE) = pl;
@@ -580,8 +598,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
     // side(step) is called once per (k-group, mi) step, in front of its MFMAs: the chunk loop hangs the next chunk's global loads
     // there, a few per step (all of them at the top of the chunk back the texture path up and the waves stall AT ISSUE, with the
     // matrix pipe idle behind them: measured 17% of a 1x1 layer)
-    auto compute6 = [&](auto g0c, auto g1c, auto&& side) __attribute__((always_inline)) {
+    auto compute6 = [&](auto g0c, auto g1c, auto&& side, auto live_c) __attribute__((always_inline)) {
         constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
+        constexpr bool LIVE1 = decltype(live_c)::value;       // the wave's column blocks beyond the first exist (BLK tiles: not in the last wave)
         constexpr int NPL = C::NPL, NPX = C::NPX, NPA = C::NPA;
         typedef typename std::conditional<C::F16, _Float16, __bf16>::type h16;
         typedef h16 h16x8 __attribute__((ext_vector_type(8)));
@@ -597,7 +616,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
 #endif
             const int cg = grp / C::NTG, tg = grp % C::NTG;
 #pragma unroll
-            for (int ni = 0; ni < C::NI; ++ni)
+            for (int ni = 0; ni < (LIVE1 ? C::NI : 1); ++ni)
 #pragma unroll
                 for (int pl = 0; pl < NPX; ++pl) {
                     uint4 w4;
@@ -640,13 +659,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 // third plane otherwise)
                 if constexpr (NPL == 2) a[2] = a[0] * (h16)(1.0f / 2048.0f);
 #define SS_X6_TERM(PA, PB)                                                                                                     \
-    _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < (LIVE1 ? C::NI : 1); ++ni)                                                         \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
                 SS_X6_TERM(1, 0) SS_X6_TERM(2, 1) SS_X6_TERM(0, 0)      // lo_w * hi_x, (hi_w 2^-11) * (lo_x 2^11), hi_w * hi_x
 #undef SS_X6_TERM
             } else {
 #define SS_X6_TERM(PA, PB)                                                                                                     \
-    _Pragma("unroll") for (int ni = 0; ni < C::NI; ++ni)                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < (LIVE1 ? C::NI : 1); ++ni)                                                         \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][ni], acc[mi][ni], 0, 0, 0);
                 SS_X6_TERM(2, 0) SS_X6_TERM(0, 2) SS_X6_TERM(1, 1) SS_X6_TERM(1, 0) SS_X6_TERM(0, 1) SS_X6_TERM(0, 0)
 #undef SS_X6_TERM
@@ -814,7 +833,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                         side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSALL + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, INc{}, std::integral_constant<int, NPALL>{}, f_in_at(cn),
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QE{}, rw6, k); });
                     }
-                });
+                }, Yes{});
                 SS_CHUNK_SYNC();
                 if constexpr (more) {
                     store_w6(Q0{}, QE{}, rw6);
@@ -839,13 +858,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                 compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? NSA : 1>{}, INc{}, std::integral_constant<int, NPB>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6b, k); });
-                });
+                }, Yes{});
                 SS_CHUNK_SYNC();
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more2) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPA>{}, [](const int) {},
                                           [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cnn, Q0{}, QA{}, rw6, k); });
-                });
+                }, Yes{});
                 SS_CHUNK_SYNC();
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6b);
@@ -861,13 +880,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
             // The weight slab is staged in two k-group phases that ping-pong with the MFMA stream: under phase A the next chunk's
             // phase-A weights and input tile gather in registers; they are written when phase A's slots fall idle, the registers
             // then collect the next chunk's phase-B weights under phase B's MFMA stream.  Three barriers per chunk.
-            auto chunk = [&](const int c0, auto more_c) __attribute__((always_inline)) {
+            auto chunk = [&](const int c0, auto more_c, auto live_c) __attribute__((always_inline)) {
                 constexpr bool more = decltype(more_c)::value;
                 const int cn = c0 + C::CK;
                 compute6(Q0{}, GAc{}, [&](const int st) __attribute__((always_inline)) {
                     if constexpr (more) side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSA + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, INc{}, std::integral_constant<int, NPA>{}, f_in_at(cn),
                                          [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, Q0{}, QA{}, rw6, k); });
-                });
+                }, live_c);
                 SS_CHUNK_SYNC();                                   // phase A's slots are idle
                 if constexpr (more) store_w6(Q0{}, QA{}, rw6);
                 compute6(GAc{}, Gc{}, [&](const int st) __attribute__((always_inline)) {
@@ -875,7 +894,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                         side_items(SPRD ? st : -1 - st, std::integral_constant<int, SPRD ? (NSB + SS_X6_SPREAD_DIV - 1) / SS_X6_SPREAD_DIV : 1>{}, I0{}, std::integral_constant<int, NPB>{}, [](const int) {},
                                    [&](const int k) __attribute__((always_inline)) { fetch_w6_k(cn, QA{}, QE{}, rw6, k); });
                     }
-                });
+                }, live_c);
                 SS_CHUNK_SYNC();                                   // everyone is done with phase B's slots and this chunk's input tile
                 if constexpr (more) {
                     store_w6(QA{}, QE{}, rw6);
@@ -883,9 +902,16 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
                     SS_CHUNK_SYNC();
                 }
             };
-            int c0 = c_begin;
-            for (; c0 + C::CK < c_end; c0 += C::CK) chunk(c0, Yes{});
-            if (c0 < c_end) chunk(c0, No{});
+            auto run = [&](auto live_c) __attribute__((always_inline)) {
+                int c0 = c_begin;
+                for (; c0 + C::CK < c_end; c0 += C::CK) chunk(c0, Yes{}, live_c);
+                if (c0 < c_end) chunk(c0, No{}, live_c);
+            };
+            // BLK tiles: the last wave owns ONE column block -- its own instance of the chunk loop, without the second block's fragment reads and MFMAs
+            if constexpr (C::BLK && C::NLIVE < C::NSEG) {
+                if (ni1_live) run(Yes{});
+                else run(No{});
+            } else run(Yes{});
         }
         if constexpr (C::F16) {
             // undo the operand scales (powers of two: exact): 1 / (weight scale of the output channel x activation scale), one float per
@@ -978,13 +1004,13 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
             const int sN = wn * C::NI + ni;
-            int y = y0 + sN / C::COLS, x = x0 + (sN % C::COLS) * 32 + l31;
+            int y = y0 + seg_row(sN, l31), x = x0 + seg_col(sN, l31);
             if constexpr (C::FLAT) {                           // (statistics are only fused into per-plane flat launches: flat_t == 0)
                 const int f = F0 + sN * 32 + l31, y1 = f / pitch, x1 = f - y1 * pitch;
                 y = y1 - 1;
                 x = (x1 >= 1) ? x1 - 1 : p.W;
             }
-            ok[ni] = y < p.H && x < p.W;
+            ok[ni] = y < p.H && x < p.W && sN < C::NLIVE;
         }
 #pragma unroll
         for (int mi = 0; mi < C::MI; ++mi) {
@@ -1042,8 +1068,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
 #pragma unroll
         for (int ni = 0; ni < C::NI; ++ni) {
             const int s = wn * C::NI + ni;
-            const int y = y0 + s / C::COLS;
-            const int xs = x0 + (s % C::COLS) * 32;            // first voxel of this 32-wide segment
+            if (C::BLK && s >= C::NLIVE) continue;             // (the last wave's missing block)
+            // a lane of the transposed tile owns positions c4 .. c4 + 3 of the column block, c4 = (lane & 7) * 4: four columns of one row in either block shape
+            const int y = y0 + seg_row(s, (lane & 7) * 4);
+            const int xs = x0 + seg_col(s, (lane & 7) * 4) - (lane & 7) * 4;            // so that xs + c4 is the lane's first column
             // residual and bias of two 32-channel sub-tiles at a time are requested up front: otherwise each of the loads
             // below is waited for on its own, right where it is used, and the epilogue of a short-K conv becomes a chain of
             // HBM latencies
@@ -1098,8 +1126,9 @@ __global__ __launch_bounds__(C::NTHREADS, C::MIN_WG) void conv_igemm_kernel(cons
 #pragma unroll
     for (int ni = 0; ni < C::NI; ++ni) {
         const int s = wn * C::NI + ni;
-        int y = y0 + s / C::COLS;
-        int x = x0 + (s % C::COLS) * 32 + l31;
+        if (C::BLK && s >= C::NLIVE) continue;
+        int y = y0 + seg_row(s, l31);
+        int x = x0 + seg_col(s, l31);
         int te = t;                                            // frame of this position (flat_t: decoded from the flat index)
         if constexpr (C::FLAT) {                               // flat position -> (row, column) of the haloed plane -> output (y, x)
             int f = F0 + s * 32 + l31;
@@ -1412,6 +1441,10 @@ struct SplitTiles {
     // 1x4x4 taps on 16-channel chunks (16 k-groups of one tap x 16 channels): the 7x7 stride-2 stem as a stride-1 4x4 convolution over the
     // space-to-depth image (encoder.hip); 64 co x (16 rows x 32 cols), 512 threads
     using Y4Stem = ConvCfg<1, 4, 4, 16, 2, 2, 1, 8, 1, false, BFV>;
+    // block tiles (ConvCfg::BLK): 128 co x (20 rows x 24 columns) as 5 x 3 column blocks of 4 rows x 8 columns, 512 threads -- no junk position on
+    // 120 x 216 maps (30 x 27 blocks), where the 16 x 32 tiles compute 128 x 224
+    using Y3Blk = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 3, false, BFV, false, 0, false, 5>;
+    using Y2Blk = ConvCfg<1, 3, 3, CK2, 4, 2, 1, 8, 3, false, BFV, false, 0, false, 5>;
     // Measured in round 5 and not kept (profiles/r05b_conv_sweep_f16x3_T32.txt, tile_cfg 6 / 7 / 8 of that build): four-wave halves of the
     // eight-wave tiles, two per CU so that one's staging phases run under the other's MFMA stream -- block_4x 1 076 vs 1 006 us, layer-3 3x3
     // 214 vs 203, 1024 -> 256 110 vs 107, 256 -> 1024 + residual 170 vs 154; and 64-channel chunks for the 1x1 tiles (half the chunk
@@ -1448,7 +1481,7 @@ struct PlanCtx {
 // workgroups tile shape C makes of shape d (flat_t: the flat run crosses the frames)
 template <class C>
 static int64_t cfg_workgroups(const ConvKParams& d, int flat_t) {
-    int64_t tx = C::FLAT ? ceil_div((int64_t)d.H * d.in_ys, C::NT) : ceil_div(d.W, C::COLS * 32);
+    int64_t tx = C::FLAT ? ceil_div((int64_t)d.H * d.in_ys, C::NT) : ceil_div(d.W, C::TW);
     const int64_t ty = C::FLAT ? 1 : ceil_div(d.H, C::ROWS);
     int64_t T = d.T;
     if (C::FLAT && flat_t) { tx = ceil_div((int64_t)d.T * d.in_ts, C::NT); T = 1; }
@@ -1457,7 +1490,7 @@ static int64_t cfg_workgroups(const ConvKParams& d, int flat_t) {
 
 template <class C>
 static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scratch_floats, int force_ksplit = 0, const PlanCtx* plan = nullptr) {
-    p.tiles_x = C::FLAT ? (int)ceil_div((int64_t)p.H * p.in_ys, C::NT) : (int)ceil_div(p.W, C::COLS * 32);
+    p.tiles_x = C::FLAT ? (int)ceil_div((int64_t)p.H * p.in_ys, C::NT) : (int)ceil_div(p.W, C::TW);
     p.tiles_y = C::FLAT ? 1 : (int)ceil_div(p.H, C::ROWS);
     p.T_all = p.T;
     const int flat_t = (C::FLAT && p.flat_t) ? 1 : 0;
@@ -1526,7 +1559,7 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
     }
     dim3 grid((unsigned)((int64_t)p.tiles_x * p.tiles_y * p.T * p.n_co), (unsigned)p.nb, (unsigned)ksplit);
     const double flops = 2.0 * p.Cin * C::TAPS * (double)p.Cout * p.T_all * p.H * p.W * p.nb;
-    constexpr int tile_rows = C::FLAT ? C::NSEG : C::ROWS;      // flat tiles count under the 2-D tile of the same size
+    constexpr int tile_rows = (C::FLAT || C::BLK) ? C::NSEG : C::ROWS;      // flat / block tiles count under the 2-D tile of the same size
     const int tag = C::TAPS == 16 ? -1 : C::TAPS == 1 ? 10 + C::NSEG : (C::KT == 1 ? 20 + tile_rows : (tile_rows == 16 ? 9 : tile_rows));   // (4x4 taps = the stem: its caller's own tag)   // 9/8/4/2: 3x3x3, 18/14: 1x1x1, 28/24/22: 1x3x3
     void* ev = profile_begin(tag, flops, s);
     hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(C::NTHREADS), 0, s, p);
@@ -1559,11 +1592,11 @@ struct RowPlan { double cost; int nA, k; };
 template <class C>
 static RowPlan plan_rows(const ConvKParams& d, bool have_scratch, int64_t scratch_floats, double cu_flops, int occ, double eff) {
     const int64_t slots = 256 * occ;
-    const int tiles_x = (int)ceil_div(d.W, C::COLS * 32);
+    const int tiles_x = (int)ceil_div(d.W, C::TW);
     const int n = (int)ceil_div(d.H, C::ROWS);
     const int64_t c = (int64_t)tiles_x * d.T * ceil_div(d.Cout, C::MT);
     const int nchunks = (int)ceil_div(d.Cin, C::CK);
-    const double t_round = occ * 2.0 * C::MT * (C::ROWS * 32.0 * C::COLS) * d.Cin * C::TAPS / (cu_flops * eff);
+    const double t_round = occ * 2.0 * C::MT * ((double)C::ROWS * C::TW) * d.Cin * C::TAPS / (cu_flops * eff);
     RowPlan best{(double)ceil_div(n * c, slots) * t_round, n, 1};
     const double t_plain = best.cost;
     static const int ks[] = {2, 3, 4, 6, 8};
@@ -1615,7 +1648,7 @@ static int launch_planned(const ConvKParams& p, const ConvKParams& d, const Plan
 template <class C>
 static double tile_efficiency(const ConvKParams& p) {
     if (C::FLAT) return (double)p.H * p.W / ((double)C::NT * ceil_div((int64_t)p.H * p.in_ys, C::NT));
-    return (double)p.H * p.W / ((double)C::ROWS * ceil_div(p.H, C::ROWS) * C::COLS * 32.0 * ceil_div(p.W, C::COLS * 32));
+    return (double)p.H * p.W / ((double)C::ROWS * ceil_div(p.H, C::ROWS) * (double)C::TW * ceil_div(p.W, C::TW));
 }
 template <class Flat, class Tile2D>
 static bool prefer_flat(const ConvKParams& p, int tile_cfg) {
@@ -1632,7 +1665,7 @@ static int launch_gl(const ConvKParams& p, hipStream_t s, float* scratch, int64_
 
 template <class C>
 static int64_t num_workgroups(const ConvKParams& d) {
-    return ceil_div(d.W, C::COLS * 32) * ceil_div(d.H, C::ROWS) * d.T * ceil_div(d.Cout, C::MT);
+    return ceil_div(d.W, C::TW) * ceil_div(d.H, C::ROWS) * d.T * ceil_div(d.Cout, C::MT);
 }
 
 // split-staged precisions: the weights were packed with stemseg_hip_pack_conv_weight_prec(..., precision).  Tile = the largest whose
@@ -1646,7 +1679,7 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     using Y2Big = typename F::Y2Big; using Y2Med = typename F::Y2Med; using Y2Small = typename F::Y2Small; using Y2M64 = typename F::Y2M64;
     using Y1Small = typename F::Y1Small; using Y1Big = typename F::Y1Big; using Y1M64 = typename F::Y1M64; using Y1Wide = typename F::Y1Wide;
     const bool auto_cfg = tile_cfg <= 0 || tile_cfg > 3;
-    int cfg = auto_cfg ? 0 : tile_cfg;
+    int cfg = (auto_cfg || tile_cfg == 6) ? 0 : tile_cfg;
     if constexpr (BFV == 3) {
         // Flat tiles (f16x3: the default mode): a 2-D tile of 16 rows x 32 columns computes 128 x 224 positions for a 120 x 216 map and
         // 32 x 64 for layer 3's 30 x 54: 13-21 % of the MFMAs feed positions that are never stored; the flat tile computes the halo
@@ -1665,6 +1698,21 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
                 return launch_cfg<typename F::template Y2Flat<224>>(p, s, scratch, scratch_floats, 0, pc);
             }
         }
+    }
+    // Block tiles (f16x3): where the big 16 x 32 tile would be chosen and the map wastes > 6 % more of it than of 20 x 24 tiles of 4 x 8 blocks
+    // (120 x 216: 10.6 % vs 0), take those; tile_cfg 6 forces them.  Same k order per output: bit-identical to the 16 x 32 tiles.
+    static const bool blk_on = [] { const char* e = getenv("STEMSEG_BLK_TILES"); return !(e && e[0] == '0'); }();      // (A/B switch; default on)
+    auto blk_gain = [&]() {
+        if (!blk_on) return false;
+        const double e_blk = (double)p.H * p.W / ((double)ceil_div(p.H, 20) * 20 * ceil_div(p.W, 24) * 24);
+        const double e_big = (double)p.H * p.W / ((double)ceil_div(p.H, 16) * 16 * ceil_div(p.W, 32) * 32);
+        return e_blk > 1.06 * e_big;
+    };
+    if constexpr (BFV == 3) {
+        if (k3 && p.vec4 && (tile_cfg == 6 || (auto_cfg && num_workgroups<Y3Big>(d) >= 384 && num_workgroups<typename F::Y3Blk>(d) >= 384 && blk_gain())))
+            return launch_cfg<typename F::Y3Blk>(p, s, scratch, scratch_floats, 0, pc);
+        if (k2 && p.vec4 && p.Cout > 64 && (tile_cfg == 6 || (auto_cfg && num_workgroups<Y2Big>(d) >= (scratch ? 96 : 384) && num_workgroups<typename F::Y2Blk>(d) >= 384 && blk_gain())))
+            return launch_cfg<typename F::Y2Blk>(p, s, scratch, scratch_floats, 0, pc);
     }
     if (k3) {
         if (cfg == 0) cfg = num_workgroups<Y3Big>(d) >= 384 ? 1 : (num_workgroups<Y3Med>(d) >= (scratch ? 32 : 256) ? 2 : 3);

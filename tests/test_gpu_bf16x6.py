@@ -363,3 +363,47 @@ def test_flat_split_tiles_vs_fp64(hip, case):
     assert np.isfinite(outs[5]).all() and e_flat <= max(3.0 * e_2d, 4e-7 * np.abs(want).max())
     if form in ("plain", "relu+res", "gn"):
         assert np.array_equal(outs[5], outs[1]), "same chunk order, same products: the flat tile must reproduce the 2-D tile bit for bit"
+
+
+@pytest.mark.parametrize("case", [("k3", 16, 128, 3, 40, 48, "plain"), ("k3", 8, 128, 2, 120, 216, "gn"), ("k3", 12, 256, 2, 37, 50, "relu+res"),
+                                  ("k2", 32, 128, 3, 120, 216, "plain"), ("k2", 16, 256, 2, 23, 29, "relu+res"), ("k3", 8, 128, 4, 20, 24, "splitk")])
+def test_block_tiles_vs_fp64(hip, case):
+    """Block tiles (tile_cfg 6; f16x3 only): a workgroup owns 20 rows x 24 columns of the map as 5 x 3 MFMA column blocks of 4 rows x 8 columns
+    (15 blocks: the eighth wave carries one instead of two), so that a 120 x 216 map is tiled with no junk position.  Same operands, same k
+    order per output as the 16-row x 32-column tile: bit-identical to it (ragged maps, residual / ReLU, fused GroupNorm statistics included),
+    fp32-level error vs fp64, identical run to run."""
+    if SP != "f16x3":
+        pytest.skip("block tiles exist for the default mode")
+    kind, Cin, Cout, T, H, W, form = case
+    kt = 3 if kind == "k3" else 1
+    x, w, b = _rand((Cin, T, H, W), 15), _rand((Cout, Cin, kt, 3, 3), 16, 1.0 / np.sqrt(Cin * 9 * kt)), _rand((Cout,), 17)
+    ref = _ref64(x, w, b, kt)
+    buf, vin = _haloed(hip, x, kt)
+    pw = hip.pack_conv_weight_any(dev(w), SP)
+    outs, stats = {}, {}
+    r = _rand((Cout, T, H, W), 18) if form == "relu+res" else None
+    for cfg in (6, 1, 6):
+        out = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        epi = dict(precision=SP)
+        if form == "relu+res":
+            rd = dev(r)
+            epi.update(relu=1, residual=rd, res_strides=(T * H * W, H * W, W))
+        scratch = torch.full((8 * Cout * T * H * W,), float("nan"), device="cuda") if form == "splitk" else None
+        if form == "gn":
+            st = hip.conv3d_gn(vin, pw, dev(b), hip.dense_volume(out), 3, 32, 1e-5, cfg, None, SP)
+            stats.setdefault(cfg, []).append(st.cpu().numpy())
+        else:
+            hip.conv3d(vin, pw, dev(b), hip.dense_volume(out), (kt, 3, 3), cfg, scratch, epi)
+        torch.cuda.synchronize()
+        outs.setdefault(cfg, []).append(out.cpu().numpy().astype(np.float64))
+    want = ref if form != "relu+res" else np.maximum(ref + r, 0.0)
+    e_blk, e_2d = np.abs(outs[6][0] - want).max(), np.abs(outs[1][0] - want).max()
+    print("[f16x3] block tile %s: max|err| vs fp64 %.3e, 16 x 32 tile %.3e (max|ref| %.3g)" % (case, e_blk, e_2d, np.abs(want).max()))
+    assert np.isfinite(outs[6][0]).all() and e_blk <= max(3.0 * e_2d, 4e-7 * np.abs(want).max())
+    assert np.array_equal(outs[6][0], outs[6][1]), "run to run"
+    if form != "splitk":
+        assert np.array_equal(outs[6][0], outs[1][0]), "same chunk order, same products: the block tile must reproduce the 16 x 32 tile bit for bit"
+    if form == "gn":
+        o = outs[6][0].reshape(32, -1)
+        assert np.array_equal(stats[6][0], stats[6][1])
+        assert np.abs(stats[6][0].reshape(32, 2)[:, 0] - o.mean(1)).max() <= 2e-6 * max(1.0, np.abs(o.mean(1)).max())
