@@ -524,7 +524,7 @@ def main():
     ap.add_argument("--plan-frames", type=int, default=None,
                     help="frames the encoder plans its launches for (default: the model's own constant, ResNetFPN.plan_frames = 32, whatever "
                          "--clips-per-step / --sequence say: two batchings of one job give the same bits).  A throughput knob for A/B runs only")
-    ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: stages whose bottleneck tails run fused (bit mask 1 | 2 | 4; default: the model's, 7; 0: none)")
+    ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: stages whose bottleneck tails run fused (bit mask 1 | 2 | 4; default: the model's, 7; 0: none; + 8: stage 3 on the 16-column form)")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()

@@ -282,7 +282,9 @@ typedef struct StemsegEncoderDesc {
                                     the next one run as ONE back-to-back kernel (resnet.py:262-282 of two consecutive blocks): the 4x-wide block
                                     output is written once and never read back by conv1, and conv2 hands its output over as fp16 operand
                                     planes.  Same operands and k order: bit-identical to the separate launches wherever those run without
-                                    split-K.  0: three launches per block everywhere (rounds 1-5). */
+                                    split-K.  0: three launches per block everywhere (rounds 1-5).  Bits 3-4 pick stage 3's kernel (A/B):
+                                    0 = the library's choice (one wave per SIMD, bit-identical like stages 1-2), 1 (value 8) = the
+                                    16-column form (fp32 round-off apart from the separate launches), 2 (value 16) = one wave per SIMD. */
 } StemsegEncoderDesc;
 
 typedef struct StemsegEncoderWeights {

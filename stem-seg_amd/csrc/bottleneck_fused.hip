@@ -25,7 +25,8 @@
 #include "common.h"
 
 // Timing probes / A-B switches: EXPERIMENT builds only (-DSS_EXPERIMENTS), as in conv_igemm.hip.  SS_FT_PROBE (results WRONG for any value but 0):
-// 1 no identity loads and no block-output stores (the kernel's HBM traffic), 2 no LDS-DMA of the input chunks, 3 no MFMAs.
+// 1 no identity loads and no block-output stores (the kernel's HBM traffic), 2 no LDS-DMA of the input chunks, 3 no MFMAs, 4 (R1 form) no weight DMA,
+// 5 (R1 form) identity loads but no output stores, 6 (R1 form) output stores but no identity loads.
 // SS_FT_STAGGER n: workgroup b starts (b % 16) * n * ~0.5 us late (spreads the workgroups' HBM bursts; same results).
 #ifndef SS_EXPERIMENTS
 #if defined(SS_FT_PROBE) || defined(SS_FT_STAGGER)
@@ -639,6 +640,357 @@ __global__ __launch_bounds__(C::NTHREADS, 2) void fused_tail16_kernel(const Fuse
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The one-wave-per-SIMD form ("R1"; MID = 256).  The 16-column form above is latency-shaped: two 256-register waves per SIMD meet the same
+// barrier 64 times, a stage is 0.7 us of matrix work behind LDS reads that one spare fragment set cannot cover, and every stage's vmcnt(0)
+// also waits for the identity loads and output stores of that stage (PMC: waves parked 42 %, the MFMA pipe busy 29 % of the launch).  Here
+// a workgroup is FOUR waves, one per SIMD, with the whole 512-register file each:
+//   * a wave owns 32 positions and keeps, for all of them, conv3's whole input (MID / 16 k-groups x (hi, lo) = 128 registers, loaded once),
+//     conv1's MID x 32 accumulators (128) and the co-tile's CT x 32 (64): an A fragment read from LDS feeds a 32-column MFMA, i.e. half the
+//     LDS traffic per MFMA cycle of the 16-column form, and the k order per accumulator is the separate launches' (v_mfma_f32_32x32x16_f16,
+//     two 16-deep k-groups per 32-channel chunk) => bit-identical to them again;
+//   * the spare registers are a ring of A-fragment sets two steps ahead of the MFMAs, and a second identity buffer: the identity rows of a
+//     32-channel tile are requested two stages before its epilogue;
+//   * the end-of-stage wait is COUNTED: the stage's LDS-DMA pieces are issued first, so `s_waitcnt vmcnt(n)` with n = the identity loads
+//     and output stores issued behind them waits for the weights only (vmcnt retires in issue order);
+//   * the epilogue of tile u + 1 (scale / bias / identity / ReLU / store / split / lane exchange) is cut into slices that sit between the
+//     MFMAs of conv1's k-step u; identity loads and output stores are buffer instructions (row base in an SGPR offset, one loop-invariant
+//     lane offset; columns past V are dropped by the descriptor's range check): no address arithmetic, no branch inside a stage.
+typedef __amdgpu_buffer_rsrc_t ft_rsrc_t;
+#define FT_VMCNT_(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0F70)
+#if defined(SS_EXPERIMENTS) && defined(SS_FT_PROBE) && SS_FT_PROBE == 7      // (probe 7: the stage ends do not wait for their DMA)
+#define FT_VMCNT(n) FT_VMCNT_(63)
+#else
+#define FT_VMCNT(n) FT_VMCNT_(n)
+#endif
+#ifndef FT_PPS
+#define FT_PPS 4           // DMA pieces per step
+#endif
+#define FT_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+template <int MID_, int CT_>
+struct FusedTailR1Cfg {
+    static constexpr int MID = MID_, CT = CT_, COUT = 4 * MID_;
+    static constexpr int NW = 4, NTHREADS = 64 * NW, P = 32 * NW;
+    static constexpr int NC3 = MID / 32, NG = MID / 16, NCT = COUT / CT;
+    static constexpr int MI3 = CT / 32, MI1 = MID / 32;        // 32-row accumulator tiles: conv3 co-tile, conv1
+    static constexpr int SC = 2;                              // conv3 chunks per stage
+    static constexpr int NS = NC3 / SC, NU = CT / 32;         // conv3 stages / conv1 k-steps per co-tile
+    static constexpr int NX3 = SC * 2 * (MI3 / 2), NX1 = 2 * (MI1 / 2);     // steps (two tiles x three products) per conv3 stage / conv1 k-step
+    static constexpr int W3_CHUNK = 8 * CT * 16, W3_BYTES = SC * W3_CHUNK;
+    static constexpr int W1_BYTES = 8 * MID * 16;
+    static constexpr int TAB_BYTES = 1024;
+    static constexpr int LDS_BYTES = 2 * W3_BYTES + 2 * W1_BYTES + 2 * TAB_BYTES;
+    static constexpr int W3_PIECES = W3_BYTES / 1024 / NW, W1_PIECES = W1_BYTES / 1024 / NW;
+    static_assert(NC3 % SC == 0 && MI3 % 2 == 0 && MI1 % 2 == 0 && W3_BYTES % (1024 * NW) == 0 && W1_BYTES % (1024 * NW) == 0 && 2 * CT * 4 <= TAB_BYTES, "whole DMA pieces per wave");
+    static_assert(LDS_BYTES <= 160 * 1024 && 2 * MID * 4 <= W3_BYTES && NX1 >= 8 && NX3 >= 3 && NU >= 2 && NU % 2 == 0, "LDS / slice placement / identity buffer parity");
+    static_assert(NG * 8 + MI1 * 16 <= 256, "the conv3 input and conv1's accumulators are the AGPR half of the register file");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 1) void fused_tail_r1_kernel(const FusedTailParams p) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];
+    char* const w3buf = smem;
+    char* const w1buf = smem + 2 * C::W3_BYTES;
+    char* const tabbuf = smem + 2 * C::W3_BYTES + 2 * C::W1_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int pos = blockIdx.x * C::P + wave * 32 + l31;       // this lane's position (column of every accumulator tile of the wave)
+    const bool pos_ok = pos < p.V;
+    const int pos_c = min(pos, p.V - 1);
+    const int64_t V = p.V;
+    const unsigned int V4 = (unsigned int)p.V * 4u;           // bytes per channel row
+    // rows (r & 3) + 8 (r >> 2) + 4 half of a 32-channel tile: the 4 half part and the column are the lane offset; loads of a column past V read
+    // the last valid one, its stores carry an offset the descriptor's range check drops
+    const unsigned int lane_ld = (unsigned int)(4 * half) * V4 + (unsigned int)pos_c * 4u;
+    const unsigned int lane_st = pos_ok ? lane_ld : 0xFFFFFF00u;
+    const unsigned int tile_bytes = (unsigned int)C::CT * V4;  // a co-tile's rows: the extent of its descriptors
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* inv3 = reinterpret_cast<const float*>(p.w3 + (int64_t)C::NC3 * 8 * C::COUT * 16);
+    const float* inv1 = reinterpret_cast<const float*>(p.w1 + (int64_t)(C::COUT / 32) * 8 * C::MID * 16);
+
+    // ---- LDS-DMA, as inline assembly ---------------------------------------------------------------------------------------------------
+    // One piece = 1 KB per wave instruction (global_load_lds_dwordx4: wave-uniform 64-bit base in SGPRs + ONE loop-invariant lane offset, LDS
+    // base in M0).  Assembly, not the builtin: the compiler cannot tell an LDS read from the target of a DMA it knows to be in flight, and
+    // guards the first table read behind a request with a vmcnt(0); requests it does not see are waited for by the counted s_waitcnt at the
+    // end of the stage and by nothing else.  (Its own counts for the identity loads stay safe: unseen requests only make a vmcnt(n) stricter.)
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+    const unsigned int lds_w3 = (unsigned int)(uintptr_t)(lptr_t)w3buf, lds_w1 = (unsigned int)(uintptr_t)(lptr_t)w1buf;
+    auto dma_piece = [&](const char* sbase, const unsigned int lds_addr) __attribute__((always_inline)) {
+#if SS_FT_PROBE == 4
+        return;
+#endif
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane16), "s"(sbase) : "memory");
+    };
+    auto dma_w3 = [&](const int j, const int st, const int buf, const int k) __attribute__((always_inline)) {      // piece k of chunks SC st .. of co-tile j
+        constexpr int PER_ROW = C::CT * 16 / 1024, PER_CHUNK = C::W3_CHUNK / 1024;
+        const int idx = wave + k * C::NW, sc = idx / PER_CHUNK, r = idx % PER_CHUNK, row = r / PER_ROW, part = r % PER_ROW;
+        dma_piece(p.w3 + ((int64_t)(st * C::SC + sc) * 8 + row) * (C::COUT * 16) + (int64_t)j * (C::CT * 16) + part * 1024, lds_w3 + buf * C::W3_BYTES + idx * 1024);
+    };
+    auto dma_w1 = [&](const int cc, const int buf, const int k) __attribute__((always_inline)) {                   // piece k of conv1 k-step (32-channel chunk) cc
+        const int idx = wave + k * C::NW;
+        dma_piece(p.w1 + (int64_t)cc * C::W1_BYTES + (int64_t)idx * 1024, lds_w1 + buf * C::W1_BYTES + idx * 1024);
+    };
+    static_assert(C::W3_PIECES == 8 && C::W1_PIECES == 8, "the pieces of a stage are requested in its first two steps, four each");
+    // co-tile j's (1 / scale | bias) table: lanes 0 .. CT / 4 - 1 of wave 0 fetch the scales, the next CT / 4 the biases (an ordinary load at the
+    // top of conv3's last stage), and store them at its end
+    float4 tabv = {0.f, 0.f, 0.f, 0.f};
+    auto tab_fetch = [&](const int j) __attribute__((always_inline)) {
+        if (wave == 0 && lane < 2 * (C::CT / 4))
+            tabv = *reinterpret_cast<const float4*>((lane < C::CT / 4 ? inv3 : p.b3 - C::CT) + (int64_t)j * C::CT + lane * 4);
+    };
+    auto tab_store = [&](const int j) __attribute__((always_inline)) {
+        if (wave == 0 && lane < 2 * (C::CT / 4)) *reinterpret_cast<float4*>(tabbuf + (j & 1) * C::TAB_BYTES + lane * 16) = tabv;
+    };
+    auto rsrc_of = [&](const float* base, const int jj) __attribute__((always_inline)) {        // the CT rows of co-tile jj of a dense [4 MID][V] map
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)jj * C::CT * V), 0, (int)tile_bytes, 0x00020000);
+    };
+    // identity rows of 32-channel tile u of co-tile jj, this lane's column
+    auto load_identity = [&](const int jj, const int u, float (&rr)[16]) __attribute__((always_inline)) {
+        const ft_rsrc_t rs = rsrc_of(p.res, jj);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#if SS_FT_PROBE == 1 || SS_FT_PROBE == 6
+            rr[r] = 0.f;
+#else
+            rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_ld, (unsigned int)(32 * u + (r & 3) + 8 * (r >> 2)) * V4, 0));
+#endif
+    };
+    const f16x8 k2048 = {(_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f),
+                         (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f)};
+    // two tiles per step, their MFMAs alternating (never two in a row on one accumulator); per accumulator the three products in mma3's order
+    auto mma6 = [&](f32x16& c0, f32x16& c1, const f16x8 (&a_hi)[2], const f16x8 (&a_lo)[2], const f16x8 (&a_his)[2], const f16x8 b_hi, const f16x8 b_lo)
+        __attribute__((always_inline)) {
+#if SS_FT_PROBE == 3
+        asm volatile("" ::"v"(a_his[0]), "v"(a_lo[0]), "v"(a_his[1]), "v"(a_lo[1]), "v"(a_hi[0]), "v"(a_hi[1]), "v"(b_hi), "v"(b_lo));
+        return;
+#endif
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0], b_hi, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1], b_hi, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_his[0], b_lo, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_his[1], b_lo, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0], b_hi, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1], b_hi, c1, 0, 0, 0);
+    };
+
+    // ---- prologue: the first stage's weights, the first two tiles' identity rows, the wave's whole conv3 input --------------------------
+#pragma unroll
+    for (int k = 0; k < C::W3_PIECES; ++k) dma_w3(0, 0, 0, k);
+    float rres[2][16];
+    load_identity(0, 0, rres[0]);
+    load_identity(0, 1, rres[1]);
+    f16x8 xh[C::NG], xl[C::NG];                    // k-group G: lane (half, n) = octet 2 G + half of both planes at its position
+    {
+        const char* xs = reinterpret_cast<const char*>(p.x16) + (size_t)((unsigned int)pos_c * 16u);
+#pragma unroll
+        for (int G = 0; G < C::NG; ++G) {
+            xh[G] = *reinterpret_cast<const f16x8*>(xs + ((int64_t)(2 * G + half)) * V * 16);
+            xl[G] = *reinterpret_cast<const f16x8*>(xs + ((int64_t)(C::MID / 8 + 2 * G + half)) * V * 16);
+        }
+    }
+    f32x16 acc1[C::MI1];
+#pragma unroll
+    for (int m = 0; m < C::MI1; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[m][r] = 0.f;
+    FT_VMCNT(0);
+    __syncthreads();
+    int sb = 0, eb = 0;                                      // buffers of the conv3 stage / the conv1 k-step about to run
+#pragma unroll 1
+    for (int j = 0; j < C::NCT; ++j) {
+        f32x16 acc3[C::MI3];
+#pragma unroll
+        for (int m = 0; m < C::MI3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[m][r] = 0.f;
+        // ---- conv3: NS stages of SC chunks ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+            if (st + 1 == C::NS) tab_fetch(j);
+            const char* wb = w3buf + sb * C::W3_BYTES + (half * C::CT + l31) * 16;
+            f16x8 a_hi[3][2], a_lo[3][2], a_his[2][2];
+            auto ld3 = [&](const int s, const int k) __attribute__((always_inline)) {
+                const int sc = s / (C::NX3 / C::SC), g = (s / (C::MI3 / 2)) & 1, mp = s % (C::MI3 / 2);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a_hi[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (((g * 2 + 0) * 2) * C::CT + (2 * mp + e) * 32) * 16);
+                    a_lo[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (((g * 2 + 1) * 2) * C::CT + (2 * mp + e) * 32) * 16);
+                }
+            };
+            ld3(0, 0);
+            ld3(1, 1);
+            a_his[0][0] = a_hi[0][0] * k2048;
+            a_his[0][1] = a_hi[0][1] * k2048;
+#pragma unroll
+            for (int s = 0; s < C::NX3; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < 8 / FT_PPS) {                        // what the next stage reads, FT_PPS pieces in each of the first steps
+#pragma unroll
+                    for (int k = FT_PPS * s; k < FT_PPS * s + FT_PPS; ++k) {
+                        if (st + 1 < C::NS) dma_w3(j, st + 1, sb ^ 1, k);
+                        else dma_w1(j * C::NU, eb, k);
+                    }
+                }
+                if (s + 2 < C::NX3) ld3(s + 2, (s + 2) % 3);
+                if (s + 1 < C::NX3) {
+                    a_his[(s + 1) & 1][0] = a_hi[(s + 1) % 3][0] * k2048;
+                    a_his[(s + 1) & 1][1] = a_hi[(s + 1) % 3][1] * k2048;
+                }
+                const int sc = s / (C::NX3 / C::SC), g = (s / (C::MI3 / 2)) & 1, mp = s % (C::MI3 / 2), G = 2 * (st * C::SC + sc) + g;
+                mma6(acc3[2 * mp], acc3[2 * mp + 1], a_hi[s % 3], a_lo[s % 3], a_his[s & 1], xh[G], xl[G]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { FT_SGB(0x008, 1); FT_SGB(0x100, 1); FT_SGB(0x002, 2); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            FT_VMCNT(0);                                     // (this stage issued nothing behind its requests; older loads / stores have had a stage)
+            if (st + 1 == C::NS) tab_store(j);
+            __syncthreads();
+            sb ^= 1;
+        }
+        // ---- epilogue slices + conv1's k-steps ---------------------------------------------------------------------------------------------
+        const float* tab = reinterpret_cast<const float*>(tabbuf + (j & 1) * C::TAB_BYTES) + 4 * half;
+        const ft_rsrc_t ry = rsrc_of(p.y, j);
+        unsigned int hw[8], lw[8];
+        f16x8 b_hi[2][2], b_lo[2][2];                       // [k-step parity][k-group]: conv1's B fragments
+        // rows 8 q4 + 4 half + 0 .. 3 of tile u: scale back, + bias, + identity, ReLU, store, split
+        auto e_slice = [&](const int u, const int q4) __attribute__((always_inline)) {
+            const int c4 = 32 * u + 8 * q4;
+            const float4 sc = *reinterpret_cast<const float4*>(tab + c4);
+            const float4 bv = *reinterpret_cast<const float4*>(tab + C::CT + c4);
+            float (&rr)[16] = rres[u & 1];
+            // (explicitly rounded steps: the standalone kernel scales its accumulators in one place and adds bias / identity in another)
+            float v0 = __fmul_rn(acc3[u][4 * q4 + 0], sc.x), v1 = __fmul_rn(acc3[u][4 * q4 + 1], sc.y), v2 = __fmul_rn(acc3[u][4 * q4 + 2], sc.z),
+                  v3 = __fmul_rn(acc3[u][4 * q4 + 3], sc.w);
+            v0 = relu_keep_nan(__fadd_rn(__fadd_rn(v0, bv.x), rr[4 * q4 + 0]));
+            v1 = relu_keep_nan(__fadd_rn(__fadd_rn(v1, bv.y), rr[4 * q4 + 1]));
+            v2 = relu_keep_nan(__fadd_rn(__fadd_rn(v2, bv.z), rr[4 * q4 + 2]));
+            v3 = relu_keep_nan(__fadd_rn(__fadd_rn(v3, bv.w), rr[4 * q4 + 3]));
+#if SS_FT_PROBE != 1 && SS_FT_PROBE != 5
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v0), ry, lane_st, (unsigned int)(c4 + 0) * V4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v1), ry, lane_st, (unsigned int)(c4 + 1) * V4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v2), ry, lane_st, (unsigned int)(c4 + 2) * V4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v3), ry, lane_st, (unsigned int)(c4 + 3) * V4, 0);
+#endif
+            ft_split_pair(v0, v1, hw[2 * q4], lw[2 * q4]);
+            ft_split_pair(v2, v3, hw[2 * q4 + 1], lw[2 * q4 + 1]);
+        };
+        // k-group gg of the tile as conv1's B fragment: the lane halves hold (q4 even: ch 0-3 | 4-7), (q4 odd: 8-11 | 12-15) of the group; swapping
+        // the upper half of the q4-even words with the lower half of the q4-odd words gives (0-3, 4-7) to half 0 and (8-11, 12-15) to half 1
+        auto e_perm = [&](const int gg, f16x8& bh, f16x8& bl) __attribute__((always_inline)) {
+            unsigned int xh_[2], yh_[2], xl_[2], yl_[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                auto sh = __builtin_amdgcn_permlane32_swap(hw[4 * gg + i], hw[4 * gg + 2 + i], false, false);
+                xh_[i] = sh[0]; yh_[i] = sh[1];
+                auto sl = __builtin_amdgcn_permlane32_swap(lw[4 * gg + i], lw[4 * gg + 2 + i], false, false);
+                xl_[i] = sl[0]; yl_[i] = sl[1];
+            }
+            const u32x4 bh4 = {xh_[0], xh_[1], yh_[0], yh_[1]}, bl4 = {xl_[0], xl_[1], yl_[0], yl_[1]};
+            bh = __builtin_bit_cast(f16x8, bh4);
+            bl = __builtin_bit_cast(f16x8, bl4);
+        };
+        // tile 0 of the co-tile has nothing to hide behind: its accumulators were finished by the stage that just ended
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) e_slice(0, q4);
+        e_perm(0, b_hi[0][0], b_lo[0][0]);
+        e_perm(1, b_hi[0][1], b_lo[0][1]);
+#pragma unroll
+        for (int u = 0; u < C::NU; ++u) {
+            const char* w1b = w1buf + eb * C::W1_BYTES + (half * C::MID + l31) * 16;
+            f16x8 a_hi[3][2], a_lo[3][2], a_his[2][2];
+            auto ld1 = [&](const int s, const int k) __attribute__((always_inline)) {
+                const int g = s / (C::MI1 / 2), mp = s % (C::MI1 / 2);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a_hi[k][e] = *reinterpret_cast<const f16x8*>(w1b + (((g * 2 + 0) * 2) * C::MID + (2 * mp + e) * 32) * 16);
+                    a_lo[k][e] = *reinterpret_cast<const f16x8*>(w1b + (((g * 2 + 1) * 2) * C::MID + (2 * mp + e) * 32) * 16);
+                }
+            };
+            ld1(0, 0);
+            ld1(1, 1);
+            a_his[0][0] = a_hi[0][0] * k2048;
+            a_his[0][1] = a_hi[0][1] * k2048;
+#pragma unroll
+            for (int s = 0; s < C::NX1; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                // Steps 0-1: what the next stage reads.  Step 2: the identity rows of tile u + 2 (tile u's buffer: its epilogue ran a stage ago) -- a
+                // stage ahead of the slices that add them, and BEHIND this stage's requests, so that the counted wait leaves them in flight.
+                // Steps 2-5: the next tile's epilogue, rows 8 (s - 2) .. per step; steps 6-7: its two lane exchanges.
+                if (s < 8 / FT_PPS) {
+#pragma unroll
+                    for (int k = FT_PPS * s; k < FT_PPS * s + FT_PPS; ++k) {
+                        if (u + 1 < C::NU) dma_w1(j * C::NU + u + 1, eb ^ 1, k);
+                        else if (j + 1 < C::NCT) dma_w3(j + 1, 0, sb, k);
+                    }
+                }
+                if (s == (8 / FT_PPS < 7 ? 8 / FT_PPS : 7)) load_identity(u + 2 < C::NU ? j : min(j + 1, C::NCT - 1), (u + 2) % C::NU, rres[u & 1]);      // (past the last tile: the last co-tile's rows again, never used)
+                if (s + 2 < C::NX1) ld1(s + 2, (s + 2) % 3);
+                if (s + 1 < C::NX1) {
+                    a_his[(s + 1) & 1][0] = a_hi[(s + 1) % 3][0] * k2048;
+                    a_his[(s + 1) & 1][1] = a_hi[(s + 1) % 3][1] * k2048;
+                }
+                if (u + 1 < C::NU) {
+                    if (s >= 2 && s < 6) e_slice(u + 1, s - 2);
+                    else if (s == 6) e_perm(0, b_hi[(u + 1) & 1][0], b_lo[(u + 1) & 1][0]);
+                    else if (s == 7) e_perm(1, b_hi[(u + 1) & 1][1], b_lo[(u + 1) & 1][1]);
+                }
+                const int g = s / (C::MI1 / 2), mp = s % (C::MI1 / 2);
+                mma6(acc1[2 * mp], acc1[2 * mp + 1], a_hi[s % 3], a_lo[s % 3], a_his[s & 1], b_hi[u & 1][g], b_lo[u & 1][g]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { FT_SGB(0x008, 1); FT_SGB(0x100, 1); FT_SGB(0x002, 7); FT_SGB(0x040, 1); FT_SGB(0x020, 3); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // behind the requests of steps 0-1 this stage issued 16 identity loads and, if it carried an epilogue, 16 output stores: those stay in flight
+            // (FT_PPS pieces per step: the slices of steps >= 8 / FT_PPS are the ones behind the last request)
+            constexpr int ST_AFTER = 4 * (6 - (8 / FT_PPS) < 0 ? 0 : (6 - (8 / FT_PPS) > 4 ? 4 : 6 - (8 / FT_PPS)));
+            if (u + 1 < C::NU) FT_VMCNT(16 + ST_AFTER);
+            else FT_VMCNT(16);
+            __syncthreads();
+            eb ^= 1;
+        }
+    }
+    // ---- conv1's epilogue: scale back, + bias, ReLU, flat position -> (t, y, x) of the zero-haloed consumer layout -------------------------
+    // its (1 / scale | bias) table: waves 0 / 1 put the MID scales / biases into the (idle) w3 buffer
+    static_assert(C::MID / 4 <= 64, "one lane per four channels");
+    if (wave < 2 && lane < C::MID / 4)
+        *reinterpret_cast<float4*>(w3buf + wave * (C::MID * 4) + lane * 16) = *reinterpret_cast<const float4*>((wave == 0 ? inv1 : p.b1) + lane * 4);
+    __syncthreads();
+    if (pos_ok) {
+        const int hwp = p.dec_H * p.dec_W;
+        const int t2 = pos / hwp, r2 = pos - t2 * hwp, y2 = r2 / p.dec_W, x2 = r2 - y2 * p.dec_W;
+        const unsigned int z_off = (unsigned int)(((int64_t)(4 * half) * p.z_cs + (int64_t)t2 * p.z_ts + (int64_t)y2 * p.z_ys + x2) * 4);      // bytes
+        const float* ttab = reinterpret_cast<const float*>(w3buf);
+#pragma unroll
+        for (int m1 = 0; m1 < C::MI1; ++m1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co4 = m1 * 32 + 8 * q + 4 * half;
+                const float4 sc = *reinterpret_cast<const float4*>(ttab + co4);
+                const float4 bv = *reinterpret_cast<const float4*>(ttab + C::MID + co4);
+                char* zo = reinterpret_cast<char*>(p.z + (int64_t)(m1 * 32 + 8 * q) * p.z_cs);     // (uniform)
+                *reinterpret_cast<float*>(zo + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 0], sc.x), bv.x));
+                *reinterpret_cast<float*>(zo + p.z_cs * 4 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 1], sc.y), bv.y));
+                *reinterpret_cast<float*>(zo + p.z_cs * 8 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 2], sc.z), bv.z));
+                *reinterpret_cast<float*>(zo + p.z_cs * 12 + (size_t)z_off) = relu_keep_nan(__fadd_rn(__fmul_rn(acc1[m1][4 * q + 3], sc.w), bv.w));
+            }
+    }
+}
+
+template <class C>
+static int launch_fused_r1_cfg(const FusedTailParams& p, hipStream_t s) {
+    const double flops = 2.0 * 2.0 * (double)C::MID * C::COUT * (double)p.V;
+    void* ev = profile_begin(19, flops, s);
+    hipLaunchKernelGGL(fused_tail_r1_kernel<C>, dim3((unsigned)ceil_div(p.V, C::P)), dim3(C::NTHREADS), 0, s, p);
+    profile_end(ev, s);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
 template <class C>
 static int launch_fused16_cfg(const FusedTailParams& p, hipStream_t s) {
     const double flops = 2.0 * 2.0 * (double)C::MID * C::COUT * (double)p.V;
@@ -667,7 +1019,7 @@ bool fused_tail_supported(int mid) { return mid == 64 || mid == 128 || mid == 25
 #endif
 
 int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const float* b3, const float* res, float* y, const float* w1, const float* b1,
-                      const StemsegVolume& z, int dec_H, int dec_W, int64_t V, hipStream_t s) {
+                      const StemsegVolume& z, int dec_H, int dec_W, int64_t V, int form, hipStream_t s) {
     SS_CHECK_ARG(x16 && w3 && b3 && res && y && w1 && b1 && z.ptr, "fused_tail: null pointer");
     SS_CHECK_ARG(fused_tail_supported(mid), "fused_tail: mid = %d (64, 128 or 256)", mid);
     SS_CHECK_ARG(V > 0 && V <= (1ll << 27) && z.c_stride <= (1ll << 27) && dec_H > 0 && dec_W > 0 && V % ((int64_t)dec_H * dec_W) == 0, "fused_tail: V = %lld positions of %d x %d planes",
@@ -688,7 +1040,13 @@ int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const f
 #if defined(SS_EXPERIMENTS) && defined(SS_FT_W32)
     if (mid == 256) return launch_fused_cfg<FusedTailCfg<256, 64, 128>>(p, s);
 #else
-    if (mid == 256) return launch_fused16_cfg<FusedTail16Cfg<256>>(p, s);
+    if (mid == 256) {
+        // form: 0 = the library's choice (the one-wave-per-SIMD form wherever its co-tile descriptors -- 128 V 4 bytes -- fit), 1 = the 16-column form, 2 = the
+        // one-wave-per-SIMD form
+        const bool r1_fits = (int64_t)128 * V * 4 < (1ll << 32) - (1 << 20);
+        if (form != 1 && r1_fits) return launch_fused_r1_cfg<FusedTailR1Cfg<256, 128>>(p, s);
+        return launch_fused16_cfg<FusedTail16Cfg<256>>(p, s);
+    }
 #endif
 #if defined(SS_EXPERIMENTS) && defined(SS_FT_W16_ALL)
     if (mid == 128) return launch_fused16_cfg<FusedTail16Cfg<128>>(p, s);

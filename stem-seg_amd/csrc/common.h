@@ -133,7 +133,7 @@ int launch_conv3d(const StemsegVolume& in, const float* packed_w, const float* b
 // conv3 of a bottleneck block (+ bias + identity + ReLU) and conv1 of the next (+ bias + ReLU) in one launch (bottleneck_fused.hip, f16x3)
 bool fused_tail_supported(int mid);
 int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const float* b3, const float* res, float* y, const float* w1, const float* b1,
-                      const StemsegVolume& z, int dec_H, int dec_W, int64_t V, hipStream_t s);
+                      const StemsegVolume& z, int dec_H, int dec_W, int64_t V, int form, hipStream_t s);
 int launch_gn_stats(const float* x, int C, int64_t S, int groups, float eps, float* stats, double* scratch, hipStream_t s);
 // conv + GroupNorm statistics of its output in one pass: the conv's epilogue (or its split-K reduce) leaves per-tile partial
 // sums in `gn_scratch` (>= gn_scratch_doubles(Cout, groups) doubles), one more tiny launch turns them into stats[2g] = mean,

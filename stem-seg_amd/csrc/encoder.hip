@@ -651,7 +651,7 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             if (want_fuse && p16_done) {
                 SS_CHECK_ARG(wts->conv1_w[bi + 1] && wts->conv1_b[bi + 1], "encoder_forward: null weights for block %d", bi + 1);
                 rc = launch_fused_tail(mid, reinterpret_cast<const unsigned int*>(ws + p.M2), wts->conv3_w[bi], wts->conv3_b[bi], idt, y, wts->conv1_w[bi + 1],
-                                       wts->conv1_b[bi + 1], interior2d_view(ws + p.M1[st], mid, T, h, w), h, w, V, s);
+                                       wts->conv1_b[bi + 1], interior2d_view(ws + p.M1[st], mid, T, h, w), h, w, V, (desc->fuse_tail >> 3) & 3, s);
                 if (rc) return rc;
                 conv1_done = true;
             } else {

@@ -17,6 +17,7 @@ ap.add_argument("--h", type=int, default=480)
 ap.add_argument("--w", type=int, default=864)
 ap.add_argument("--passes", type=int, default=6)
 ap.add_argument("--no-fuse", action="store_true")
+ap.add_argument("--fuse-tail", type=int, default=None, help="StemsegEncoderDesc.fuse_tail (7 | 8: stage 3 on the 16-column form, 7 | 16: on the one-wave-per-SIMD form)")
 ap.add_argument("--backbone", default="R-101-FPN")
 ap.add_argument("--precision", default="f16x3")
 a = ap.parse_args()
@@ -30,7 +31,7 @@ with torch.no_grad():
         if p_.dim() >= 2:
             p_.normal_(0, (2.0 / p_[0].numel()) ** 0.5)
 bb = bb.cuda()
-bb.fuse_tail = not a.no_fuse
+bb.fuse_tail = (not a.no_fuse) if a.fuse_tail is None else a.fuse_tail
 bb.precision = a.precision
 x = torch.randn(a.frames, 3, a.h, a.w, device="cuda") * 50
 outs = [torch.empty(256, a.frames, a.h // s, a.w // s, device="cuda") for s in (4, 8, 16, 32)]
