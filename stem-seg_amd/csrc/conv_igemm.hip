@@ -1517,6 +1517,11 @@ static int launch_cfg(ConvKParams p, hipStream_t s, float* scratch, int64_t scra
         const int64_t plan_scratch = plan ? plan->scratch_floats : scratch_floats / p.nb;      // (a clip batch decides on one clip's share)
         const int64_t wg_target = (C::X6 && C::NWAVES >= 8) ? 320 : 640;
         while (scratch && ksplit * 2 <= 16 && ksplit * 2 <= nchunks && wgs * ksplit * 2 <= wg_target && slab_plan * ksplit * 2 <= plan_scratch) ksplit *= 2;
+        // A launch asked for pair-plane output feeds a fused bottleneck tail, which only an UN-split launch can (bottleneck_fused.hip).  From half a
+        // round of workgroups on, splitting buys this launch nothing a one-round launch does not have (144 workgroups over the whole K take what
+        // 288 take over half of it on 256 CUs, minus the slab reduce), and costs the block its fused tail: 384 x 640 maps, layer 3 -- 167 us of
+        // conv3 + conv1 launches where the fused kernel runs one 94 %-full round.  Decided, like the split, on the planning shape.
+        if (p.out_p16 && C::F16 && wgs >= 128) ksplit = 1;
     }
     if (force_ksplit > 0) ksplit = (scratch && (int64_t)p.nb * force_ksplit * slab <= scratch_floats) ? std::min(force_ksplit, nchunks) : 1;
     p.chunks_per_split = (int)ceil_div(nchunks, ksplit);

@@ -318,6 +318,16 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const float* __restrict
     }
 }
 
+// The bilinear blend of the FPN top-down path with its rounding steps spelled out -- fma(1 - wx, c[x0], wx c[x1]) per coarse row, then
+// fma(1 - wy, row0, wy row1): what the compiler's contraction made of the plain expression, fixed here so that the three forms below agree by
+// construction, not by the optimiser's choice (the two-row form shares the row blends between two outputs: a value with two uses contracts
+// differently).
+__device__ __forceinline__ float up2_blend(const float c00, const float c01, const float c10, const float c11, const float wx, const float wy) {
+    const float h0 = __fmaf_rn(1.f - wx, c00, __fmul_rn(wx, c01));
+    const float h1 = __fmaf_rn(1.f - wx, c10, __fmul_rn(wx, c11));
+    return __fmaf_rn(1.f - wy, h0, __fmul_rn(wy, h1));
+}
+
 // FPN top-down path (fpn.py:64-66): fine += bilinear_x2(coarse), both zero-haloed 2-D layouts, align_corners = False
 __global__ __launch_bounds__(256) void upsample2x_add_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int64_t planes, int H, int W,
                                                               int64_t f_ts, int64_t f_pitch, int64_t c_ts, int64_t c_pitch) {
@@ -335,9 +345,9 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(float* __restrict__
         const int y1 = y0 + (y0 < Hc - 1 ? 1 : 0), x1 = x0 + (x0 < Wc - 1 ? 1 : 0);
         const float wy = sy - (float)y0, wx = sx - (float)x0;
         const float* c = coarse + pl * c_ts;
-        const float v = (1.f - wy) * ((1.f - wx) * c[y0 * c_pitch + x0] + wx * c[y0 * c_pitch + x1]) +
-                        wy * ((1.f - wx) * c[y1 * c_pitch + x0] + wx * c[y1 * c_pitch + x1]);
-        fine[pl * f_ts + (int64_t)y * f_pitch + x] += v;
+        const float v = up2_blend(c[y0 * c_pitch + x0], c[y0 * c_pitch + x1], c[y1 * c_pitch + x0], c[y1 * c_pitch + x1], wx, wy);
+        float* fo = fine + pl * f_ts + (int64_t)y * f_pitch + x;
+        *fo = __fadd_rn(*fo, v);
     }
 }
 
@@ -372,10 +382,53 @@ __global__ __launch_bounds__(256) void upsample2x_add_vec4_kernel(float* __restr
         sx = sx < 0.f ? 0.f : sx;
         const int x0 = (int)sx, x1 = x0 + (x0 < Wc - 1 ? 1 : 0);
         const float wx = sx - (float)x0;
-        const float v = (1.f - wy) * ((1.f - wx) * c0[x0] + wx * c0[x1]) + wy * ((1.f - wx) * c1[x0] + wx * c1[x1]);
-        fv[j] += v;
+        fv[j] = __fadd_rn(fv[j], up2_blend(c0[x0], c0[x1], c1[x0], c1[x1], wx, wy));
     }
     *fp = f;
+}
+
+// Two fine rows per thread: rows 2m - 1 and 2m interpolate between the SAME coarse rows (m - 1, m), and the four columns of an aligned group
+// between coarse columns 2k - 1, 2k, 2k + 1: six coarse loads, two 16-byte loads and two 16-byte stores for eight outputs, where the one-row form
+// issues eighteen memory instructions for four (it re-loads all four corners per output).  m = 0 holds row 0 alone (its row - 1 does not exist), m = Hc
+// row H - 1 alone.  Every output goes through up2_blend with the (x0, x1, wx) / (y0, y1, wy) the scalar form computes for it -- for even H and W
+// these are exact quarters: x = 2n + 1 -> (n, .25), x = 2n + 2 -> (n, .75), x = 0 -> (0, 0), clamped at the far edge -- so the bits are the scalar
+// form's.  n_items = planes x (H / 2 + 1) x groups per row.
+__global__ __launch_bounds__(256) void upsample2x_add_vec4x2_kernel(float* __restrict__ fine_halo, const float* __restrict__ coarse, int H, int W, unsigned gq,
+                                                                     unsigned n_items, int64_t f_ts, int f_pitch, int64_t c_ts, int c_pitch) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_items) return;
+    const int Hc = H / 2, Wc = W / 2;
+    const unsigned rowp = idx / gq;                          // plane * (Hc + 1) + m
+    const int k = (int)(idx - rowp * gq);
+    const unsigned pl = rowp / (unsigned)(Hc + 1);
+    const int m = (int)(rowp - pl * (unsigned)(Hc + 1));
+    const bool row_a = m >= 1, row_b = m < Hc;               // rows 2m - 1, 2m
+    const int y0 = m >= 1 ? m - 1 : 0, y1 = y0 + (y0 < Hc - 1 ? 1 : 0);
+    const float wy_a = 0.25f, wy_b = m >= 1 ? 0.75f : 0.f;
+    const float* c0 = coarse + (int64_t)pl * c_ts + (int64_t)y0 * c_pitch;
+    const float* c1 = coarse + (int64_t)pl * c_ts + (int64_t)y1 * c_pitch;
+    const int xa = min(max(2 * k - 1, 0), Wc - 1), xb = min(2 * k, Wc - 1), xc = min(2 * k + 1, Wc - 1);
+    const float a0 = c0[xa], b0 = c0[xb], d0 = c0[xc], a1 = c1[xa], b1 = c1[xb], d1 = c1[xc];
+    float* fbase = fine_halo + (int64_t)pl * f_ts + 4 * k;
+    float4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+    if (row_a) fa = *reinterpret_cast<const float4*>(fbase + (int64_t)(2 * m) * f_pitch);            // (row y sits at haloed row y + 1)
+    if (row_b) fb = *reinterpret_cast<const float4*>(fbase + (int64_t)(2 * m + 1) * f_pitch);
+    float* va = reinterpret_cast<float*>(&fa);
+    float* vb = reinterpret_cast<float*>(&fb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = 4 * k - 1 + j;
+        if (x < 0 || x >= W) continue;
+        // corners (c[x0], c[x1]) of the two coarse rows and wx: j = 0, 1 -> columns (2k - 1, 2k), j = 2, 3 -> (2k, 2k + 1); x = 0 -> (0, 1) with wx = 0
+        const bool first = j < 2 && x > 0;
+        const float p0 = first ? a0 : (x == 0 ? a0 : b0), p1 = first ? b0 : d0;
+        const float q0 = first ? a1 : (x == 0 ? a1 : b1), q1 = first ? b1 : d1;
+        const float wx = x == 0 ? 0.f : ((x & 1) ? 0.25f : 0.75f);
+        if (row_a) va[j] = __fadd_rn(va[j], up2_blend(p0, p1, q0, q1, wx, wy_a));
+        if (row_b) vb[j] = __fadd_rn(vb[j], up2_blend(p0, p1, q0, q1, wx, wy_b));
+    }
+    if (row_a) *reinterpret_cast<float4*>(fbase + (int64_t)(2 * m) * f_pitch) = fa;
+    if (row_b) *reinterpret_cast<float4*>(fbase + (int64_t)(2 * m + 1) * f_pitch) = fb;
 }
 
 static int grid1d(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 256 * 16)); }
@@ -681,7 +734,13 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
             void* ev = profile_begin(50, 4.0 * 256.0 * (2.0 * p.V[k] + p.V[k + 1]), s);         // fine read + written, coarse read
             const unsigned gq = (unsigned)((w + 1) / 4 + 1);                              // aligned groups covering haloed columns 1 .. w
             const int64_t ua_items = (int64_t)256 * T * h * gq;
-            if (gf.pitch % 4 == 0 && (int64_t)4 * gq <= gf.pitch && ua_items < (1ll << 32) - 256 && (reinterpret_cast<uintptr_t>(ws + p.L[k]) % 16 == 0) && gf.ts % 4 == 0)
+            const bool ua_vec = gf.pitch % 4 == 0 && (int64_t)4 * gq <= gf.pitch && ua_items < (1ll << 32) - 256 && (reinterpret_cast<uintptr_t>(ws + p.L[k]) % 16 == 0) && gf.ts % 4 == 0;
+            static const bool ua_two_rows = [] { const char* e = getenv("STEMSEG_FPN_ADD_ROWS"); return !(e && e[0] == '1'); }();      // (A/B switch; default: two rows per thread)
+            const int64_t ua2_items = (int64_t)256 * T * (h / 2 + 1) * gq;
+            if (ua_vec && ua_two_rows && h % 2 == 0 && w % 2 == 0 && p.h[k + 1] == h / 2 && p.w[k + 1] == w / 2)
+                hipLaunchKernelGGL(upsample2x_add_vec4x2_kernel, dim3((unsigned)ceil_div(ua2_items, 256)), dim3(256), 0, s, ws + p.L[k],
+                                   (const float*)(ws + p.L[k + 1] + gc.interior), h, w, gq, (unsigned)ua2_items, gf.ts, (int)gf.pitch, gc.ts, (int)gc.pitch);
+            else if (ua_vec)
                 hipLaunchKernelGGL(upsample2x_add_vec4_kernel, dim3((unsigned)ceil_div(ua_items, 256)), dim3(256), 0, s, ws + p.L[k],
                                    (const float*)(ws + p.L[k + 1] + gc.interior), h, w, gq, (unsigned)ua_items, gf.ts, (int)gf.pitch, gc.ts, (int)gc.pitch);
             else

@@ -134,25 +134,35 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
     return rc;
 }
 
-// flags[b] = 1 when chunk b of x holds a non-finite value, else 0 -- every flag is (re)written by every launch (no reset, no atomics)
-__global__ __launch_bounds__(256) void nonfinite_flags_kernel(const float* __restrict__ x, long long n, int* __restrict__ flags) {
+// flags[b] = 1 when chunk b of x holds a non-finite value, else 0 -- every flag is (re)written by every launch (no reset, no atomics).
+// One workgroup of 1024 threads per chunk, four 16-byte loads in flight per thread: n_flags workgroups are all the parallelism there is (64
+// per head output), and with one load per thread in flight a 20 MB class-logit volume (41 classes, 384 x 640) took 310 us per call -- 7 % of a
+// YouTube-VIS step.
+__global__ __launch_bounds__(1024) void nonfinite_flags_kernel(const float* __restrict__ x, long long n, int* __restrict__ flags) {
     const long long per = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    int bad = 0;
-    auto test = [&](const float v) { bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; };      // exponent all ones: inf or NaN
-    // 16-B loads over the aligned middle of the chunk (64 blocks scan a whole head output: scalar loads made this 15 us per call)
+    unsigned int bad = 0;
+    auto test = [&](const float v) { bad |= (unsigned int)((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u); };      // exponent all ones: inf or NaN
     long long a = lo + ((4 - (((reinterpret_cast<uintptr_t>(x) >> 2) + lo) & 3)) & 3);
     if (a > hi) a = hi;
     const long long n4 = (hi - a) / 4;
-    for (long long i = lo + threadIdx.x; i < a; i += 256) test(x[i]);
+    for (long long i = lo + threadIdx.x; i < a; i += 1024) test(x[i]);
     const float4* x4 = reinterpret_cast<const float4*>(x + a);
-    for (long long i = threadIdx.x; i < n4; i += 256) {
+    long long i = threadIdx.x;
+    for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+        const float4 v0 = x4[i], v1 = x4[i + 1024], v2 = x4[i + 2048], v3 = x4[i + 3072];
+        test(v0.x); test(v0.y); test(v0.z); test(v0.w);
+        test(v1.x); test(v1.y); test(v1.z); test(v1.w);
+        test(v2.x); test(v2.y); test(v2.z); test(v2.w);
+        test(v3.x); test(v3.y); test(v3.z); test(v3.w);
+    }
+    for (; i < n4; i += 1024) {
         const float4 v = x4[i];
         test(v.x); test(v.y); test(v.z); test(v.w);
     }
-    for (long long i = a + 4 * n4 + threadIdx.x; i < hi; i += 256) test(x[i]);
-    bad = __syncthreads_or(bad);
-    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 1 : 0;
+    for (long long k = a + 4 * n4 + threadIdx.x; k < hi; k += 1024) test(x[k]);
+    const int any = __syncthreads_or((int)bad);
+    if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1 : 0;
 }
 
 }  // namespace stemseg
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256) void nonfinite_flags_kernel(const float* __res
 extern "C" int stemseg_hip_nonfinite_flags(const float* x, int64_t n, int32_t* flags, int32_t n_flags, void* stream) {
     using namespace stemseg;
     SS_CHECK_ARG(flags && n >= 0 && n_flags >= 1 && n_flags <= 4096 && (x || n == 0), "nonfinite_flags: bad arguments");
-    hipLaunchKernelGGL(nonfinite_flags_kernel, dim3((unsigned)n_flags), dim3(256), 0, as_stream(stream), x, (long long)n, flags);
+    hipLaunchKernelGGL(nonfinite_flags_kernel, dim3((unsigned)n_flags), dim3(1024), 0, as_stream(stream), x, (long long)n, flags);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
