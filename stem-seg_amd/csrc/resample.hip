@@ -113,6 +113,78 @@ __global__ __launch_bounds__(256) void upsample_vec4_kernel(UpParams p, unsigned
         make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// Block form of the (1 | 2, 2, 2) up-samplings of the decoders: one thread = output rows 2 my - 1 and 2 my (they interpolate between the SAME two
+// input rows) of output planes 2 mt - 1 and 2 mt (ST = 2: the same two input planes; ST = 1: one plane) x 4 columns -- sixteen loads for four
+// (ST = 1: two) 16-byte stores, where the one-row form issues sixteen loads per store: the x2 up-sampling of a 60 x 108 map was bound by its
+// load instructions, not by its bytes (2.2 TB/s).  Indices and weights come from src_index() per output, every lerp is the scalar kernel's
+// fma(a, wa, round(b * wb)): the same bits.  my = 0 holds row 0 alone, my = H row 2 H - 1 alone; likewise the planes.  grid.y = (channel, mt).
+template <int ST>
+__global__ __launch_bounds__(256) void upsample2_blk_kernel(UpParams p, unsigned wq, unsigned n_items) {
+    static_assert(ST == 1 || ST == 2, "temporal scale 1 or 2");
+    const unsigned item = blockIdx.x * 256u + threadIdx.x;
+    if (item >= n_items) return;
+    p.in += (int64_t)blockIdx.z * p.in_bs; p.out += (int64_t)blockIdx.z * p.out_bs;
+    constexpr int NP = ST;                                    // output planes per thread
+    const int ntp = ST == 2 ? p.T + 1 : p.To;
+    const int c = blockIdx.y / ntp, mt = blockIdx.y - c * ntp;
+    const int my = (int)(item / wq), j = (int)(item - (unsigned)my * wq);
+    int to_[NP], yo_[2];
+    bool tv[NP], yv[2];
+    if (ST == 2) { to_[0] = 2 * mt - 1; to_[NP - 1] = 2 * mt; tv[0] = mt >= 1; tv[NP - 1] = mt < p.T; }
+    else { to_[0] = mt; tv[0] = true; }
+    yo_[0] = 2 * my - 1; yo_[1] = 2 * my; yv[0] = my >= 1; yv[1] = my < p.H;
+    int t0 = 0, t1 = 0, y0 = 0, y1 = 0;
+    float wt[NP], wy[2];
+#pragma unroll
+    for (int a = NP - 1; a >= 0; --a) {
+        wt[a] = 0.f;
+        if (tv[a]) src_index(to_[a], p.rt, p.T, t0, t1, wt[a]);      // (both valid: the same (t0, t1))
+    }
+#pragma unroll
+    for (int b = 1; b >= 0; --b) {
+        wy[b] = 0.f;
+        if (yv[b]) src_index(yo_[b], p.ry, p.H, y0, y1, wy[b]);
+    }
+    const int HW = p.H * p.W;
+    const float* base = p.in + (int64_t)c * p.T * HW;
+    const float* rows[4] = {base + t0 * HW + y0 * p.W, base + t0 * HW + y1 * p.W, base + t1 * HW + y0 * p.W, base + t1 * HW + y1 * p.W};
+    const int xb = 2 * j - 1;                                 // first input column this thread needs
+    float v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = min(max(xb + k, 0), p.W - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r][k] = rows[r][xx];
+    }
+    auto lerp = [](float a, float wa, float b2, float wb) { return __fmaf_rn(a, wa, __fmul_rn(b2, wb)); };
+    float r00[4], r01[4], r10[4], r11[4];                     // the x lerps: shared by the rows / planes of the block
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x0, x1;
+        float wx;
+        src_index(4 * j + k, p.rx, p.W, x0, x1, wx);
+        const float ux = __fsub_rn(1.f, wx);
+        constexpr int r2[4] = {0, 1, 1, 2};                   // position of x0 in v[]: outputs 0, 1, 2, 3 start at 2j - 1, 2j, 2j, 2j + 1
+        const int i0 = r2[k];
+        r00[k] = lerp(v[0][i0], ux, v[0][i0 + 1], wx); r01[k] = lerp(v[1][i0], ux, v[1][i0 + 1], wx);
+        r10[k] = lerp(v[2][i0], ux, v[2][i0 + 1], wx); r11[k] = lerp(v[3][i0], ux, v[3][i0 + 1], wx);
+    }
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+        if (!tv[a]) continue;
+        const float ut = __fsub_rn(1.f, wt[a]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (!yv[b]) continue;
+            const float uy = __fsub_rn(1.f, wy[b]);
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = lerp(lerp(r00[k], uy, r01[k], wy[b]), ut, lerp(r10[k], uy, r11[k], wy[b]), wt[a]);
+            *reinterpret_cast<float4*>(p.out + (int64_t)c * p.out_cs + (int64_t)to_[a] * p.out_ts + (int64_t)yo_[b] * p.out_ys + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 struct CopyParams {
     const float* in;
     float* out;
@@ -152,7 +224,13 @@ int launch_upsample(const float* in, int C, int T, int H, int W, int st, int sy,
     const bool vec = (sx == 2 || sx == 4) && p.Wo % 4 == 0 && (int64_t)C * p.To <= 65535 && (int64_t)T * H * W < (1ll << 31) &&
                      (int64_t)p.Ho * p.Wo < (1ll << 32) && (reinterpret_cast<uintptr_t>(out.ptr) % 16 == 0) && out.c_stride % 4 == 0 &&
                      out.t_stride % 4 == 0 && out.y_stride % 4 == 0;
-    if (vec) {
+    static const bool blk_on = [] { const char* e = getenv("STEMSEG_UPSAMPLE_BLK"); return !(e && e[0] == '0'); }();      // (A/B switch; default on)
+    if (vec && blk_on && sx == 2 && sy == 2 && (st == 1 || st == 2) && (int64_t)C * (st == 2 ? T + 1 : p.To) <= 65535) {
+        const unsigned wq = (unsigned)(p.Wo / 4), items = wq * (unsigned)(H + 1);
+        const dim3 grid((unsigned)ceil_div(items, 256), (unsigned)(C * (st == 2 ? T + 1 : p.To)), (unsigned)cb.nb);
+        if (st == 2) hipLaunchKernelGGL(upsample2_blk_kernel<2>, grid, dim3(256), 0, s, p, wq, items);
+        else hipLaunchKernelGGL(upsample2_blk_kernel<1>, grid, dim3(256), 0, s, p, wq, items);
+    } else if (vec) {
         const unsigned wq = (unsigned)(p.Wo / 4), items = wq * (unsigned)p.Ho;
         const dim3 grid((unsigned)ceil_div(items, 256), (unsigned)(C * p.To), (unsigned)cb.nb);
         if (sx == 2) hipLaunchKernelGGL(upsample_vec4_kernel<2>, grid, dim3(256), 0, s, p, wq, items);
