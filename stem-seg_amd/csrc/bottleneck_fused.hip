@@ -664,9 +664,6 @@ typedef __amdgpu_buffer_rsrc_t ft_rsrc_t;
 #else
 #define FT_VMCNT(n) FT_VMCNT_(n)
 #endif
-#ifndef FT_PPS
-#define FT_PPS 4           // DMA pieces per step
-#endif
 #define FT_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 template <int MID_, int CT_>
@@ -683,8 +680,13 @@ struct FusedTailR1Cfg {
     static constexpr int TAB_BYTES = 1024;
     static constexpr int LDS_BYTES = 2 * W3_BYTES + 2 * W1_BYTES + 2 * TAB_BYTES;
     static constexpr int W3_PIECES = W3_BYTES / 1024 / NW, W1_PIECES = W1_BYTES / 1024 / NW;
+    // a conv1 k-step of NX1 steps carries the next tile's epilogue: SL slices (rows 8 q4 ..) per step from step S0 on, the lane exchanges behind them;
+    // the requests of the next stage go out in the steps before S0, M_PPS pieces per step (MID = 256: 8 steps -- requests 0-1, slices 2-5, exchanges
+    // 6-7; MID = 128: 4 steps -- requests 0, slices 1-2, exchanges 3)
+    static constexpr int SL = 8 / NX1, S0 = NX1 / 4, M_PPS = 8 / S0;
     static_assert(NC3 % SC == 0 && MI3 % 2 == 0 && MI1 % 2 == 0 && W3_BYTES % (1024 * NW) == 0 && W1_BYTES % (1024 * NW) == 0 && 2 * CT * 4 <= TAB_BYTES, "whole DMA pieces per wave");
-    static_assert(LDS_BYTES <= 160 * 1024 && 2 * MID * 4 <= W3_BYTES && NX1 >= 8 && NX3 >= 3 && NU >= 2 && NU % 2 == 0, "LDS / slice placement / identity buffer parity");
+    static_assert(LDS_BYTES <= 160 * 1024 && 2 * MID * 4 <= W3_BYTES && (NX1 == 8 || NX1 == 4) && NX3 == 8 && NU >= 2 && NU % 2 == 0, "LDS / slice placement / identity buffer parity");
+    static_assert(W3_PIECES == 8 && W1_PIECES <= 8, "the pieces of a stage are requested in its first steps");
     static_assert(NG * 8 + MI1 * 16 <= 256, "the conv3 input and conv1's accumulators are the AGPR half of the register file");
 };
 
@@ -735,7 +737,6 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void fused_tail_r1_kernel(const Fus
         const int idx = wave + k * C::NW;
         dma_piece(p.w1 + (int64_t)cc * C::W1_BYTES + (int64_t)idx * 1024, lds_w1 + buf * C::W1_BYTES + idx * 1024);
     };
-    static_assert(C::W3_PIECES == 8 && C::W1_PIECES == 8, "the pieces of a stage are requested in its first two steps, four each");
     // co-tile j's (1 / scale | bias) table: lanes 0 .. CT / 4 - 1 of wave 0 fetch the scales, the next CT / 4 the biases (an ordinary load at the
     // top of conv3's last stage), and store them at its end
     float4 tabv = {0.f, 0.f, 0.f, 0.f};
@@ -828,11 +829,11 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void fused_tail_r1_kernel(const Fus
 #pragma unroll
             for (int s = 0; s < C::NX3; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (s < 8 / FT_PPS) {                        // what the next stage reads, FT_PPS pieces in each of the first steps
+                if (s < 2) {                                 // what the next stage reads, four pieces in each of the first two steps
 #pragma unroll
-                    for (int k = FT_PPS * s; k < FT_PPS * s + FT_PPS; ++k) {
+                    for (int k = 4 * s; k < 4 * s + 4; ++k) {
                         if (st + 1 < C::NS) dma_w3(j, st + 1, sb ^ 1, k);
-                        else dma_w1(j * C::NU, eb, k);
+                        else if (k < C::W1_PIECES) dma_w1(j * C::NU, eb, k);
                     }
                 }
                 if (s + 2 < C::NX3) ld3(s + 2, (s + 2) % 3);
@@ -918,37 +919,39 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void fused_tail_r1_kernel(const Fus
 #pragma unroll
             for (int s = 0; s < C::NX1; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
-                // Steps 0-1: what the next stage reads.  Step 2: the identity rows of tile u + 2 (tile u's buffer: its epilogue ran a stage ago) -- a
-                // stage ahead of the slices that add them, and BEHIND this stage's requests, so that the counted wait leaves them in flight.
-                // Steps 2-5: the next tile's epilogue, rows 8 (s - 2) .. per step; steps 6-7: its two lane exchanges.
-                if (s < 8 / FT_PPS) {
+                // Steps before S0: what the next stage reads.  Step S0: the identity rows of tile u + 2 (tile u's buffer: its epilogue ran a stage ago) --
+                // a stage ahead of the slices that add them, and BEHIND this stage's requests, so that the counted wait leaves them in flight.
+                // From step S0: the next tile's epilogue, SL slices (rows 8 q4 ..) per step; behind them its two lane exchanges.
+                if (s < C::S0) {
 #pragma unroll
-                    for (int k = FT_PPS * s; k < FT_PPS * s + FT_PPS; ++k) {
-                        if (u + 1 < C::NU) dma_w1(j * C::NU + u + 1, eb ^ 1, k);
+                    for (int k = C::M_PPS * s; k < C::M_PPS * s + C::M_PPS; ++k) {
+                        if (u + 1 < C::NU) { if (k < C::W1_PIECES) dma_w1(j * C::NU + u + 1, eb ^ 1, k); }
                         else if (j + 1 < C::NCT) dma_w3(j + 1, 0, sb, k);
                     }
                 }
-                if (s == (8 / FT_PPS < 7 ? 8 / FT_PPS : 7)) load_identity(u + 2 < C::NU ? j : min(j + 1, C::NCT - 1), (u + 2) % C::NU, rres[u & 1]);      // (past the last tile: the last co-tile's rows again, never used)
+                if (s == C::S0) load_identity(u + 2 < C::NU ? j : min(j + 1, C::NCT - 1), (u + 2) % C::NU, rres[u & 1]);      // (past the last tile: the last co-tile's rows again, never used)
                 if (s + 2 < C::NX1) ld1(s + 2, (s + 2) % 3);
                 if (s + 1 < C::NX1) {
                     a_his[(s + 1) & 1][0] = a_hi[(s + 1) % 3][0] * k2048;
                     a_his[(s + 1) & 1][1] = a_hi[(s + 1) % 3][1] * k2048;
                 }
                 if (u + 1 < C::NU) {
-                    if (s >= 2 && s < 6) e_slice(u + 1, s - 2);
-                    else if (s == 6) e_perm(0, b_hi[(u + 1) & 1][0], b_lo[(u + 1) & 1][0]);
-                    else if (s == 7) e_perm(1, b_hi[(u + 1) & 1][1], b_lo[(u + 1) & 1][1]);
+                    constexpr int SE = C::S0 + 4 / C::SL;     // first step behind the slices
+                    if (s >= C::S0 && s < SE) {
+#pragma unroll
+                        for (int q = 0; q < C::SL; ++q) e_slice(u + 1, (s - C::S0) * C::SL + q);
+                    }
+                    if (C::SL == 1 ? s == SE : s == SE) e_perm(0, b_hi[(u + 1) & 1][0], b_lo[(u + 1) & 1][0]);
+                    if (C::SL == 1 ? s == SE + 1 : s == SE) e_perm(1, b_hi[(u + 1) & 1][1], b_lo[(u + 1) & 1][1]);
                 }
                 const int g = s / (C::MI1 / 2), mp = s % (C::MI1 / 2);
                 mma6(acc1[2 * mp], acc1[2 * mp + 1], a_hi[s % 3], a_lo[s % 3], a_his[s & 1], b_hi[u & 1][g], b_lo[u & 1][g]);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { FT_SGB(0x008, 1); FT_SGB(0x100, 1); FT_SGB(0x002, 7); FT_SGB(0x040, 1); FT_SGB(0x020, 3); }
+                for (int i = 0; i < 6; ++i) { FT_SGB(0x008, 1); FT_SGB(0x100, 1); FT_SGB(0x002, 7 * C::SL); FT_SGB(0x040, C::SL); FT_SGB(0x020, 3); }
             }
             __builtin_amdgcn_sched_barrier(0);
             // behind the requests of steps 0-1 this stage issued 16 identity loads and, if it carried an epilogue, 16 output stores: those stay in flight
-            // (FT_PPS pieces per step: the slices of steps >= 8 / FT_PPS are the ones behind the last request)
-            constexpr int ST_AFTER = 4 * (6 - (8 / FT_PPS) < 0 ? 0 : (6 - (8 / FT_PPS) > 4 ? 4 : 6 - (8 / FT_PPS)));
-            if (u + 1 < C::NU) FT_VMCNT(16 + ST_AFTER);
+            if (u + 1 < C::NU) FT_VMCNT(32);
             else FT_VMCNT(16);
             __syncthreads();
             eb ^= 1;
@@ -1052,8 +1055,12 @@ int launch_fused_tail(int mid, const unsigned int* x16, const float* w3, const f
     if (mid == 128) return launch_fused16_cfg<FusedTail16Cfg<128>>(p, s);
     return launch_fused16_cfg<FusedTail16Cfg<64>>(p, s);
 #endif
-    if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, 64, 128>>(p, s);
-    return launch_fused_cfg<FusedTailCfg<64, 64, 128>>(p, s);
+#ifndef SS_FT_CT12
+#define SS_FT_CT12 128    // co-tile of the 32-column form (stages 1-2): 128 channels halve the re-reads of the input tile (229 / 196 registers, 80 / 72 KB: still two workgroups per CU); stage 2 335 -> 303 us, stage 1 510 -> 495
+#endif
+    if (mid == 128 && form != 1 && (int64_t)128 * V * 4 < (1ll << 32) - (1 << 20)) return launch_fused_r1_cfg<FusedTailR1Cfg<128, 128>>(p, s);
+    if (mid == 128) return launch_fused_cfg<FusedTailCfg<128, SS_FT_CT12, 128>>(p, s);
+    return launch_fused_cfg<FusedTailCfg<64, SS_FT_CT12, 128>>(p, s);
 #endif
 }
 
