@@ -685,7 +685,7 @@ struct FusedTailR1Cfg {
     // 6-7; MID = 128: 4 steps -- requests 0, slices 1-2, exchanges 3)
     static constexpr int SL = 8 / NX1, S0 = NX1 / 4, M_PPS = 8 / S0;
     static_assert(NC3 % SC == 0 && MI3 % 2 == 0 && MI1 % 2 == 0 && W3_BYTES % (1024 * NW) == 0 && W1_BYTES % (1024 * NW) == 0 && 2 * CT * 4 <= TAB_BYTES, "whole DMA pieces per wave");
-    static_assert(LDS_BYTES <= 160 * 1024 && 2 * MID * 4 <= W3_BYTES && (NX1 == 8 || NX1 == 4) && NX3 == 8 && NU >= 2 && NU % 2 == 0, "LDS / slice placement / identity buffer parity");
+    static_assert(LDS_BYTES <= 160 * 1024 && 2 * MID * 4 <= W3_BYTES && (NX1 == 8 || NX1 == 4) && NX3 == 8 && MI3 == 4 && NS >= 2 && NU >= 2 && NU % 2 == 0, "LDS / slice placement / identity buffer parity");
     static_assert(W3_PIECES == 8 && W1_PIECES <= 8, "the pieces of a stage are requested in its first steps");
     static_assert(NG * 8 + MI1 * 16 <= 256, "the conv3 input and conv1's accumulators are the AGPR half of the register file");
 };
@@ -808,51 +808,7 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void fused_tail_r1_kernel(const Fus
         for (int m = 0; m < C::MI3; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[m][r] = 0.f;
-        // ---- conv3: NS stages of SC chunks ------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int st = 0; st < C::NS; ++st) {
-            if (st + 1 == C::NS) tab_fetch(j);
-            const char* wb = w3buf + sb * C::W3_BYTES + (half * C::CT + l31) * 16;
-            f16x8 a_hi[3][2], a_lo[3][2], a_his[2][2];
-            auto ld3 = [&](const int s, const int k) __attribute__((always_inline)) {
-                const int sc = s / (C::NX3 / C::SC), g = (s / (C::MI3 / 2)) & 1, mp = s % (C::MI3 / 2);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    a_hi[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (((g * 2 + 0) * 2) * C::CT + (2 * mp + e) * 32) * 16);
-                    a_lo[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (((g * 2 + 1) * 2) * C::CT + (2 * mp + e) * 32) * 16);
-                }
-            };
-            ld3(0, 0);
-            ld3(1, 1);
-            a_his[0][0] = a_hi[0][0] * k2048;
-            a_his[0][1] = a_hi[0][1] * k2048;
-#pragma unroll
-            for (int s = 0; s < C::NX3; ++s) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (s < 2) {                                 // what the next stage reads, four pieces in each of the first two steps
-#pragma unroll
-                    for (int k = 4 * s; k < 4 * s + 4; ++k) {
-                        if (st + 1 < C::NS) dma_w3(j, st + 1, sb ^ 1, k);
-                        else if (k < C::W1_PIECES) dma_w1(j * C::NU, eb, k);
-                    }
-                }
-                if (s + 2 < C::NX3) ld3(s + 2, (s + 2) % 3);
-                if (s + 1 < C::NX3) {
-                    a_his[(s + 1) & 1][0] = a_hi[(s + 1) % 3][0] * k2048;
-                    a_his[(s + 1) & 1][1] = a_hi[(s + 1) % 3][1] * k2048;
-                }
-                const int sc = s / (C::NX3 / C::SC), g = (s / (C::MI3 / 2)) & 1, mp = s % (C::MI3 / 2), G = 2 * (st * C::SC + sc) + g;
-                mma6(acc3[2 * mp], acc3[2 * mp + 1], a_hi[s % 3], a_lo[s % 3], a_his[s & 1], xh[G], xl[G]);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) { FT_SGB(0x008, 1); FT_SGB(0x100, 1); FT_SGB(0x002, 2); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            FT_VMCNT(0);                                     // (this stage issued nothing behind its requests; older loads / stores have had a stage)
-            if (st + 1 == C::NS) tab_store(j);
-            __syncthreads();
-            sb ^= 1;
-        }
-        // ---- epilogue slices + conv1's k-steps ---------------------------------------------------------------------------------------------
+        // ---- the epilogue's pieces (used from conv3's last stage on) -----------------------------------------------------------------------
         const float* tab = reinterpret_cast<const float*>(tabbuf + (j & 1) * C::TAB_BYTES) + 4 * half;
         const ft_rsrc_t ry = rsrc_of(p.y, j);
         unsigned int hw[8], lw[8];
@@ -894,10 +850,59 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void fused_tail_r1_kernel(const Fus
             bh = __builtin_bit_cast(f16x8, bh4);
             bl = __builtin_bit_cast(f16x8, bl4);
         };
-        // tile 0 of the co-tile has nothing to hide behind: its accumulators were finished by the stage that just ended
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- conv3: NS stages of SC chunks ------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) e_slice(0, q4);
+        for (int st = 0; st < C::NS; ++st) {
+            if (st + 2 == C::NS) tab_fetch(j);
+            const char* wb = w3buf + sb * C::W3_BYTES + (half * C::CT + l31) * 16;
+            f16x8 a_hi[3][2], a_lo[3][2], a_his[2][2];
+            auto ld3 = [&](const int s, const int k) __attribute__((always_inline)) {
+                const int mp = s / (2 * C::SC), sc = (s % (2 * C::SC)) / 2, g = s % 2;      // tile pair outermost: tiles 0-1 are finished half a stage early
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    a_hi[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (((g * 2 + 0) * 2) * C::CT + (2 * mp + e) * 32) * 16);
+                    a_lo[k][e] = *reinterpret_cast<const f16x8*>(wb + sc * C::W3_CHUNK + (((g * 2 + 1) * 2) * C::CT + (2 * mp + e) * 32) * 16);
+                }
+            };
+            ld3(0, 0);
+            ld3(1, 1);
+            a_his[0][0] = a_hi[0][0] * k2048;
+            a_his[0][1] = a_hi[0][1] * k2048;
+#pragma unroll
+            for (int s = 0; s < C::NX3; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < 2) {                                 // what the next stage reads, four pieces in each of the first two steps
+#pragma unroll
+                    for (int k = 4 * s; k < 4 * s + 4; ++k) {
+                        if (st + 1 < C::NS) dma_w3(j, st + 1, sb ^ 1, k);
+                        else if (k < C::W1_PIECES) dma_w1(j * C::NU, eb, k);
+                    }
+                }
+                if (s + 2 < C::NX3) ld3(s + 2, (s + 2) % 3);
+                if (s + 1 < C::NX3) {
+                    a_his[(s + 1) & 1][0] = a_hi[(s + 1) % 3][0] * k2048;
+                    a_his[(s + 1) & 1][1] = a_hi[(s + 1) % 3][1] * k2048;
+                }
+                // the co-tile's LAST stage: tile 0 got its last products in step NX3 / 2 - 1 -- its epilogue, a slice per step, sits between the MFMAs of
+                // the other tile pair (nothing of it is left in front of conv1's first k-step but the two lane exchanges)
+                if (st + 1 == C::NS && s >= C::NX3 / 2) e_slice(0, s - C::NX3 / 2);
+                const int mp = s / (2 * C::SC), sc = (s % (2 * C::SC)) / 2, g = s % 2, G = 2 * (st * C::SC + sc) + g;
+                mma6(acc3[2 * mp], acc3[2 * mp + 1], a_hi[s % 3], a_lo[s % 3], a_his[s & 1], xh[G], xl[G]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    FT_SGB(0x008, 1); FT_SGB(0x100, 1);
+                    if (st + 1 == C::NS && s >= C::NX3 / 2) { FT_SGB(0x002, 7); FT_SGB(0x040, 1); }
+                    else FT_SGB(0x002, 2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 == C::NS) FT_VMCNT(16);               // (tile 0's 16 output stores stay in flight; otherwise nothing was issued behind the requests)
+            else FT_VMCNT(0);
+            if (st + 2 == C::NS) tab_store(j);
+            __syncthreads();
+            sb ^= 1;
+        }
+        // ---- conv1's k-steps, each carrying the next tile's epilogue ---------------------------------------------------------------------------
         e_perm(0, b_hi[0][0], b_lo[0][0]);
         e_perm(1, b_hi[0][1], b_lo[0][1]);
 #pragma unroll
