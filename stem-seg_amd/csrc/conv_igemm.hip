@@ -1445,6 +1445,10 @@ struct SplitTiles {
     // 120 x 216 maps (30 x 27 blocks), where the 16 x 32 tiles compute 128 x 224
     using Y3Blk = ConvCfg<3, 3, 3, 4, 4, 2, 1, 8, 3, false, BFV, false, 0, false, 5>;
     using Y2Blk = ConvCfg<1, 3, 3, CK2, 4, 2, 1, 8, 3, false, BFV, false, 0, false, 5>;
+    // the medium 3x3x3 tile's block form: 128 co x (4 rows x 56 columns) as 1 x 7 column blocks (the wave pair that would own the eighth block runs
+    // one) -- the decoders' 60 x 108 and 30 x 54 maps compute 60 x 112 / 32 x 56 positions instead of the 8-row x 32-column tile's 64 x 128 / 32 x 64
+    // (21 % junk -> 3.6 % / 9.6 %): under the power limit MFMAs not issued are time even where the round count stays (DESIGN.md sections 5f, 5h)
+    using Y3Blk7 = ConvCfg<3, 3, 3, 4, 2, 2, 2, 4, 7, false, BFV, false, 0, false, 1>;
     // Measured in round 5 and not kept (profiles/r05b_conv_sweep_f16x3_T32.txt, tile_cfg 6 / 7 / 8 of that build): four-wave halves of the
     // eight-wave tiles, two per CU so that one's staging phases run under the other's MFMA stream -- block_4x 1 076 vs 1 006 us, layer-3 3x3
     // 214 vs 203, 1024 -> 256 110 vs 107, 256 -> 1024 + residual 170 vs 154; and 64-channel chunks for the 1x1 tiles (half the chunk
@@ -1721,6 +1725,15 @@ static int launch_split_family(ConvKParams& p, const ConvKParams& d, const PlanC
     }
     if (k3) {
         if (cfg == 0) cfg = num_workgroups<Y3Big>(d) >= 384 ? 1 : (num_workgroups<Y3Med>(d) >= (scratch ? 32 : 256) ? 2 : 3);
+        if constexpr (BFV == 3) {
+            // where the medium tile is the choice and the map wastes > 6 % more of it than of 4-row x 56-column block tiles, take those (tile_cfg 7
+            // forces them; STEMSEG_BLK_TILES=0 switches all block tiles off).  Same k order per output: bit-identical to the 8 x 32 tile.
+            const double e_b7 = (double)p.H * p.W / ((double)ceil_div(p.H, 4) * 4 * ceil_div(p.W, 56) * 56);
+            const double e_med = (double)p.H * p.W / ((double)ceil_div(p.H, 8) * 8 * ceil_div(p.W, 32) * 32);
+            static const bool blk7_on = [] { const char* e = getenv("STEMSEG_BLK7"); return !(e && e[0] == '0'); }();      // (A/B switch; default on)
+            if (p.vec4 && (tile_cfg == 7 || (auto_cfg && cfg == 2 && blk_on && blk7_on && e_b7 > 1.06 * e_med)))
+                return launch_cfg<typename F::Y3Blk7>(p, s, scratch, scratch_floats, 0, pc);
+        }
         if (cfg == 1) return launch_cfg<Y3Big>(p, s, scratch, scratch_floats, 0, pc);
         if (cfg == 2) return launch_cfg<Y3Med>(p, s, scratch, scratch_floats, 0, pc);
         return launch_cfg<Y3Small>(p, s, scratch, scratch_floats, 0, pc);

@@ -401,6 +401,15 @@ def test_block_tiles_vs_fp64(hip, case):
     print("[f16x3] block tile %s: max|err| vs fp64 %.3e, 16 x 32 tile %.3e (max|ref| %.3g)" % (case, e_blk, e_2d, np.abs(want).max()))
     assert np.isfinite(outs[6][0]).all() and e_blk <= max(3.0 * e_2d, 4e-7 * np.abs(want).max())
     assert np.array_equal(outs[6][0], outs[6][1]), "run to run"
+    if kind == "k3" and form in ("plain", "relu+res"):
+        # the medium tile's block form (tile_cfg 7: 4 rows x 56 columns as 1 x 7 blocks, the eighth block missing): the same bits again
+        out7 = torch.full((Cout, T, H, W), float("nan"), device="cuda")
+        epi7 = dict(precision=SP)
+        if form == "relu+res":
+            epi7.update(relu=1, residual=dev(r), res_strides=(T * H * W, H * W, W))
+        hip.conv3d(vin, pw, dev(b), hip.dense_volume(out7), (kt, 3, 3), 7, None, epi7)
+        torch.cuda.synchronize()
+        assert np.array_equal(out7.cpu().numpy().astype(np.float64), outs[1][0]), "4 x 56 block tile vs the 16 x 32 tile"
     if form != "splitk":
         assert np.array_equal(outs[6][0], outs[1][0]), "same chunk order, same products: the block tile must reproduce the 16 x 32 tile bit for bit"
     if form == "gn":

@@ -43,7 +43,7 @@ rm -rf gpurun_out/prof_graph gpucore.*
 PREC=f16x3 ROUND=${R}_f16x3 bash tools/gpu_round.sh pmc 2>&1 | grep -v rocprofv3 | tail -6
 PREC=bf16x6 ROUND=${R}_bf16x6 bash tools/gpu_round.sh pmc 2>&1 | grep -v rocprofv3 | tail -4
 bash tools/pmc_step.sh > gpurun_out/${R}_pmc_whole_step_hbm.txt 2>&1; tail -8 gpurun_out/${R}_pmc_whole_step_hbm.txt
-KPAT="fused_tail16" bash tools/gpu_r6_pmc_kernel.sh ${R}_fused_tail16 > /dev/null 2>&1; head -40 gpurun_out/${R}_fused_tail16_pmc_kernel.txt
+KPAT="fused_tail_r1_kernel<stemseg::FusedTailR1Cfg<256" bash tools/gpu_r6_pmc_kernel.sh ${R}_fused_tail_r1 > /dev/null 2>&1; head -40 gpurun_out/${R}_fused_tail_r1_pmc_kernel.txt
 for wl in davis ytvis; do
   timeout 600 python tools/soak_probe.py --workload $wl --lanes 3 --reps ${SOAK_REPS:-200} > gpurun_out/${R}_soak_${wl}.txt 2>&1; echo "soak $wl exit $?"; tail -1 gpurun_out/${R}_soak_${wl}.txt | cut -c1-200
 done
