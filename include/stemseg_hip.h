@@ -228,7 +228,10 @@ typedef struct StemsegDecoderWeights {
     const float* conv_b[7];
     const float* gn_w[7];
     const float* gn_b[7];
-    const float* fuse_w[3];      /* conv_16, conv_8, conv_4 (1x1x1, no bias), packed layout */
+    const float* fuse_w[3];      /* conv_16, conv_8, conv_4 (1x1x1, no bias), packed layout.  fuse_w[2] = NULL: conv_4 is FOLDED into the heads --
+                                    head_w then holds W_heads . W_conv4 over the inter[2] + inter[3] channels of the last concat buffer (dense
+                                    [n_out][inter[2] + inter[3]], or the packed 1x1x1 weight with that Cin for a wide head) and the inter[3]-channel
+                                    map is never materialised (one linear map for two: within fp32 round-off of the two-step form) */
     const float* head_w;         /* [n_out][inter[3]] row-major */
     const float* head_b;         /* [n_out] (zero where the reference conv has no bias) */
     const float* grid_t;         /* [T], [H4], [W4] linspace vectors (may be NULL if no act uses the grid) */

@@ -358,7 +358,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
         return STEMSEG_E_WORKSPACE;
     }
     for (int i = 0; i < 7; ++i) SS_CHECK_ARG(wts->conv_w[i] && wts->conv_b[i] && wts->gn_w[i] && wts->gn_b[i], "decoder_forward: null block weight %d", i);
-    for (int i = 0; i < 3; ++i) SS_CHECK_ARG(wts->fuse_w[i], "decoder_forward: null fuse weight %d", i);
+    for (int i = 0; i < 2; ++i) SS_CHECK_ARG(wts->fuse_w[i], "decoder_forward: null fuse weight %d", i);      // (fuse_w[2] NULL: conv_4 folded into the heads, below)
     SS_CHECK_ARG(wts->head_w, "decoder_forward: null head weight");
     for (int i = 0; i < 4; ++i) SS_CHECK_ARG(feats[i], "decoder_forward: null feature map %d", i);
 
@@ -457,15 +457,24 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
                  p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision, nb, pin_bs[3], WS);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
-    if (rc) return rc;
+    // conv_4 (1x1x1, no bias, no activation: embedding_decoder.py:80,129) feeds nothing but the heads (1x1x1 as well): a caller that hands over
+    // head weights ALREADY MULTIPLIED by conv_4's -- head_w = W_heads . W_conv4, [n_out][c8 + c4], fuse_w[2] = NULL -- gets the heads straight off
+    // the concat buffer: the c4-channel map (106 MB per clip at 480p) is neither computed, written nor read back.  One linear map instead of two:
+    // the same fold as FrozenBN into its convolution, results within fp32 round-off of the two-step form.
+    const bool fold4 = wts->fuse_w[2] == nullptr;
+    const float* head_in = fold4 ? ws + p.cat4 : ws + p.X4;
+    const int head_cin = fold4 ? p.c8 + p.c4 : p.c4;
+    if (!fold4) {
+        rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
+        if (rc) return rc;
+    }
     // 5. heads (:131-143)
     if (desc->n_out > STEMSEG_MAX_HEAD_OUT) {
         // wide linear head (semseg_decoder.py:116: conv_out, class logits, no activation): the 1x1x1 MFMA conv; head_w is
         // then a PACKED conv weight with Cout = n_out (zero-padded to a multiple of 32 by the caller), head_b may be NULL
         ConvEpilogue head_epi = fuse_epi;
         head_epi.out_bs = p.out_bs;
-        rc = launch_conv3d(flat_volume(ws + p.X4, p.c4, V4), wts->head_w, wts->head_b, flat_volume(out, desc->n_out, V4), 1, 1, 1, 0, sm, nullptr, 0, &head_epi);
+        rc = launch_conv3d(flat_volume(const_cast<float*>(head_in), head_cin, V4), wts->head_w, wts->head_b, flat_volume(out, desc->n_out, V4), 1, 1, 1, 0, sm, nullptr, 0, &head_epi);
         if (rc) return rc;
     } else {
         HeadSpec hs;
@@ -473,7 +482,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
         for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
         ClipBatch hb;
         hb.nb = nb; hb.in_bs = WS; hb.out_bs = p.out_bs;
-        rc = launch_heads(ws + p.X4, p.c4, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm, hb);
+        rc = launch_heads(head_in, head_cin, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm, hb);
         if (rc) return rc;
     }
     if (detached) SS_HIP(hipEventRecord(bs->done[3], sm));

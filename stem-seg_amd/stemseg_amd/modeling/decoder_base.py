@@ -63,6 +63,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.conv_8 = nn.Conv3d(c16 + c8, c8, 1, bias=False)
         self.conv_4 = nn.Conv3d(c8 + c4, c4, 1, bias=False)
         self._cache = {}          # precision -> packed weights (valid while the parameter versions match)
+        self.fold_conv4 = True    # conv_4 folded into the heads at load (see _fold; False: the two-step form, for A/B and exactness checks)
         self._retired = []        # superseded packings, kept alive for captured graphs
         self._workspaces, self._ws_desc = {}, {}     # (T, H4, W4, layout, device, lane) -> workspace tensor / the descriptor it was sized for
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
@@ -76,9 +77,19 @@ class SqueezeExpandTrunk(nn.Module):
         """-> (weight [n_out, c4] tensor, bias [n_out] tensor, act codes, grid_axis codes)"""
         raise NotImplementedError
 
+    def _fold(self, w_head):
+        """conv_4 (1x1x1, no bias, no activation: embedding_decoder.py:80,129) feeds nothing but the 1x1x1 heads: with ``fold_conv4`` the head
+        weights are multiplied by conv_4's at load (fp64 product, rounded once) and the decoder applies them to the last concat buffer directly
+        (StemsegDecoderWeights.fuse_w[2] = NULL) -- one linear map for two, like FrozenBN folded into its convolution; the inter[3]-channel
+        map is never computed, written or read.  w_head: dense [n_out, inter[3]] -> [n_out, inter[2] + inter[3]] (unchanged without the fold)."""
+        if not self.fold_conv4:
+            return w_head
+        w4 = self.conv_4.weight.detach().reshape(self.conv_4.out_channels, -1)
+        return (w_head.detach().double() @ w4.double()).float()
+
     # ---- weights --------------------------------------------------------------------------------------
     def _param_signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bool(self.fold_conv4),)
 
     def _packed(self):
         # one packing per precision: an overflow re-run in bf16x6 (ClipPipeline.step_checked, GraphedStep.collect) must not throw the
@@ -100,7 +111,8 @@ class SqueezeExpandTrunk(nn.Module):
                 else:                                        # no normalisation layer: scale 1, shift 0
                     gn_w.append(torch.ones(conv.out_channels, dtype=torch.float32, device=dev))
                     gn_b.append(torch.zeros(conv.out_channels, dtype=torch.float32, device=dev))
-            fuse = [hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8, self.conv_4)]
+            fuse = [hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8)]
+            fuse.append(None if self.fold_conv4 else hip.pack_conv_weight_any(self.conv_4.weight.detach().float(), self.precision))
             hw, hb, act, axes = self._head_spec()
             if c:
                 self._retired.append(dict(c))
@@ -194,7 +206,7 @@ class SqueezeExpandTrunk(nn.Module):
             w.conv_w[i], w.conv_b[i] = c["conv_w"][i].data_ptr(), c["conv_b"][i].data_ptr()
             w.gn_w[i], w.gn_b[i] = c["gn_w"][i].data_ptr(), c["gn_b"][i].data_ptr()
         for i in range(3):
-            w.fuse_w[i] = c["fuse"][i].data_ptr()
+            w.fuse_w[i] = c["fuse"][i].data_ptr() if c["fuse"][i] is not None else None      # (conv_4 folded into the heads: NULL)
         w.head_w, w.head_b = c["head_w"].data_ptr(), c["head_b"].data_ptr()
         gt, gy, gx = self._grid(c, T, H4, W4, dev)
         if gt is not None:

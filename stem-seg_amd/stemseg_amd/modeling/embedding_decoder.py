@@ -64,7 +64,7 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
             bs.append(torch.zeros(1, device=ws[0].device))
             act.append(ACT_SIGMOID)
             axes.append(0)
-        return torch.cat(ws, 0), torch.cat([b.float() for b in bs], 0), act, axes
+        return self._fold(torch.cat(ws, 0)), torch.cat([b.float() for b in bs], 0), act, axes
 
     def _grid(self, c, T, H4, W4, dev):
         # the time_scale buffer lives on the device: read it back once per value, not per call (a per-call .item() is a

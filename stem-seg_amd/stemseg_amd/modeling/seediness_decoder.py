@@ -22,7 +22,7 @@ class SqueezingExpandDecoder(SqueezeExpandTrunk):
         self.conv_out = nn.Conv3d(inter_channels[3], 1, kernel_size=1, padding=0, bias=False)
 
     def _head_spec(self):
-        w = self.conv_out.weight.reshape(1, -1)
+        w = self._fold(self.conv_out.weight.reshape(1, -1))
         return w, torch.zeros(1, device=w.device), [2], [0]     # sigmoid, no grid
 
     @torch.no_grad()

@@ -32,11 +32,12 @@ class SqueezeExpandDecoder(SqueezeExpandTrunk):
     def _head_spec(self):
         n = self.out_channels
         if n <= 8:                                   # narrow: fused heads kernel, identity activation
-            w = self.conv_out.weight.reshape(n, -1)
+            w = self._fold(self.conv_out.weight.reshape(n, -1))
             return w, torch.zeros(n, device=w.device), [0] * n, [0] * n
         npad = (n + 31) // 32 * 32                   # wide: 1x1x1 MFMA conv on zero-padded output channels
-        w = torch.zeros(npad, self.inter_channels[3], 1, 1, 1, dtype=torch.float32, device=self.conv_out.weight.device)
-        w[:n] = self.conv_out.weight.detach().float()
+        wf = self._fold(self.conv_out.weight.detach().float().reshape(n, -1))
+        w = torch.zeros(npad, wf.shape[1], 1, 1, 1, dtype=torch.float32, device=self.conv_out.weight.device)
+        w[:n] = wf.reshape(n, -1, 1, 1, 1)
         packed = hip.pack_conv_weight_any(w, self.precision)
         return packed, torch.zeros(npad, device=w.device), [0] * npad, [0] * npad
 

@@ -422,6 +422,37 @@ def test_seediness_decoder_vs_golden(hip, golden, T):
     assert np.array_equal(a, b), "decoder is not run-to-run deterministic"
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv4_folded_into_the_heads_vs_the_two_step_form(hip, precision):
+    """conv_4 (1x1x1, no bias, no activation: embedding_decoder.py:80,129) feeds only the 1x1x1 heads; by default its weights are multiplied into
+    the head weights at load (fp64 product, rounded once: SqueezeExpandTrunk._fold) and the 128-channel map is never materialised
+    (StemsegDecoderWeights.fuse_w[2] = NULL).  Against the two-step form (fold_conv4 = False) on the same inputs: fp32 round-off -- embedding,
+    variance and seediness heads of the embedding decoder, the seediness decoder's sigmoid head, the 41-class semseg head on the MFMA conv."""
+    from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
+    from stemseg_amd.modeling.semseg_decoder import SqueezeExpandDecoder as Sem
+    T, h32, w32 = 8, 6, 10
+    feats = [dev(f)[None] for f in synth.synth_features(T, h32, w32, seed=57)]
+    heads = [_emb_head("xytff", 5, True, True, T, 57)]
+    for cls, args, prefix in ((Seed, (256, [256, 256, 128, 128]), "seediness_head."), (Sem, (256, 41, [256, 256, 128, 128], (4, 8, 16, 32), True), "semseg_head.")):
+        m = cls(*args, NormType=_gn, num_frames=T)
+        sd = synth.synth_state_dict([(k, v.shape) for k, v in m.state_dict().items()], 58, prefix=prefix)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(m.state_dict()[k].shape) for k, v in sd.items()})
+        heads.append(m.cuda().eval())
+    for m in heads:
+        m.precision = precision
+        x = feats[::-1] if isinstance(m, Sem) else feats          # (the semseg head takes 4x .. 32x)
+        assert m.fold_conv4
+        a = m(x)[0].cpu().numpy()
+        m.fold_conv4 = False
+        b = m(x)[0].cpu().numpy()
+        m.fold_conv4 = True
+        c = m(x)[0].cpu().numpy()
+        scale = np.maximum(1.0, np.abs(b))
+        err = float(np.abs(a - b).max() if a.size else 0), float((np.abs(a - b) / scale).max())
+        print("[fold] %s %s: folded vs two-step max |diff| %.3g (rel to max(1, |x|) %.3g)" % (type(m).__module__.split(".")[-1], precision, err[0], err[1]))
+        assert err[1] <= 2e-5 and np.array_equal(a, c)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_decoder_full_size_480x864_vs_oracle(hip, precision):
     """BASELINE config 1 shape (T=8, padded 480x864 -> 120x216 outputs): HIP decoder vs the CPU oracle, both MFMA modes."""
