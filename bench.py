@@ -525,7 +525,8 @@ def main():
                     help="frames the encoder plans its launches for (default: the model's own constant, ResNetFPN.plan_frames = 32, whatever "
                          "--clips-per-step / --sequence say: two batchings of one job give the same bits).  A throughput knob for A/B runs only")
     ap.add_argument("--fuse-tail", type=int, default=None, help="A/B: stages whose bottleneck tails run fused (bit mask 1 | 2 | 4; default: the model's, 7; 0: none; + 8: stage 3 on the 16-column form)")
-    ap.add_argument("--no-fold-conv4", action="store_true", help="A/B: the decoders' conv_4 as its own launch instead of folded into the head weights")
+    ap.add_argument("--no-fold-conv4", action="store_true", help="A/B: the decoders' tail step by step (fuse convs, 128 / 256-channel up-samplings, heads on conv_4's output)")
+    ap.add_argument("--no-linear-tail", action="store_true", help="A/B: the decoders' tail with conv_16 / conv_8 and their up-samplings as launches, only conv_4 folded into the head weights")
     ap.add_argument("--no-overlap", action="store_true", help="run both decoders and all their branches on one stream")
     ap.add_argument("--graph-overlap", action="store_true", help="capture the graph WITH the fork/join branch streams (experimental)")
     args = ap.parse_args()
@@ -584,11 +585,13 @@ def main():
     args.plan_frames = int(pipe.model._model.backbone.plan_frames)
     if args.fuse_tail is not None:
         pipe.model._model.backbone.fuse_tail = int(args.fuse_tail)
-    if args.no_fold_conv4:
+    if args.no_fold_conv4 or args.no_linear_tail:
         for name in ("embedding_head", "seediness_head", "semseg_head"):
             head = getattr(pipe.model._model, name, None)
             if head is not None:
-                head.fold_conv4 = False
+                head.fold_linear_tail = False
+                if args.no_fold_conv4:
+                    head.fold_conv4 = False
     if args.sequence:
         sequence_mode(args, pipe, device, rank, world, use_dist)
         if use_dist:
@@ -833,7 +836,8 @@ def main():
                        # (the reference's own inference form, resnet.py:49-60) and -- unless --no-fold-conv4 -- the decoders' conv_4 into the head weights
                        # (1x1x1, no bias, no activation, feeding only the 1x1x1 heads: W_heads . W_conv4 as one fp64 product rounded once; outputs
                        # within fp32 round-off of the two-step form, tests/test_gpu_parity.py::test_conv4_folded_into_the_heads_vs_the_two_step_form)
-                       "weight_folds": ["FrozenBN -> conv"] + ([] if args.no_fold_conv4 else ["decoder conv_4 -> head weights"])},
+                       "weight_folds": ["FrozenBN -> conv"] + ([] if args.no_fold_conv4 else (["decoder conv_4 -> head weights"] if args.no_linear_tail else
+                                        ["decoder linear tail (conv_16, conv_8, conv_4, heads; up-sampling commutes with 1x1x1 convs) -> per-level head matrices"]))},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3, %s)" % {"f32": "fp32 MFMA 32x32x2", "bf16x6": "bf16x6 on MFMA 32x32x16 bf16; peak = 2500/6 fp32-equivalent TFLOP/s", "f16x3": "f16x3 on MFMA 32x32x16 f16; peak = 2500/3 fp32-equivalent TFLOP/s"}[args.precision],
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s" if args.precision == "f32" else "TFLOP/s (fp32-equivalent: conv FLOPs / time; the MFMA pipe issues %d 16-bit products per fp32 product)" % PRODUCTS.get(args.precision, 1),
                          "frac": round(ach / peak, 4), "achieved_vs_fp32_input_mfma_peak": round(ach / PEAK_MFMA_F32_TFLOPS, 3),

@@ -164,6 +164,9 @@ struct HeadSpec {
     int grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
 };
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
-                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb = ClipBatch());
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb = ClipBatch(),
+                 const float* add = nullptr, int64_t add_bs = 0);
+int launch_level_head(const float* x, int Cin, int64_t V, const float* w, int n_out, const float* add, float* out, hipStream_t s, int nb, int64_t x_bs,
+                      int64_t add_bs, int64_t out_bs);
 
 }  // namespace stemseg

@@ -358,7 +358,10 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
         return STEMSEG_E_WORKSPACE;
     }
     for (int i = 0; i < 7; ++i) SS_CHECK_ARG(wts->conv_w[i] && wts->conv_b[i] && wts->gn_w[i] && wts->gn_b[i], "decoder_forward: null block weight %d", i);
-    for (int i = 0; i < 2; ++i) SS_CHECK_ARG(wts->fuse_w[i], "decoder_forward: null fuse weight %d", i);      // (fuse_w[2] NULL: conv_4 folded into the heads, below)
+    // fuse_w[2] NULL: conv_4 folded into the heads; all three NULL: the whole linear tail folded into per-level head matrices (below)
+    const bool lin_tail = !wts->fuse_w[0] && !wts->fuse_w[1] && !wts->fuse_w[2];
+    if (!lin_tail) for (int i = 0; i < 2; ++i) SS_CHECK_ARG(wts->fuse_w[i], "decoder_forward: null fuse weight %d", i);
+    SS_CHECK_ARG(!lin_tail || desc->n_out <= STEMSEG_MAX_HEAD_OUT, "decoder_forward: the linear tail serves the fused heads kernel (n_out <= %d), not the wide head", STEMSEG_MAX_HEAD_OUT);
     SS_CHECK_ARG(wts->head_w, "decoder_forward: null head weight");
     for (int i = 0; i < 4; ++i) SS_CHECK_ARG(feats[i], "decoder_forward: null feature map %d", i);
 
@@ -423,8 +426,37 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     rc = conv_gn(padded_halo_view(ws + p.P32c, p.c32, p.Ta2, p.h[0], p.w[0]), wts->conv_w[2], wts->conv_b[2], wts->gn_w[2], wts->gn_b[2], p.c32,
                  p.Ta2, p.h[0], p.w[0], desc->pool[2], dense_volume(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0]), D[0], stats[0], scratch[0], G, eps, s32, ws + p.S[0], p.Sfloats[0], desc->precision, nb, WS, WS);
     if (rc) return rc;
-    rc = launch_upsample(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2,
-                         slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s32, wsb);
+    // THE LINEAR TAIL.  Between the last GroupNorm + ReLU of every branch and the heads' activations the reference applies only linear maps:
+    // trilinear up-sampling, concatenation, the bias-free 1x1x1 fuse convs conv_16 / conv_8 / conv_4 (embedding_decoder.py:64-80,112-129) and the
+    // 1x1x1 heads (:131-143).  Channel mixing commutes with up-sampling, so
+    //   heads(x) = up(up(up(M32 x32) + M16 y16) + M8 y8) + M4 y4,   M4 = Wh W4b, M8 = Wh W4a W8b, M16 = Wh W4a W8a W16b, M32 = Wh W4a W8a W16a
+    // (W4 = [W4a | W4b] over the (up-sampled, own) halves of its concat input, likewise W8, W16): with fuse_w[0..2] = NULL the caller hands over
+    // head_w = [M32 | M16 | M8 | M4] (fp64 products, rounded once) and every level contributes its n_out-channel share AT ITS OWN RESOLUTION --
+    // the up-samplings move n_out channels instead of 256 / 256 / 128, the three fuse convs and the concat halves they read disappear.  The same
+    // function, within fp32 round-off of the step-by-step form (one rounding of the product matrices instead of one per stage).
+    const int64_t V32 = (int64_t)p.Ta3 * p.h[0] * p.w[0];
+    const int64_t V16l = (int64_t)p.T16 * p.h[1] * p.w[1], V8l = (int64_t)p.T8 * p.h[2] * p.w[2];
+    const int NO = desc->n_out;
+    const float* M32 = wts->head_w;
+    const float* M16 = M32 + (int64_t)NO * p.c32;
+    const float* M8 = M16 + (int64_t)NO * p.c16;
+    const float* M4 = M8 + (int64_t)NO * p.c8;
+    // n_out-channel level maps live in the (otherwise unused) X16 / X8 / X4 slices: [z32 | up16 | z16], [up8 | z8], [up4]
+    float* z32 = ws + p.X16;
+    float* up16 = z32 + (int64_t)NO * V16l;
+    float* z16 = up16 + (int64_t)NO * V16l;
+    float* up8 = ws + p.X8;
+    float* z8 = up8 + (int64_t)NO * V8l;
+    float* up4 = ws + p.X4;
+    if (lin_tail) {
+        SS_CHECK_ARG(3 * NO <= p.c16 && 2 * NO <= p.c8 && NO <= p.c4 && V32 <= V16l, "decoder: level maps do not fit the fuse slices");
+        rc = launch_level_head(ws + p.X32, p.c32, V32, M32, NO, nullptr, z32, s32, nb, WS, 0, WS);
+        if (rc) return rc;
+        rc = launch_upsample(z32, NO, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2, dense_volume(up16, NO, p.T16, p.h[1], p.w[1]), s32, wsb);
+    } else {
+        rc = launch_upsample(ws + p.X32, p.c32, p.Ta3, p.h[0], p.w[0], desc->t_scale[0], 2, 2,
+                             slice_volume(ws + p.cat16, 0, p.c32, p.T16, p.h[1], p.w[1]), s32, wsb);
+    }
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[0], s32));
     // 2. block_16x on s16 into cat16[c32:], join 32x, 1x1x1 fuse, upsample into cat8[0:c16]  (:112-117)
@@ -436,10 +468,16 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (rc) return rc;
     const int64_t V16 = (int64_t)p.T16 * p.h[1] * p.w[1], V8 = (int64_t)p.T8 * p.h[2] * p.w[2], V4 = (int64_t)T * p.h[3] * p.w[3];
     if (bs) SS_HIP(hipStreamWaitEvent(s16, bs->done[0], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16, ws + p.S[1], p.Sfloats[1], &fuse_epi);
-    if (rc) return rc;
-    rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
-                         slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16, wsb);
+    if (lin_tail) {
+        rc = launch_level_head(ws + p.cat16 + (int64_t)p.c32 * V16, p.c16, V16, M16, NO, up16, z16, s16, nb, WS, WS, WS);
+        if (rc) return rc;
+        rc = launch_upsample(z16, NO, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2, dense_volume(up8, NO, p.T8, p.h[2], p.w[2]), s16, wsb);
+    } else {
+        rc = launch_conv3d(flat_volume(ws + p.cat16, p.c32 + p.c16, V16), wts->fuse_w[0], nullptr, flat_volume(ws + p.X16, p.c16, V16), 1, 1, 1, 0, s16, ws + p.S[1], p.Sfloats[1], &fuse_epi);
+        if (rc) return rc;
+        rc = launch_upsample(ws + p.X16, p.c16, p.T16, p.h[1], p.w[1], desc->t_scale[1], 2, 2,
+                             slice_volume(ws + p.cat8, 0, p.c16, p.T8, p.h[2], p.w[2]), s16, wsb);
+    }
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[1], s16));
     // 3. block_8x on s8 into cat8[c16:], join 16x, fuse, upsample into cat4[0:c8]  (:119-123)
@@ -447,9 +485,15 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
                  p.w[2], desc->pool[0], slice_volume(ws + p.cat8, p.c16, p.c8, p.T8, p.h[2], p.w[2]), D[2], stats[2], scratch[2], G, eps, s8, ws + p.S[2], p.Sfloats[2], desc->precision, nb, pin_bs[2], WS);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(s8, bs->done[1], 0));
-    rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, ws + p.S[2], p.Sfloats[2], &fuse_epi);
-    if (rc) return rc;
-    rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8, wsb);
+    if (lin_tail) {
+        rc = launch_level_head(ws + p.cat8 + (int64_t)p.c16 * V8, p.c8, V8, M8, NO, up8, z8, s8, nb, WS, WS, WS);
+        if (rc) return rc;
+        rc = launch_upsample(z8, NO, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, dense_volume(up4, NO, T, p.h[3], p.w[3]), s8, wsb);
+    } else {
+        rc = launch_conv3d(flat_volume(ws + p.cat8, p.c16 + p.c8, V8), wts->fuse_w[1], nullptr, flat_volume(ws + p.X8, p.c8, V8), 1, 1, 1, 0, s8, ws + p.S[2], p.Sfloats[2], &fuse_epi);
+        if (rc) return rc;
+        rc = launch_upsample(ws + p.X8, p.c8, p.T8, p.h[2], p.w[2], desc->t_scale[2], 2, 2, slice_volume(ws + p.cat4, 0, p.c8, T, p.h[3], p.w[3]), s8, wsb);
+    }
     if (rc) return rc;
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
@@ -462,8 +506,8 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     // the concat buffer: the c4-channel map (106 MB per clip at 480p) is neither computed, written nor read back.  One linear map instead of two:
     // the same fold as FrozenBN into its convolution, results within fp32 round-off of the two-step form.
     const bool fold4 = wts->fuse_w[2] == nullptr;
-    const float* head_in = fold4 ? ws + p.cat4 : ws + p.X4;
-    const int head_cin = fold4 ? p.c8 + p.c4 : p.c4;
+    const float* head_in = lin_tail ? ws + p.cat4 + (int64_t)p.c8 * V4 : (fold4 ? ws + p.cat4 : ws + p.X4);      // (linear tail: the 4x branch's own half)
+    const int head_cin = lin_tail ? p.c4 : (fold4 ? p.c8 + p.c4 : p.c4);
     if (!fold4) {
         rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
         if (rc) return rc;
@@ -482,7 +526,8 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
         for (int o = 0; o < desc->n_out; ++o) { hs.act[o] = desc->act[o]; hs.grid_axis[o] = desc->grid_axis[o]; }
         ClipBatch hb;
         hb.nb = nb; hb.in_bs = WS; hb.out_bs = p.out_bs;
-        rc = launch_heads(head_in, head_cin, T, p.h[3], p.w[3], wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm, hb);
+        rc = launch_heads(head_in, head_cin, T, p.h[3], p.w[3], lin_tail ? M4 : wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm, hb,
+                          lin_tail ? up4 : nullptr, WS);
         if (rc) return rc;
     }
     if (detached) SS_HIP(hipEventRecord(bs->done[3], sm));

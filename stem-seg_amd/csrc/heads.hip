@@ -19,10 +19,11 @@ struct HeadsParams {
     const float* gt;
     const float* gy;
     const float* gx;
+    const float* add;              // optional [n_out][V] term added to the linear part before bias / activation (the linear tail of the decoders)
     float* out;
     int Cin, T, H, W;
     int64_t V;
-    int64_t x_bs, out_bs;          // clip batch (grid.y = clip)
+    int64_t x_bs, out_bs, add_bs;  // clip batch (grid.y = clip)
     int act[HEADS_MAX_OUT];
     int axis[HEADS_MAX_OUT];
 };
@@ -42,6 +43,7 @@ template <int NOUT>
 __global__ __launch_bounds__(256) void heads_kernel(HeadsParams p) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [NOUT][Cin]
     p.x += (int64_t)blockIdx.y * p.x_bs; p.out += (int64_t)blockIdx.y * p.out_bs;
+    if (p.add) p.add += (int64_t)blockIdx.y * p.add_bs;
     for (int i = threadIdx.x; i < NOUT * p.Cin; i += blockDim.x) w_lds[i] = p.w[i];
     __syncthreads();
     const int64_t nq = p.V / 4;
@@ -72,6 +74,10 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsParams p) {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             const float b = p.bias ? p.bias[o] : 0.f;
+            if (p.add) {
+                const float4 a4 = reinterpret_cast<const float4*>(p.add + (int64_t)o * p.V)[q];
+                acc[o].x += a4.x; acc[o].y += a4.y; acc[o].z += a4.z; acc[o].w += a4.w;
+            }
             float g[4] = {0.f, 0.f, 0.f, 0.f};
             const int ax = p.axis[o];
             if (ax == 1) { g[0] = g[1] = g[2] = g[3] = p.gt[t]; }
@@ -96,8 +102,64 @@ static int launch_heads_n(const HeadsParams& p, int nb, hipStream_t s) {
     return STEMSEG_OK;
 }
 
+// A level of the decoders' LINEAR TAIL (decoder.hip): z = M x (+ add), M [NOUT][Cin], x dense [Cin][V], no bias, no activation -- the coarse
+// levels' share of the heads, computed at their own resolution.  One thread per voxel (any V: the 32x / 16x maps are 15 x 27 / 30 x 54), the
+// weights broadcast from LDS; these maps are tens of thousands of voxels, nothing to optimise.
+template <int NOUT>
+__global__ __launch_bounds__(256) void level_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ add,
+                                                          float* __restrict__ out, int Cin, int64_t V, int64_t x_bs, int64_t add_bs, int64_t out_bs) {
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [NOUT][Cin]
+    x += (int64_t)blockIdx.y * x_bs; out += (int64_t)blockIdx.y * out_bs;
+    if (add) add += (int64_t)blockIdx.y * add_bs;
+    for (int i = threadIdx.x; i < NOUT * Cin; i += blockDim.x) w_lds[i] = w[i];
+    __syncthreads();
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+        float acc[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+        for (int c = 0; c < Cin; ++c) {
+            const float xv = x[(int64_t)c * V + v];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) acc[o] += w_lds[o * Cin + c] * xv;
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) out[(int64_t)o * V + v] = add ? acc[o] + add[(int64_t)o * V + v] : acc[o];
+    }
+}
+
+template <int NOUT>
+static int launch_level_head_n(const float* x, int Cin, int64_t V, const float* w, const float* add, float* out, hipStream_t s, int nb, int64_t x_bs,
+                               int64_t add_bs, int64_t out_bs) {
+    const int blocks = (int)std::min<int64_t>(ceil_div(V, 256), 256 * 8);
+    hipLaunchKernelGGL(level_head_kernel<NOUT>, dim3(blocks, (unsigned)nb), dim3(256), (size_t)NOUT * Cin * sizeof(float), s, x, w, add, out, Cin, V, x_bs, add_bs, out_bs);
+    SS_LAUNCH_CHECK();
+    return STEMSEG_OK;
+}
+
+int launch_level_head(const float* x, int Cin, int64_t V, const float* w, int n_out, const float* add, float* out, hipStream_t s, int nb, int64_t x_bs,
+                      int64_t add_bs, int64_t out_bs) {
+    SS_CHECK_ARG(x && w && out && nb >= 1 && nb <= 65535 && Cin > 0 && V > 0, "level_head: bad arguments");
+    SS_CHECK_ARG(n_out >= 1 && n_out <= STEMSEG_MAX_HEAD_OUT && (size_t)n_out * Cin * sizeof(float) <= 48 * 1024, "level_head: n_out=%d, Cin=%d unsupported", n_out, Cin);
+    void* ev = profile_begin(44, 4.0 * (double)V * (Cin + n_out) * nb, s);
+    int rc;
+    switch (n_out) {
+        case 1: rc = launch_level_head_n<1>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 2: rc = launch_level_head_n<2>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 3: rc = launch_level_head_n<3>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 4: rc = launch_level_head_n<4>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 5: rc = launch_level_head_n<5>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 6: rc = launch_level_head_n<6>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 7: rc = launch_level_head_n<7>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 8: rc = launch_level_head_n<8>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        case 9: rc = launch_level_head_n<9>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+        default: rc = launch_level_head_n<10>(x, Cin, V, w, add, out, s, nb, x_bs, add_bs, out_bs); break;
+    }
+    profile_end(ev, s);
+    return rc;
+}
+
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
-                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb) {
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb, const float* add, int64_t add_bs) {
     SS_CHECK_ARG(x && w && out && cb.nb >= 1 && cb.nb <= 65535 && cb.in_bs % 4 == 0 && cb.out_bs % 4 == 0, "heads: null pointer");
     SS_CHECK_ARG(hs.n_out >= 1 && hs.n_out <= STEMSEG_MAX_HEAD_OUT, "heads: n_out=%d unsupported (1..%d)", hs.n_out, STEMSEG_MAX_HEAD_OUT);
     SS_CHECK_ARG(Cin % 4 == 0 && W % 4 == 0, "heads: Cin %% 4 == 0 and W %% 4 == 0 required (Cin=%d, W=%d)", Cin, W);
@@ -106,6 +168,8 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
     p.x = x; p.w = w; p.bias = bias; p.gt = gt; p.gy = gy; p.gx = gx; p.out = out;
     p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.V = (int64_t)T * H * W;
     p.x_bs = cb.in_bs; p.out_bs = cb.out_bs;
+    p.add = add; p.add_bs = add_bs;
+    SS_CHECK_ARG(!add || (reinterpret_cast<uintptr_t>(add) % 16 == 0 && add_bs % 4 == 0), "heads: 16-byte aligned addend");
     const int nb = cb.nb;
     for (int o = 0; o < HEADS_MAX_OUT; ++o) { p.act[o] = 0; p.axis[o] = 0; }
     for (int o = 0; o < hs.n_out; ++o) {

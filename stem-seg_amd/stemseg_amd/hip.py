@@ -384,6 +384,7 @@ def heads(x, w, bias, act, grid_axis, gt, gy, gx):
 
 
 NONFINITE_FLAGS = 64
+MAX_HEAD_OUT = 10          # STEMSEG_MAX_HEAD_OUT: widest head the fused heads kernel serves (wider: the 1x1x1 MFMA conv)
 
 
 class NonFiniteError(FloatingPointError):

@@ -64,6 +64,7 @@ class SqueezeExpandTrunk(nn.Module):
         self.conv_4 = nn.Conv3d(c8 + c4, c4, 1, bias=False)
         self._cache = {}          # precision -> packed weights (valid while the parameter versions match)
         self.fold_conv4 = True    # conv_4 folded into the heads at load (see _fold; False: the two-step form, for A/B and exactness checks)
+        self.fold_linear_tail = True     # the whole linear tail folded into per-level head matrices (see _linear_tail; narrow heads only)
         self._retired = []        # superseded packings, kept alive for captured graphs
         self._workspaces, self._ws_desc = {}, {}     # (T, H4, W4, layout, device, lane) -> workspace tensor / the descriptor it was sized for
         self.input_layout = 0     # 0: [C,T,h,w] per sample (reference API); 2: caller passes zero-haloed buffers
@@ -77,11 +78,32 @@ class SqueezeExpandTrunk(nn.Module):
         """-> (weight [n_out, c4] tensor, bias [n_out] tensor, act codes, grid_axis codes)"""
         raise NotImplementedError
 
+    def _linear_tail(self, w_head):
+        """Between the last GroupNorm + ReLU of every branch and the heads' activations the reference applies only linear maps (trilinear
+        up-sampling, concatenation, the bias-free 1x1x1 convs conv_16 / conv_8 / conv_4, the 1x1x1 heads; embedding_decoder.py:64-80,112-143), and
+        channel mixing commutes with up-sampling:  heads(x) = up(up(up(M32 x32) + M16 y16) + M8 y8) + M4 y4.  -> the four level matrices
+        [n_out, c32], [n_out, c16], [n_out, c8], [n_out, c4] as fp64 products rounded once (StemsegDecoderWeights: fuse_w[0..2] = NULL,
+        head_w = [M32 | M16 | M8 | M4])."""
+        c32, c16, c8, c4 = self.inter_channels
+        wh = w_head.detach().double()
+        w4 = self.conv_4.weight.detach().reshape(c4, c8 + c4).double()
+        w8 = self.conv_8.weight.detach().reshape(c8, c16 + c8).double()
+        w16 = self.conv_16.weight.detach().reshape(c16, c32 + c16).double()
+        m4 = wh @ w4[:, c8:]
+        a = wh @ w4[:, :c8]
+        m8 = a @ w8[:, c16:]
+        b = a @ w8[:, :c16]
+        m16 = b @ w16[:, c32:]
+        m32 = b @ w16[:, :c32]
+        return [m.float().contiguous() for m in (m32, m16, m8, m4)]
+
     def _fold(self, w_head):
         """conv_4 (1x1x1, no bias, no activation: embedding_decoder.py:80,129) feeds nothing but the 1x1x1 heads: with ``fold_conv4`` the head
         weights are multiplied by conv_4's at load (fp64 product, rounded once) and the decoder applies them to the last concat buffer directly
         (StemsegDecoderWeights.fuse_w[2] = NULL) -- one linear map for two, like FrozenBN folded into its convolution; the inter[3]-channel
         map is never computed, written or read.  w_head: dense [n_out, inter[3]] -> [n_out, inter[2] + inter[3]] (unchanged without the fold)."""
+        if self.fold_linear_tail and w_head.shape[0] <= hip.MAX_HEAD_OUT:
+            return torch.cat([m.reshape(-1) for m in self._linear_tail(w_head)])      # (flat [M32 | M16 | M8 | M4]: the narrow heads' form)
         if not self.fold_conv4:
             return w_head
         w4 = self.conv_4.weight.detach().reshape(self.conv_4.out_channels, -1)
@@ -89,7 +111,7 @@ class SqueezeExpandTrunk(nn.Module):
 
     # ---- weights --------------------------------------------------------------------------------------
     def _param_signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bool(self.fold_conv4),)
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bool(self.fold_conv4), bool(self.fold_linear_tail))
 
     def _packed(self):
         # one packing per precision: an overflow re-run in bf16x6 (ClipPipeline.step_checked, GraphedStep.collect) must not throw the
@@ -111,9 +133,10 @@ class SqueezeExpandTrunk(nn.Module):
                 else:                                        # no normalisation layer: scale 1, shift 0
                     gn_w.append(torch.ones(conv.out_channels, dtype=torch.float32, device=dev))
                     gn_b.append(torch.zeros(conv.out_channels, dtype=torch.float32, device=dev))
-            fuse = [hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8)]
-            fuse.append(None if self.fold_conv4 else hip.pack_conv_weight_any(self.conv_4.weight.detach().float(), self.precision))
             hw, hb, act, axes = self._head_spec()
+            lin = self.fold_linear_tail and len(act) <= hip.MAX_HEAD_OUT          # (the wide semseg head keeps conv_16 / conv_8 and folds conv_4 only)
+            fuse = [None if lin else hip.pack_conv_weight_any(m.weight.detach().float(), self.precision) for m in (self.conv_16, self.conv_8)]
+            fuse.append(None if (lin or self.fold_conv4) else hip.pack_conv_weight_any(self.conv_4.weight.detach().float(), self.precision))
             if c:
                 self._retired.append(dict(c))
             c.clear()

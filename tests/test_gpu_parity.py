@@ -423,11 +423,14 @@ def test_seediness_decoder_vs_golden(hip, golden, T):
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-def test_conv4_folded_into_the_heads_vs_the_two_step_form(hip, precision):
-    """conv_4 (1x1x1, no bias, no activation: embedding_decoder.py:80,129) feeds only the 1x1x1 heads; by default its weights are multiplied into
-    the head weights at load (fp64 product, rounded once: SqueezeExpandTrunk._fold) and the 128-channel map is never materialised
-    (StemsegDecoderWeights.fuse_w[2] = NULL).  Against the two-step form (fold_conv4 = False) on the same inputs: fp32 round-off -- embedding,
-    variance and seediness heads of the embedding decoder, the seediness decoder's sigmoid head, the 41-class semseg head on the MFMA conv."""
+def test_linear_tail_folds_vs_the_step_by_step_form(hip, precision):
+    """Between the last GroupNorm + ReLU of every branch and the heads' activations the reference applies only linear maps (trilinear
+    up-sampling, concatenation, the bias-free 1x1x1 convs conv_16 / conv_8 / conv_4, the 1x1x1 heads: embedding_decoder.py:64-80,112-143).
+    By default the narrow heads fold that whole tail into four per-level matrices at load (SqueezeExpandTrunk._linear_tail: every level adds
+    its n_out-channel share at its own resolution, fuse_w[0..2] = NULL) and the wide semseg head folds conv_4 into its weights (_fold,
+    fuse_w[2] = NULL).  Against the step-by-step form (both switches off) on the same inputs: fp32 round-off -- the embedding decoder's
+    embedding / variance / seediness heads, the seediness decoder's sigmoid, the 41 + 1-class head on the MFMA conv -- and the intermediate
+    form (conv_4 only) likewise."""
     from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
     from stemseg_amd.modeling.semseg_decoder import SqueezeExpandDecoder as Sem
     T, h32, w32 = 8, 6, 10
@@ -441,16 +444,18 @@ def test_conv4_folded_into_the_heads_vs_the_two_step_form(hip, precision):
     for m in heads:
         m.precision = precision
         x = feats[::-1] if isinstance(m, Sem) else feats          # (the semseg head takes 4x .. 32x)
-        assert m.fold_conv4
-        a = m(x)[0].cpu().numpy()
-        m.fold_conv4 = False
-        b = m(x)[0].cpu().numpy()
-        m.fold_conv4 = True
-        c = m(x)[0].cpu().numpy()
-        scale = np.maximum(1.0, np.abs(b))
-        err = float(np.abs(a - b).max() if a.size else 0), float((np.abs(a - b) / scale).max())
-        print("[fold] %s %s: folded vs two-step max |diff| %.3g (rel to max(1, |x|) %.3g)" % (type(m).__module__.split(".")[-1], precision, err[0], err[1]))
-        assert err[1] <= 2e-5 and np.array_equal(a, c)
+        assert m.fold_conv4 and m.fold_linear_tail
+        outs = {}
+        for name, lin, c4 in (("default", True, True), ("conv_4 only", False, True), ("step by step", False, False), ("default again", True, True)):
+            m.fold_linear_tail, m.fold_conv4 = lin, c4
+            outs[name] = m(x)[0].cpu().numpy()
+        ref = outs["step by step"]
+        scale = np.maximum(1.0, np.abs(ref))
+        for name in ("default", "conv_4 only"):
+            err = float(np.abs(outs[name] - ref).max()), float((np.abs(outs[name] - ref) / scale).max())
+            print("[fold] %s %s, %s vs step by step: max |diff| %.3g (rel to max(1, |x|) %.3g)" % (type(m).__module__.split(".")[-1], precision, name, err[0], err[1]))
+            assert err[1] <= 2e-5
+        assert np.array_equal(outs["default"], outs["default again"])
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
