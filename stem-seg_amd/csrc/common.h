@@ -163,9 +163,16 @@ struct HeadSpec {
     int act[STEMSEG_MAX_EMB_DIMS * 2];
     int grid_axis[STEMSEG_MAX_EMB_DIMS * 2];
 };
+struct HeadsGN {               // the heads read a RAW conv output and apply GroupNorm + affine + ReLU on the fly (stats: (mean, rstd) per group, per clip)
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    int cpg;
+    int64_t stats_bs;
+};
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
                  const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb = ClipBatch(),
-                 const float* add = nullptr, int64_t add_bs = 0);
+                 const float* add = nullptr, int64_t add_bs = 0, const HeadsGN* gn = nullptr);
 int launch_level_head(const float* x, int Cin, int64_t V, const float* w, int n_out, const float* add, float* out, hipStream_t s, int nb, int64_t x_bs,
                       int64_t add_bs, int64_t out_bs);
 

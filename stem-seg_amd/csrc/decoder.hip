@@ -234,7 +234,7 @@ static inline StemsegVolume flat_volume(float* base, int C, int64_t V) {
 // the workspace (D, stats, scratch, dst) ws_bs floats
 static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b, const float* gw, const float* gb, int Cout, int T, int H,
                    int W, int pool, const StemsegVolume& dst, float* D, float* stats, double* scratch, int G, float eps, hipStream_t s,
-                   float* splitk, int64_t splitk_floats, int precision, int nb, int64_t in_bs, int64_t ws_bs) {
+                   float* splitk, int64_t splitk_floats, int precision, int nb, int64_t in_bs, int64_t ws_bs, bool apply = true) {
     StemsegVolume d = dense_volume(D, Cout, T, H, W);
     ConvEpilogue e;
     e.precision = precision;
@@ -244,12 +244,12 @@ static int conv_gn(const StemsegVolume& in_halo, const float* w, const float* b,
     if (G == 0) {      // NORMALIZATION_LAYER 'none' (model_builder.py:29-33): conv -> ReLU -> pool; gw / gb are ones / zeros from the caller
         int rc0 = launch_conv3d(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e);
         for (int c = 0; c < nb && !rc0; ++c) rc0 = launch_gn_identity_stats(stats + c * ws_bs, 1, s);
-        if (rc0) return rc0;
+        if (rc0 || !apply) return rc0;      // (!apply: the consumer normalises as it reads D -- the heads of the linear tail)
         return launch_gn_relu_pool(D, Cout, T, H, W, 1, stats, gw, gb, pool, dst, s, cb);
     }
     // the conv's epilogue (or its split-K reduce) leaves the GroupNorm partial sums: its output is not read again for them
     int rc = launch_conv3d_gn(in_halo, w, b, d, 3, 3, 3, 0, s, splitk, splitk_floats, &e, G, eps, stats, scratch, ws_bs);
-    if (rc) return rc;
+    if (rc || !apply) return rc;
     return launch_gn_relu_pool(D, Cout, T, H, W, G, stats, gw, gb, pool, dst, s, cb);
 }
 
@@ -498,7 +498,8 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     if (bs) SS_HIP(hipEventRecord(bs->done[2], s8));
     // 4. block_4x on the caller's stream into cat4[c8:], join 8x, fuse  (:125-129)
     rc = conv_gn(padded_halo_view(pin[3], p.cin, T, p.h[3], p.w[3]), wts->conv_w[6], wts->conv_b[6], wts->gn_w[6], wts->gn_b[6], p.c4, T, p.h[3],
-                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision, nb, pin_bs[3], WS);
+                 p.w[3], 0, slice_volume(ws + p.cat4, p.c8, p.c4, T, p.h[3], p.w[3]), D[3], stats[3], scratch[3], G, eps, sm, ws + p.S[3], p.Sfloats[3], desc->precision, nb, pin_bs[3], WS,
+                 /* the linear tail's heads are the only reader of the normalised 4x map: they normalise the raw conv output as they read it */ !lin_tail);
     if (rc) return rc;
     if (bs) SS_HIP(hipStreamWaitEvent(sm, bs->done[2], 0));
     // conv_4 (1x1x1, no bias, no activation: embedding_decoder.py:80,129) feeds nothing but the heads (1x1x1 as well): a caller that hands over
@@ -506,7 +507,9 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
     // the concat buffer: the c4-channel map (106 MB per clip at 480p) is neither computed, written nor read back.  One linear map instead of two:
     // the same fold as FrozenBN into its convolution, results within fp32 round-off of the two-step form.
     const bool fold4 = wts->fuse_w[2] == nullptr;
-    const float* head_in = lin_tail ? ws + p.cat4 + (int64_t)p.c8 * V4 : (fold4 ? ws + p.cat4 : ws + p.X4);      // (linear tail: the 4x branch's own half)
+    const float* head_in = lin_tail ? D[3] : (fold4 ? ws + p.cat4 : ws + p.X4);      // (linear tail: the 4x branch's RAW conv output, normalised on the fly)
+    HeadsGN hgn;
+    hgn.stats = stats[3]; hgn.gamma = wts->gn_w[6]; hgn.beta = wts->gn_b[6]; hgn.cpg = G > 0 ? p.c4 / G : p.c4; hgn.stats_bs = WS;
     const int head_cin = lin_tail ? p.c4 : (fold4 ? p.c8 + p.c4 : p.c4);
     if (!fold4) {
         rc = launch_conv3d(flat_volume(ws + p.cat4, p.c8 + p.c4, V4), wts->fuse_w[2], nullptr, flat_volume(ws + p.X4, p.c4, V4), 1, 1, 1, 0, sm, ws + p.S[3], p.Sfloats[3], &fuse_epi);
@@ -527,7 +530,7 @@ extern "C" int stemseg_hip_decoder_forward(const StemsegDecoderDesc* desc, const
         ClipBatch hb;
         hb.nb = nb; hb.in_bs = WS; hb.out_bs = p.out_bs;
         rc = launch_heads(head_in, head_cin, T, p.h[3], p.w[3], lin_tail ? M4 : wts->head_w, wts->head_b, hs, wts->grid_t, wts->grid_y, wts->grid_x, out, sm, hb,
-                          lin_tail ? up4 : nullptr, WS);
+                          lin_tail ? up4 : nullptr, WS, lin_tail ? &hgn : nullptr);
         if (rc) return rc;
     }
     if (detached) SS_HIP(hipEventRecord(bs->done[3], sm));

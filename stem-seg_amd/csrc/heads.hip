@@ -20,6 +20,11 @@ struct HeadsParams {
     const float* gy;
     const float* gx;
     const float* add;              // optional [n_out][V] term added to the linear part before bias / activation (the linear tail of the decoders)
+    const float* gn_stats;         // optional: x is a RAW conv output; GroupNorm (mean, rstd per group) + affine + ReLU are applied as it is read --
+    const float* gn_gamma;         // relu(fma(x, rstd gamma, beta - mean rstd gamma)), the expressions of gn_relu_stream_kernel (norm_pool.hip), so the
+    const float* gn_beta;          // normalised map the heads are the only reader of is never written
+    int gn_cpg;
+    int64_t gn_stats_bs;
     float* out;
     int Cin, T, H, W;
     int64_t V;
@@ -41,10 +46,21 @@ __device__ __forceinline__ float head_act(float z, int act, float grid) {
 // one thread = 4 consecutive voxels (float4 loads along W), NOUT accumulators each
 template <int NOUT>
 __global__ __launch_bounds__(256) void heads_kernel(HeadsParams p) {
-    extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [NOUT][Cin]
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [NOUT][Cin] (+ [2][Cin]: the GroupNorm scale / shift per channel)
     p.x += (int64_t)blockIdx.y * p.x_bs; p.out += (int64_t)blockIdx.y * p.out_bs;
     if (p.add) p.add += (int64_t)blockIdx.y * p.add_bs;
     for (int i = threadIdx.x; i < NOUT * p.Cin; i += blockDim.x) w_lds[i] = p.w[i];
+    float* ab = w_lds + NOUT * p.Cin;
+    if (p.gn_stats) {
+        const float* st = p.gn_stats + (int64_t)blockIdx.y * p.gn_stats_bs;
+        for (int c = threadIdx.x; c < p.Cin; c += blockDim.x) {
+            const int g = c / p.gn_cpg;
+            const float a = st[2 * g + 1] * p.gn_gamma[c];
+            const float b = p.gn_beta[c] - st[2 * g] * a;
+            ab[c] = a;
+            ab[p.Cin + c] = b;
+        }
+    }
     __syncthreads();
     const int64_t nq = p.V / 4;
     const int64_t HW = (int64_t)p.H * p.W;
@@ -57,6 +73,14 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadsParams p) {
             float4 xv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) xv[k] = xp[(int64_t)(c + k) * nq];
+            if (p.gn_stats) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = ab[c + k], b = ab[p.Cin + c + k];
+                    xv[k].x = relu_keep_nan(fmaf(xv[k].x, a, b)); xv[k].y = relu_keep_nan(fmaf(xv[k].y, a, b));
+                    xv[k].z = relu_keep_nan(fmaf(xv[k].z, a, b)); xv[k].w = relu_keep_nan(fmaf(xv[k].w, a, b));
+                }
+            }
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 const float4 wv = *reinterpret_cast<const float4*>(w_lds + o * p.Cin + c);   // LDS broadcast
@@ -97,7 +121,7 @@ template <int NOUT>
 static int launch_heads_n(const HeadsParams& p, int nb, hipStream_t s) {
     const int64_t nq = p.V / 4;
     const int blocks = (int)std::min<int64_t>(ceil_div(nq, 256), 256 * 8);
-    hipLaunchKernelGGL(heads_kernel<NOUT>, dim3(blocks, (unsigned)nb), dim3(256), (size_t)NOUT * p.Cin * sizeof(float), s, p);
+    hipLaunchKernelGGL(heads_kernel<NOUT>, dim3(blocks, (unsigned)nb), dim3(256), (size_t)(NOUT + 2) * p.Cin * sizeof(float), s, p);
     SS_LAUNCH_CHECK();
     return STEMSEG_OK;
 }
@@ -159,7 +183,8 @@ int launch_level_head(const float* x, int Cin, int64_t V, const float* w, int n_
 }
 
 int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, const float* bias, const HeadSpec& hs,
-                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb, const float* add, int64_t add_bs) {
+                 const float* gt, const float* gy, const float* gx, float* out, hipStream_t s, const ClipBatch& cb, const float* add, int64_t add_bs,
+                 const HeadsGN* gn) {
     SS_CHECK_ARG(x && w && out && cb.nb >= 1 && cb.nb <= 65535 && cb.in_bs % 4 == 0 && cb.out_bs % 4 == 0, "heads: null pointer");
     SS_CHECK_ARG(hs.n_out >= 1 && hs.n_out <= STEMSEG_MAX_HEAD_OUT, "heads: n_out=%d unsupported (1..%d)", hs.n_out, STEMSEG_MAX_HEAD_OUT);
     SS_CHECK_ARG(Cin % 4 == 0 && W % 4 == 0, "heads: Cin %% 4 == 0 and W %% 4 == 0 required (Cin=%d, W=%d)", Cin, W);
@@ -169,6 +194,9 @@ int launch_heads(const float* x, int Cin, int T, int H, int W, const float* w, c
     p.Cin = Cin; p.T = T; p.H = H; p.W = W; p.V = (int64_t)T * H * W;
     p.x_bs = cb.in_bs; p.out_bs = cb.out_bs;
     p.add = add; p.add_bs = add_bs;
+    p.gn_stats = gn ? gn->stats : nullptr; p.gn_gamma = gn ? gn->gamma : nullptr; p.gn_beta = gn ? gn->beta : nullptr;
+    p.gn_cpg = gn ? gn->cpg : 1; p.gn_stats_bs = gn ? gn->stats_bs : 0;
+    SS_CHECK_ARG(!gn || (gn->stats && gn->gamma && gn->beta && gn->cpg > 0 && Cin % gn->cpg == 0), "heads: bad GroupNorm arguments");
     SS_CHECK_ARG(!add || (reinterpret_cast<uintptr_t>(add) % 16 == 0 && add_bs % 4 == 0), "heads: 16-byte aligned addend");
     const int nb = cb.nb;
     for (int o = 0; o < HEADS_MAX_OUT; ++o) { p.act[o] = 0; p.axis[o] = 0; }
