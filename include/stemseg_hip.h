@@ -228,10 +228,18 @@ typedef struct StemsegDecoderWeights {
     const float* conv_b[7];
     const float* gn_w[7];
     const float* gn_b[7];
-    const float* fuse_w[3];      /* conv_16, conv_8, conv_4 (1x1x1, no bias), packed layout.  fuse_w[2] = NULL: conv_4 is FOLDED into the heads --
-                                    head_w then holds W_heads . W_conv4 over the inter[2] + inter[3] channels of the last concat buffer (dense
-                                    [n_out][inter[2] + inter[3]], or the packed 1x1x1 weight with that Cin for a wide head) and the inter[3]-channel
-                                    map is never materialised (one linear map for two: within fp32 round-off of the two-step form) */
+    const float* fuse_w[3];      /* conv_16, conv_8, conv_4 (1x1x1, no bias), packed layout.  Between the last GroupNorm + ReLU of a branch and the
+                                    heads' activations the decoder is LINEAR (up-sampling, concatenation, these convs, the 1x1x1 heads), and a
+                                    caller may hand over the product matrices instead of the factors:
+                                    * fuse_w[2] = NULL: conv_4 folded into the heads -- head_w = W_heads . W_conv4 over the inter[2] + inter[3]
+                                      channels of the last concat buffer (dense [n_out][inter[2] + inter[3]], or the packed 1x1x1 weight with that
+                                      Cin for a wide head); the inter[3]-channel map is never materialised;
+                                    * fuse_w[0..2] = NULL (n_out <= STEMSEG_MAX_HEAD_OUT): the whole tail folded -- 1x1x1 convs commute with
+                                      up-sampling, so heads(x) = up(up(up(M32 x32) + M16 y16) + M8 y8) + M4 y4 and head_w = [M32 | M16 | M8 | M4],
+                                      M_l dense [n_out][inter[l]] (M4 = Wh W4b, M8 = Wh W4a W8b, M16 = Wh W4a W8a W16b, M32 = Wh W4a W8a W16a for
+                                      W = [Wa | Wb] over the (up-sampled, own) halves of a concat input): every level adds its n_out-channel
+                                      share at its own resolution, and the heads normalise the 4x branch's raw conv output as they read it.
+                                    Either way the same function, within fp32 round-off of the step-by-step form. */
     const float* head_w;         /* [n_out][inter[3]] row-major */
     const float* head_b;         /* [n_out] (zero where the reference conv has no bias) */
     const float* grid_t;         /* [T], [H4], [W4] linspace vectors (may be NULL if no act uses the grid) */
