@@ -431,6 +431,58 @@ __global__ __launch_bounds__(256) void upsample2x_add_vec4x2_kernel(float* __res
     if (row_b) *reinterpret_cast<float4*>(fbase + (int64_t)(2 * m + 1) * f_pitch) = fb;
 }
 
+// The same two-row form reading the fine term from a DENSE [planes][H][W] map (the lateral conv's output written by the 16-byte epilogue; its
+// by-element epilogue into the zero-haloed layout issued four times the store instructions and ran at 2.2 TB/s) and writing the zero-haloed
+// consumer layout: the layout change rides on the pass that touches every element anyway.  A group's four map columns 4k - 1 .. 4k + 2 straddle two
+// aligned dense groups: two 16-byte loads per row (the first is the neighbouring thread's second: an L1 hit).  Halo words of a group are written
+// as zero.  Same expression per output as the in-place form => the same bits.
+__global__ __launch_bounds__(256) void upsample2x_add_dense_vec4x2_kernel(float* __restrict__ fine_halo, const float* __restrict__ fine_dense,
+                                                                           const float* __restrict__ coarse, int H, int W, unsigned gq, unsigned n_items,
+                                                                           int64_t f_ts, int f_pitch, int64_t c_ts, int c_pitch) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= n_items) return;
+    const int Hc = H / 2, Wc = W / 2;
+    const unsigned rowp = idx / gq;                          // plane * (Hc + 1) + m
+    const int k = (int)(idx - rowp * gq);
+    const unsigned pl = rowp / (unsigned)(Hc + 1);
+    const int m = (int)(rowp - pl * (unsigned)(Hc + 1));
+    const bool row_a = m >= 1, row_b = m < Hc;               // rows 2m - 1, 2m
+    const int y0 = m >= 1 ? m - 1 : 0, y1 = y0 + (y0 < Hc - 1 ? 1 : 0);
+    const float wy_a = 0.25f, wy_b = m >= 1 ? 0.75f : 0.f;
+    const float* c0 = coarse + (int64_t)pl * c_ts + (int64_t)y0 * c_pitch;
+    const float* c1 = coarse + (int64_t)pl * c_ts + (int64_t)y1 * c_pitch;
+    const int xa = min(max(2 * k - 1, 0), Wc - 1), xb = min(2 * k, Wc - 1), xc = min(2 * k + 1, Wc - 1);
+    const float a0 = c0[xa], b0 = c0[xb], d0 = c0[xc], a1 = c1[xa], b1 = c1[xb], d1 = c1[xc];
+    const float* dbase = fine_dense + (int64_t)pl * H * W;
+    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+    // map columns 4k - 1 .. 4k + 2 of rows 2m - 1 / 2m: the last word of dense group k - 1 and the first three of group k (W % 4 == 0)
+    const bool g_lo = k >= 1, g_hi = 4 * k < W;
+    if (row_a) {
+        const float* r = dbase + (int64_t)(2 * m - 1) * W;
+        if (g_lo) va[0] = reinterpret_cast<const float4*>(r)[k - 1].w;
+        if (g_hi) { const float4 q = reinterpret_cast<const float4*>(r)[k]; va[1] = q.x; va[2] = q.y; va[3] = q.z; }
+    }
+    if (row_b) {
+        const float* r = dbase + (int64_t)(2 * m) * W;
+        if (g_lo) vb[0] = reinterpret_cast<const float4*>(r)[k - 1].w;
+        if (g_hi) { const float4 q = reinterpret_cast<const float4*>(r)[k]; vb[1] = q.x; vb[2] = q.y; vb[3] = q.z; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = 4 * k - 1 + j;
+        if (x < 0 || x >= W) { va[j] = 0.f; vb[j] = 0.f; continue; }      // halo words of the group
+        const bool first = j < 2 && x > 0;
+        const float p0 = first ? a0 : (x == 0 ? a0 : b0), p1 = first ? b0 : d0;
+        const float q0 = first ? a1 : (x == 0 ? a1 : b1), q1 = first ? b1 : d1;
+        const float wx = x == 0 ? 0.f : ((x & 1) ? 0.25f : 0.75f);
+        if (row_a) va[j] = __fadd_rn(va[j], up2_blend(p0, p1, q0, q1, wx, wy_a));
+        if (row_b) vb[j] = __fadd_rn(vb[j], up2_blend(p0, p1, q0, q1, wx, wy_b));
+    }
+    float* fbase = fine_halo + (int64_t)pl * f_ts + 4 * k;
+    if (row_a) *reinterpret_cast<float4*>(fbase + (int64_t)(2 * m) * f_pitch) = make_float4(va[0], va[1], va[2], va[3]);            // (row y sits at haloed row y + 1)
+    if (row_b) *reinterpret_cast<float4*>(fbase + (int64_t)(2 * m + 1) * f_pitch) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+}
+
 static int grid1d(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 256), 256 * 16)); }
 
 struct EncoderPlan {
@@ -723,10 +775,33 @@ extern "C" int stemseg_hip_encoder_forward(const StemsegEncoderDesc* desc, const
         const int h = p.h[k], w = p.w[k];
         ConvEpilogue e = epi_for(T), el = epi_for(T);
         e.dec_H = h; e.dec_W = w;
+        // Levels with a top-down term: the lateral conv writes a DENSE map (16-byte epilogue: its by-element epilogue into the zero-haloed layout
+        // issued four times the store instructions -- 770 us for the 4x level's 1.7 GB) into the idle block buffer A, and the add pass, which
+        // touches every element anyway, writes the zero-haloed layout.  Same tile, same sums: the same bits (STEMSEG_FPN_LATERAL_DENSE=0: in place).
+        Padded2D gf0(256, T, h, w);
+        static const bool lat_dense_on = [] { const char* e = getenv("STEMSEG_FPN_LATERAL_DENSE"); return !(e && e[0] == '0'); }();
+        const unsigned gq0 = (unsigned)((w + 1) / 4 + 1);
+        const bool lat_dense = lat_dense_on && k < 3 && h % 2 == 0 && w % 4 == 0 && p.h[k + 1] == h / 2 && p.w[k + 1] == w / 2 && gf0.pitch % 4 == 0 &&
+                               (int64_t)4 * gq0 <= gf0.pitch && (int64_t)256 * T * (h / 2 + 1) * gq0 < (1ll << 32) - 256 &&
+                               (reinterpret_cast<uintptr_t>(ws + p.L[k]) % 16 == 0) && gf0.ts % 4 == 0 && (reinterpret_cast<uintptr_t>(ws + p.A) % 16 == 0);
+        if (lat_dense) {
+            ConvEpilogue ed = epi_for(T);
+            rc = launch_conv3d(flat_view(ws + p.Cst[k], 256 << k, p.V[k]), wts->fpn_inner_w[k], wts->fpn_inner_b[k], flat_view(ws + p.A, 256, p.V[k]), 1, 1, 1, 0, s,
+                               ws + p.SK, p.SKfloats, &ed);
+            if (rc) return rc;
+            Padded2D gc0(256, T, p.h[k + 1], p.w[k + 1]);
+            void* ev = profile_begin(50, 4.0 * 256.0 * (2.0 * p.V[k] + p.V[k + 1]), s);
+            const int64_t items = (int64_t)256 * T * (h / 2 + 1) * gq0;
+            hipLaunchKernelGGL(upsample2x_add_dense_vec4x2_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, s, ws + p.L[k], (const float*)(ws + p.A),
+                               (const float*)(ws + p.L[k + 1] + gc0.interior), h, w, gq0, (unsigned)items, gf0.ts, (int)gf0.pitch, gc0.ts, (int)gc0.pitch);
+            profile_end(ev, s);
+            SS_LAUNCH_CHECK();
+        } else {
         rc = launch_conv3d(flat_view(ws + p.Cst[k], 256 << k, p.V[k]), wts->fpn_inner_w[k], wts->fpn_inner_b[k], interior2d_view(ws + p.L[k], 256, T, h, w), 1, 1, 1, 0, s,
                            ws + p.SK, p.SKfloats, &e);
         if (rc) return rc;
-        if (k < 3) {
+        }
+        if (k < 3 && !lat_dense) {
             // (Measured in round 5 and not kept: the add fused into the lateral conv's epilogue -- four gathered coarse loads per output
             // element in the by-element epilogue of a flat launch.  The separate pass goes (-0.22 ms per clip), the 1x1 class pays +0.38 ms
             // and every tile's kernel arguments grow: the step 103.0 vs 104.8 clips/s, interleaved on one box.)
