@@ -383,3 +383,50 @@ def test_instances_to_keep_and_mask_lut_vs_golden(golden):
             assert lut[k + 1] == n + 1
         assert sum(1 for v in lut if v) == len(keep)
     assert instances_to_keep({3: 5, 1: 5, -1: 9, 2: 7}, -1, 2) == [2, 3]      # ties keep the dict's order; outlier dropped
+
+
+def test_linear_tail_matrices_reproduce_the_step_by_step_tail():
+    """SqueezeExpandTrunk._linear_tail (the decoders' default since round 6): between the last GroupNorm + ReLU of every branch and the heads'
+    activations the reference applies only linear maps -- trilinear up-sampling, concatenation, the bias-free 1x1x1 convs conv_16 / conv_8 / conv_4
+    and the 1x1x1 heads (embedding_decoder.py:64-80,112-143) -- and 1x1x1 convs commute with up-sampling.  The four per-level matrices must
+    reproduce that tail: here in torch on the CPU, fp64 (exact algebra) and fp32 (round-off), with temporal scales (1, 2, 2) as at T = 8."""
+    import torch
+    import torch.nn.functional as F
+    from stemseg_amd.modeling.seediness_decoder import SqueezingExpandDecoder as Seed
+    from stemseg_amd.modeling.embedding_decoder import SqueezingExpandDecoder as Emb
+    torch.manual_seed(3)
+    for make in (lambda: Seed(256, [64, 48, 32, 24], num_frames=8), lambda: Emb(256, [64, 48, 32, 24], 5, True, True, "xytff", num_frames=8)):
+        m = make().eval()
+        for prm in m.parameters():
+            with torch.no_grad():
+                prm.normal_(0, 0.3)
+        c32, c16, c8, c4 = m.inter_channels
+        m.fold_linear_tail = False          # (the dense [n_out, c4] head matrix, as the reference's heads hold it)
+        m.fold_conv4 = False
+        wh = m._head_spec()[0].detach()
+        n_out = wh.shape[0]
+        for dt, tol in ((torch.float64, 1e-11), (torch.float32, 2e-4)):
+            x32 = torch.randn(1, c32, 2, 3, 5, dtype=dt)
+            y16 = torch.randn(1, c16, 2, 6, 10, dtype=dt)
+            y8 = torch.randn(1, c8, 4, 12, 20, dtype=dt)
+            y4 = torch.randn(1, c4, 8, 24, 40, dtype=dt)
+            up = lambda t, ts: F.interpolate(t, scale_factor=(ts, 2, 2), mode="trilinear", align_corners=False)
+            x = up(x32, 1)
+            x = F.conv3d(torch.cat((x, y16), 1), m.conv_16.weight.detach().to(dt))
+            x = up(x, 2)
+            x = F.conv3d(torch.cat((x, y8), 1), m.conv_8.weight.detach().to(dt))
+            x = up(x, 2)
+            x = F.conv3d(torch.cat((x, y4), 1), m.conv_4.weight.detach().to(dt))
+            ref = F.conv3d(x, wh.to(dt).reshape(n_out, c4, 1, 1, 1))
+            m32, m16, m8, m4 = [q.to(dt) for q in m._linear_tail(wh.double() if dt == torch.float64 else wh)]
+            if dt == torch.float64:         # (the matrices are handed over in fp32; the algebra is checked on their fp64 values)
+                w4 = m.conv_4.weight.detach().reshape(c4, c8 + c4).double(); w8 = m.conv_8.weight.detach().reshape(c8, c16 + c8).double()
+                w16 = m.conv_16.weight.detach().reshape(c16, c32 + c16).double()
+                a = wh.double() @ w4[:, :c8]; b = a @ w8[:, :c16]
+                m4, m8, m16, m32 = wh.double() @ w4[:, c8:], a @ w8[:, c16:], b @ w16[:, c32:], b @ w16[:, :c32]
+            lin = lambda mat, t: F.conv3d(t, mat.reshape(mat.shape[0], mat.shape[1], 1, 1, 1))
+            z = up(lin(m32, x32), 1) + lin(m16, y16)
+            z = up(z, 2) + lin(m8, y8)
+            z = up(z, 2) + lin(m4, y4)
+            err = float((z - ref).abs().max() / ref.abs().max())
+            assert err <= tol, (type(m).__module__, dt, err)
